@@ -1,0 +1,162 @@
+"""ORACLE TOOLING -- build-container only.  Writes tests/golden/*.npz by RUNNING THE REAL REFERENCE
+(/root/reference, imported in place through oracle/ref_shim.py) on seeded synthetic inputs.
+
+    python -m oracle.make_goldens            # regenerate every fixture
+
+Fixtures hold expected OUTPUTS (+ a sha1 of the regenerated inputs, to catch generator drift); inputs
+are rebuilt from seeds by tfpnp_amd.synth.  No reference source text is stored anywhere.
+"""
+import hashlib
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim  # noqa: E402
+from tfpnp_amd import synth  # noqa: E402
+from tests.golden_inputs import (WEIGHT_SEED, sha, denoiser_inputs, complex_inputs, csmri_actions,  # noqa: E402
+                                 spi_grid)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+def save(name, **kw):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in kw.items()})
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KB)")
+
+
+def main():
+    assert ref_shim.available(), "reference not mounted"
+    ref_shim.install()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    from tfpnp.utils import transforms as T
+    from tfpnp.pnp.denoiser.models.unet import UNet
+    from tfpnp.env.base import torch_psnr
+
+    params = synth.make_unet_params(WEIGHT_SEED)
+    tmp = tempfile.mkdtemp()
+    den = ref_shim.make_denoiser(params, tmp)
+    assert [k for k, _ in synth.unet_param_specs()] == list(den.net.state_dict().keys())
+
+    with torch.no_grad():
+        # (1) denoiser: UNet pre-clamp and UNetDenoiser2D post-clamp
+        print("[1] denoiser")
+        for (B, H, W, seed) in [(2, 32, 32, 11), (2, 64, 64, 12), (1, 128, 128, 13), (2, 48, 80, 14)]:
+            x, sigma = denoiser_inputs(B, H, W, seed)
+            xin = torch.cat([t(x), torch.ones(B, 1, H, W) * t(sigma).view(B, 1, 1, 1)], 1)
+            pre = den.net(xin)
+            post = den(t(x), t(sigma))
+            save(f"denoiser_B{B}_{H}x{W}", pre=pre, post=post, in_sha=sha(x, sigma))
+
+        # (2) centered FFTs
+        print("[2] fft2/ifft2")
+        for shape, seed in [((2, 1, 16, 32), 21), ((1, 1, 128, 128), 22), ((2, 1, 6, 10), 23), ((1, 2, 64, 8), 24)]:
+            x = complex_inputs(shape, seed)
+            save("fft_" + "x".join(map(str, shape)), fwd=T.fft2(t(x)), inv=T.ifft2(t(x)), in_sha=sha(x))
+
+        # (3) CS-MRI solvers
+        print("[3] CS-MRI solvers")
+        cs = ref_shim.load_task_module("csmri", "solver")
+        for (B, H, W, seed) in [(2, 64, 64, 31), (1, 128, 128, 32)]:
+            d = synth.make_csmri_batch(B, H, W, ratio=4, sigma_n=15.0, seed=seed)
+            y0, mask, x0 = t(d["y0"]), t(d["mask"]), t(d["x0"])
+            sol = cs.ADMMSolver_CSMRI(den)
+            v0 = sol.reset({"x0": x0})
+            out = {}
+            for Tn in ([1, 5] if H == 64 else [5]):
+                a = csmri_actions(B, Tn, seed + Tn)
+                out[f"admm_T{Tn}"] = sol((v0, (y0, mask)), (t(a["sigma_d"]), t(a["mu"])))
+            if H == 64:
+                # full 6 x 5 episode with the bench schedule
+                acts = synth.make_actions(B)
+                v = v0
+                for a in acts:
+                    v = sol((v, (y0, mask)), (t(a["sigma_d"]), t(a["mu"])))
+                out["admm_6x5"] = v
+                out["admm_6x5_output"] = sol.get_output(v)
+                a = csmri_actions(B, 5, seed + 100, ("sigma_d", "mu", "tau", "beta", "lamda"))
+                hq = cs.HQSSolver_CSMRI(den)
+                out["hqs_T5"] = hq((hq.reset({"x0": x0}), (y0, mask)), (t(a["sigma_d"]), t(a["mu"])))
+                pg = cs.PGSolver_CSMRI(den)
+                out["pg_T5"] = pg((pg.reset({"x0": x0}), (y0, mask)), (t(a["sigma_d"]), t(a["tau"])))
+                ap = cs.APGSolver_CSMRI(den)
+                out["apg_T5"] = ap((ap.reset({"x0": x0}), (y0, mask)), (t(a["sigma_d"]), t(a["tau"]), t(a["beta"])))
+                rd = cs.REDADMMSolver_CSMRI(den)
+                out["red_T5"] = rd((rd.reset({"x0": x0}), (y0, mask)), (t(a["sigma_d"]), t(a["mu"]), t(a["lamda"])))
+            save(f"csmri_B{B}_{H}x{W}", in_sha=sha(d["y0"], d["mask"], d["x0"]), **out)
+
+        # (4) phase retrieval
+        print("[4] PR")
+        pr = ref_shim.load_task_module("pr", "solver")
+        B, H, W, S, seed = 2, 64, 64, 4, 41
+        d = synth.make_pr_batch(B, H, W, S=S, alpha=9.0, seed=seed)
+        xc = complex_inputs((B, 1, H, W), seed + 1)
+        yc = complex_inputs((B, S, H, W), seed + 2)
+        a = csmri_actions(B, 5, seed + 3, ("sigma_d", "mu", "tau"))
+        a["tau"] = (a["tau"] * 0.5).astype(np.float32)
+        sol = pr.IADMMSolver_PR(den)
+        v0 = sol.reset({"x0": t(d["x0"])})
+        st = sol((v0, (t(d["y0"]), t(d["mask"]))), (t(a["sigma_d"]), t(a["mu"]), t(a["tau"])))
+        save("pr_B2_64x64", cdp_fwd=T.cdp_forward(t(xc), t(d["mask"])), cdp_bwd=T.cdp_backward(t(yc), t(d["mask"])),
+             iadmm_T5=st, iadmm_T5_output=sol.get_output(st), in_sha=sha(d["y0"], d["mask"], xc, yc))
+
+        # (5) SPI
+        print("[5] SPI")
+        spi = ref_shim.load_task_module("spi", "solver")
+        zt, K1, K, mu = spi_grid()
+        zi = T.spi_inverse(t(zt), t(K1), t(K), t(mu))
+        B, H, W, seed = 2, 64, 64, 51
+        d = synth.make_spi_batch(B, H, W, K=6, seed=seed)
+        rs = np.random.RandomState(seed + 1)
+        sg = rs.uniform(15 / 255.0, 70 / 255.0, (B, 4)).astype(np.float32)
+        m = rs.uniform(50, 120, (B, 4)).astype(np.float32)
+        sol = spi.ADMMSolver_SPI(den)
+        v0 = sol.reset({"x0": t(d["x0"])})
+        st = sol((v0, (t(d["x0"]), t(d["K"]))), (t(sg), t(m)))
+        save("spi_B2_64x64", spi_inverse=zi, admm_T4=st, in_sha=sha(zt, K1, d["x0"], sg, m))
+
+        # (6) PSNR
+        print("[6] psnr")
+        rs = np.random.RandomState(61)
+        o = rs.uniform(-0.2, 1.2, (3, 1, 32, 48)).astype(np.float32)
+        g = rs.uniform(0, 1, (3, 1, 32, 48)).astype(np.float32)
+        save("psnr", psnr=torch_psnr(t(o), t(g)), in_sha=sha(o, g))
+
+        # (7) env.step contract: 3 items, idx_stop=[0,1,0] then [1,0]
+        print("[7] env step")
+        env_mod = ref_shim.load_task_module("csmri", "env")
+        B, H, W, seed = 3, 32, 32, 71
+        d = synth.make_csmri_batch(B, H, W, ratio=4, sigma_n=15.0, seed=seed)
+        data = {k: t(v) for k, v in d.items()}
+        env = env_mod.CSMRIEnv(None, cs.ADMMSolver_CSMRI(den), max_episode_step=3)
+        env.reset(data={k: v.clone() for k, v in data.items()})
+        out = {}
+        stops = [np.array([0, 1, 0]), np.array([1, 0]), np.array([0])]
+        for s, stop in enumerate(stops):
+            nb = len(stop)
+            a = csmri_actions(nb, 2, seed + 10 + s)
+            action = {"sigma_d": t(a["sigma_d"]), "mu": t(a["mu"]), "idx_stop": torch.from_numpy(stop)}
+            ob, ob_masked, reward, all_done, info = env.step(action)
+            out[f"reward{s}"] = reward
+            out[f"done{s}"] = info["done"]
+            out[f"all_done{s}"] = np.array(all_done)
+            out[f"solver{s}"] = env.state["solver"].clone()
+            out[f"output{s}"] = env.state["output"].clone()
+            out[f"idx_left{s}"] = env.idx_left.clone()
+        save("env_step_csmri", in_sha=sha(d["y0"], d["mask"], d["x0"]), **out)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+"""Pins oracle/pnp_oracle.py (the CPU restatement) to outputs of the REAL reference stored in
+tests/golden/*.npz (written by oracle/make_goldens.py in the build container).  CPU-only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pnp_oracle as O
+from tests.conftest import golden
+from tests.golden_inputs import sha, denoiser_inputs, complex_inputs, csmri_actions, spi_grid
+from tfpnp_amd import synth
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel(a, b):
+    a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+
+
+TOL = 2e-6  # oracle vs reference: same fp32 arithmetic, only op-order noise allowed
+
+
+@pytest.fixture(scope="module")
+def den(unet_params):
+    torch.set_num_threads(8)
+    return O.Denoiser(unet_params)
+
+
+@pytest.mark.parametrize("B,H,W,seed", [(2, 32, 32, 11), (2, 64, 64, 12), (1, 128, 128, 13), (2, 48, 80, 14)])
+def test_denoiser(unet_params, B, H, W, seed):
+    g = golden(f"denoiser_B{B}_{H}x{W}")
+    x, sigma = denoiser_inputs(B, H, W, seed)
+    assert (sha(x, sigma) == g["in_sha"]).all()
+    xin = torch.cat([t(x), torch.ones(B, 1, H, W) * t(sigma).view(B, 1, 1, 1)], 1)
+    assert rel(O.unet_forward(xin, unet_params), g["pre"]) < TOL
+    assert rel(O.denoise(t(x), t(sigma), unet_params), g["post"]) < TOL
+
+
+@pytest.mark.parametrize("shape,seed", [((2, 1, 16, 32), 21), ((1, 1, 128, 128), 22), ((2, 1, 6, 10), 23),
+                                        ((1, 2, 64, 8), 24)])
+def test_fft(shape, seed):
+    g = golden("fft_" + "x".join(map(str, shape)))
+    x = complex_inputs(shape, seed)
+    assert (sha(x) == g["in_sha"]).all()
+    assert rel(O.fft2c(t(x)), g["fwd"]) < TOL
+    assert rel(O.ifft2c(t(x)), g["inv"]) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,seed", [(2, 64, 64, 31), (1, 128, 128, 32)])
+def test_csmri(den, B, H, W, seed):
+    g = golden(f"csmri_B{B}_{H}x{W}")
+    d = synth.make_csmri_batch(B, H, W, ratio=4, sigma_n=15.0, seed=seed)
+    assert (sha(d["y0"], d["mask"], d["x0"]) == g["in_sha"]).all()
+    y0, mask, x0 = t(d["y0"]), t(d["mask"]), t(d["x0"])
+    v0 = O.admm_reset(x0)
+    for Tn in ([1, 5] if H == 64 else [5]):
+        a = csmri_actions(B, Tn, seed + Tn)
+        assert rel(O.csmri_admm(den, v0, y0, mask, t(a["sigma_d"]), t(a["mu"])), g[f"admm_T{Tn}"]) < 5e-6
+    if H != 64:
+        return
+    v = v0
+    for a in synth.make_actions(B):
+        v = O.csmri_admm(den, v, y0, mask, t(a["sigma_d"]), t(a["mu"]))
+    assert rel(v, g["admm_6x5"]) < 2e-5
+    assert rel(O.complex2real(v[:, :1]), g["admm_6x5_output"]) < 2e-5
+    a = {k: t(v) for k, v in csmri_actions(B, 5, seed + 100, ("sigma_d", "mu", "tau", "beta", "lamda")).items()}
+    assert rel(O.csmri_hqs(den, torch.cat([x0, x0], 1), y0, mask, a["sigma_d"], a["mu"]), g["hqs_T5"]) < 5e-6
+    assert rel(O.csmri_pg(den, x0, y0, mask, a["sigma_d"], a["tau"]), g["pg_T5"]) < 5e-6
+    assert rel(O.csmri_apg(den, torch.cat([x0, x0], 1), y0, mask, a["sigma_d"], a["tau"], a["beta"]),
+               g["apg_T5"]) < 5e-6
+    assert rel(O.csmri_redadmm(den, v0, y0, mask, a["sigma_d"], a["mu"], a["lamda"]), g["red_T5"]) < 5e-6
+
+
+def test_pr(den):
+    g = golden("pr_B2_64x64")
+    B, H, W, S, seed = 2, 64, 64, 4, 41
+    d = synth.make_pr_batch(B, H, W, S=S, alpha=9.0, seed=seed)
+    xc = complex_inputs((B, 1, H, W), seed + 1)
+    yc = complex_inputs((B, S, H, W), seed + 2)
+    assert (sha(d["y0"], d["mask"], xc, yc) == g["in_sha"]).all()
+    assert rel(O.cdp_forward(t(xc), t(d["mask"])), g["cdp_fwd"]) < TOL
+    assert rel(O.cdp_backward(t(yc), t(d["mask"])), g["cdp_bwd"]) < TOL
+    a = csmri_actions(B, 5, seed + 3, ("sigma_d", "mu", "tau"))
+    a["tau"] = (a["tau"] * 0.5).astype(np.float32)
+    st = O.pr_iadmm(den, O.pr_reset(t(d["x0"])), t(d["y0"]), t(d["mask"]), t(a["sigma_d"]), t(a["mu"]), t(a["tau"]))
+    assert rel(st, g["iadmm_T5"]) < 2e-5
+    assert rel(O.complex2real(st[:, :1]), g["iadmm_T5_output"]) < 2e-5
+
+
+def test_spi(den):
+    g = golden("spi_B2_64x64")
+    zt, K1, K, mu = spi_grid()
+    B, H, W, seed = 2, 64, 64, 51
+    d = synth.make_spi_batch(B, H, W, K=6, seed=seed)
+    rs = np.random.RandomState(seed + 1)
+    sg = rs.uniform(15 / 255.0, 70 / 255.0, (B, 4)).astype(np.float32)
+    m = rs.uniform(50, 120, (B, 4)).astype(np.float32)
+    assert (sha(zt, K1, d["x0"], sg, m) == g["in_sha"]).all()
+    zi = O.spi_inverse(t(zt), t(K1), t(K), t(mu))
+    assert np.array_equal(zi.numpy(), g["spi_inverse"])  # pointwise fp32, same op order: bit-exact
+    x0 = t(d["x0"])
+    st = O.spi_admm(den, O.admm_reset(x0), x0, t(d["K"]), t(sg), t(m))
+    assert rel(st, g["admm_T4"]) < 5e-6
+
+
+def test_psnr():
+    g = golden("psnr")
+    rs = np.random.RandomState(61)
+    o = rs.uniform(-0.2, 1.2, (3, 1, 32, 48)).astype(np.float32)
+    gg = rs.uniform(0, 1, (3, 1, 32, 48)).astype(np.float32)
+    assert (sha(o, gg) == g["in_sha"]).all()
+    assert np.allclose(O.torch_psnr(t(o), t(gg)).numpy(), g["psnr"], rtol=1e-6, atol=1e-5)
+
+
+def test_env_step(den):
+    g = golden("env_step_csmri")
+    B, H, W, seed = 3, 32, 32, 71
+    d = synth.make_csmri_batch(B, H, W, ratio=4, sigma_n=15.0, seed=seed)
+    assert (sha(d["y0"], d["mask"], d["x0"]) == g["in_sha"]).all()
+    env = O.CSMRIEnvOracle(den, max_episode_step=3)
+    env.reset({k: t(v) for k, v in d.items()})
+    stops = [np.array([0, 1, 0]), np.array([1, 0]), np.array([0])]
+    for s, stop in enumerate(stops):
+        a = csmri_actions(len(stop), 2, seed + 10 + s)
+        reward, all_done, done = env.step({"sigma_d": t(a["sigma_d"]), "mu": t(a["mu"]),
+                                           "idx_stop": torch.from_numpy(stop)})
+        assert np.allclose(reward.numpy(), g[f"reward{s}"], atol=2e-4)
+        assert np.array_equal(done.numpy(), g[f"done{s}"])
+        assert bool(all_done) == bool(g[f"all_done{s}"])
+        assert np.array_equal(env.idx_left.numpy(), g[f"idx_left{s}"])
+        assert rel(env.state["solver"], g[f"solver{s}"]) < 1e-5
+        assert rel(env.state["output"], g[f"output{s}"]) < 1e-5
+
+
+def test_radon_adjoint_and_disc():
+    """CT is parity-unpinned (no torch_radon here): check the oracle's own pair by mathematical properties."""
+    R, V = 32, 12
+    angles, det = O.radon_geometry(R, V)
+    assert det == int(np.ceil(np.sqrt(2) * R))
+    rs = np.random.RandomState(5)
+    # analytic: centred disc of radius r -> chord length 2*sqrt(r^2 - s^2)
+    yy, xx = np.meshgrid(np.arange(R) - R / 2 + 0.5, np.arange(R) - R / 2 + 0.5, indexing="ij")
+    r = 9.0
+    disc = ((xx ** 2 + yy ** 2) <= r * r).astype(np.float32)[None, None]
+    sino = O.radon_forward(t(disc), angles, det)
+    s = np.arange(det) - det / 2 + 0.5
+    chord = 2 * np.sqrt(np.clip(r * r - s * s, 0, None))
+    err = np.abs(sino.numpy()[0, 0] - chord[None]).mean()
+    assert err < 0.6
+    # forward/backprojection are near-adjoint (ray-driven vs pixel-driven pair, like torch_radon's)
+    x = t(rs.standard_normal((1, 1, R, R)).astype(np.float32))
+    y = t(rs.standard_normal((1, 1, V, det)).astype(np.float32))
+    lhs = float((O.radon_forward(x, angles, det) * y).sum())
+    rhs = float((x * O.radon_backprojection(y, angles, R)).sum())
+    assert abs(lhs - rhs) < 0.15 * (abs(lhs) + abs(rhs) + 1.0)
+    assert O.radon_opnorm(R, V) > 0
