@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Headline benchmark: CS-MRI PnP-ADMM, 256x256, env_batch=48 per GPU, 6 policy steps x 5 inner iterations.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one episode of the hot path over one resident batch: solver.reset, 6 x ADMMSolver_CSMRI.forward
+(5 inner iterations each: UNet denoiser prox + masked-FFT data prox + dual update), 6 x PSNR reward, and -- for
+N > 1 -- 6 all_gathers of the per-item rewards over RCCL.  No early stop.  Inputs (y0, mask, x0, gt, the action
+schedule, packed weights) are in HBM before the timed region starts.  Weak scaling: every rank owns its own 48
+items.  value = ADMM inner iterations (each over a 48-image batch) per second, summed over ranks.
+
+Prints ONE JSON line on rank 0 (fields: see the contract in the task statement) including
+  roofline     fp32-MFMA roofline of the dominant kernel (conv3x3), measured with HIP events per launch;
+  cpu_baseline the CPU oracle timed on the host cores on a bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from tfpnp_amd import dist as D  # noqa: E402
+from tfpnp_amd import ops, synth  # noqa: E402
+from tfpnp_amd.env import PnPEnv  # noqa: E402
+from tfpnp_amd.pnp import UNetDenoiser2D  # noqa: E402
+from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+N_POLICY_STEPS, ACTION_PACK = 6, 5
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=48, help="env_batch per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--ratio", type=int, default=4, help="radial mask undersampling (4 or 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16, help="items in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local_rank = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B, H, W = args.batch, args.size, args.size
+
+    # ---- resident inputs --------------------------------------------------------------------------
+    params = synth.make_unet_params(0)
+    den = UNetDenoiser2D(state_dict=params)
+    solver = ADMMSolver_CSMRI(den)
+    data_np = synth.make_csmri_batch(B, H, W, ratio=args.ratio, sigma_n=15.0, seed=1234 + 1000 * rank)
+    data = {k: t(v).to(dev) for k, v in data_np.items()}
+    actions = [{k: t(v).to(dev) for k, v in a.items()} for a in synth.make_actions(B, N_POLICY_STEPS, ACTION_PACK)]
+    for a in actions:
+        a["idx_stop"] = torch.zeros(B, dtype=torch.int64, device=dev)
+    den.context(dev).reserve(B, H, W)
+    env = PnPEnv(solver, max_episode_step=N_POLICY_STEPS)
+    n_global = B * world
+
+    def episode():
+        env.reset(data)
+        rewards = []
+        for a in actions:
+            reward, _, _ = env.step(a)
+            rewards.append(D.all_gather_rows(reward, n_global))       # [B*world, 1] on every rank
+        return rewards
+
+    for _ in range(args.warmup):
+        episode()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rewards = episode()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+
+    iters = N_POLICY_STEPS * ACTION_PACK * args.steps
+    value = world * iters / elapsed
+    final_psnr_gain = float(torch.stack(rewards).sum(0).mean().item())
+
+    out = {
+        "metric": "PnP-ADMM iters/sec (and images/sec) at env_batch=48, 256x256, 30 inner iters",
+        "value": value,
+        "unit": "iters/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"CS-MRI ADMM {H}x{W} env_batch={B}/GPU radial x{args.ratio} sigma_n=15, "
+                        f"{N_POLICY_STEPS} solver calls x {ACTION_PACK} inner iters + PSNR reward, no early stop",
+            "global_batch": n_global,
+            "iters_per_step": N_POLICY_STEPS * ACTION_PACK,
+            "parallelism": f"batch-shard x{world}, all_gather(reward) per env step" if world > 1 else "single GPU",
+        },
+        "images_per_s": n_global * args.steps / elapsed,
+        "image_iters_per_s": value * B,
+        "mean_psnr_gain_db": final_psnr_gain,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        out["roofline"] = roofline(den, dev, B, H, W)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"], out["parity_rel_l2_vs_cpu"] = cpu_baseline(params, solver, dev, args, value)
+        out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def roofline(den, dev, B, H, W, reps=3):
+    """fp32-MFMA roofline of the dominant kernel family (the 27 conv3x3 launches of one denoiser forward):
+    algorithmic FLOPs (2*9*Cin*Cout*H*W*B per launch) / HIP-event duration of exactly those launches."""
+    x = torch.rand(B, 1, H, W, device=dev)
+    sigma = torch.full((B,), 25 / 255.0, device=dev)
+    ctx = den.context(dev)
+    tot_ms = conv_ms = 0.0
+    conv_fl = 0.0
+    per = {}
+    for _ in range(reps):
+        for name, ms, fl in ops.unet_profile(ctx, x, sigma):
+            tot_ms += ms
+            per[name] = per.get(name, 0.0) + ms
+            if name == "conv3x3":
+                conv_ms += ms
+                conv_fl += fl
+    achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma",
+        "kernel": "conv3x3_mfma_kernel (27 launches per denoiser forward)",
+        "achieved": achieved,
+        "peak": PEAK_FP32_MFMA_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+        "traffic": None,
+        "flops_per_forward": conv_fl / reps,
+        "conv_ms_per_forward": conv_ms / reps,
+        "denoiser_ms_per_forward": tot_ms / reps,
+        "ms_by_kernel": {k: v / reps for k, v in per.items()},
+    }
+
+
+def cpu_baseline(params, solver, dev, args, gpu_value):
+    """The CPU oracle (oracle/pnp_oracle.py, pinned to the reference by tests/golden) timed on the host cores on
+    a bounded sample: cpu_batch items x cpu_iters inner iterations of the same workload.  Also the accuracy gate:
+    the HIP path on the same sample must match to 1e-4 relative L2."""
+    from oracle import pnp_oracle as O           # the checker / timed baseline, never the product path
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bc, Tc = args.cpu_batch, args.cpu_iters
+    H = W = args.size
+    d = synth.make_csmri_batch(Bc, H, W, ratio=args.ratio, sigma_n=15.0, seed=4321)
+    a = synth.make_actions(Bc, N_POLICY_STEPS, ACTION_PACK)[0]
+    sig, mu = t(a["sigma_d"][:, :Tc]), t(a["mu"][:, :Tc])
+    oden = O.Denoiser(params)
+    v0 = O.admm_reset(t(d["x0"]))
+    with torch.no_grad():
+        O.csmri_admm(oden, v0[:1], t(d["y0"][:1]), t(d["mask"][:1]), sig[:1, :1], mu[:1, :1])   # warm up
+        t0 = time.perf_counter()
+        ref = O.csmri_admm(oden, v0, t(d["y0"]), t(d["mask"]), sig, mu)
+        dt = time.perf_counter() - t0
+    gv0 = solver.reset({"x0": t(d["x0"]).to(dev)})
+    got = solver((gv0, (t(d["y0"]).to(dev), t(d["mask"]).to(dev))), (sig.to(dev), mu.to(dev))).cpu()
+    rel = float((got - ref).norm() / ref.norm())
+    image_iters_per_s = Bc * Tc / dt
+    base = {
+        "value": image_iters_per_s / args.batch,      # same unit as `value`: iterations over a 48-image batch / s
+        "unit": "iters/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{Bc} items x {Tc} inner iterations of CS-MRI ADMM {H}x{W} ({dt:.1f} s of CPU wall), "
+                  f"scaled to env_batch={args.batch}",
+        "image_iters_per_s": image_iters_per_s,
+    }
+    return base, rel
+
+
+if __name__ == "__main__":
+    main()

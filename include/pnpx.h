@@ -1,0 +1,148 @@
+/* pnpx.h -- C ABI of the MI355X-native PnP proximal-solver inner loop (libpnpx.so).
+ *
+ * Plain C: pointers, sizes, ints.  No torch / HIP types in any signature (a HIP stream is passed as
+ * void*, a null stream is the device's default stream).  Every function returns 0 on success and a
+ * non-zero pnpx_status otherwise; nothing throws across this boundary.  pnpx_last_error() returns a
+ * thread-local description of the last failure.
+ *
+ * Each entry point replaces one piece of the reference (Vandermode/TFPnP, /root/reference); the
+ * file:line it stands in for is cited on the declaration.  Tensor layouts at this boundary are the
+ * reference's own: contiguous fp32, NCHW, complex numbers as a trailing dimension of 2 (re, im),
+ * masks as one byte per pixel (torch.bool storage).  All pointers are DEVICE pointers unless a
+ * parameter name ends in _host.
+ *
+ * Threading: a pnpx_ctx belongs to one device; calls on the same ctx are serialised by an internal
+ * mutex; different ctxs (one per GPU / per thread, as torch.nn.DataParallel would drive the reference,
+ * tfpnp/policy/sync_batchnorm/replicate.py:50-75) are independent.  Work is enqueued on the caller's
+ * stream; no call synchronises the device except ctx creation, weight upload and workspace growth.
+ */
+#ifndef PNPX_H
+#define PNPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pnpx_ctx pnpx_ctx; /* opaque: device id, packed UNet weights, workspaces, FFT tables */
+
+enum pnpx_status {
+  PNPX_OK = 0,
+  PNPX_ERR_ARG = 1,         /* null pointer / non-positive size                                  */
+  PNPX_ERR_SHAPE = 2,       /* unsupported geometry (e.g. FFT size not a power of two)           */
+  PNPX_ERR_NO_WEIGHTS = 3,  /* denoiser used before pnpx_unet_load                               */
+  PNPX_ERR_ALLOC = 4,       /* device allocation failed                                          */
+  PNPX_ERR_HIP = 5          /* a HIP runtime call failed; see pnpx_last_error()                  */
+};
+
+const char* pnpx_version(void);
+const char* pnpx_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------------------- */
+int pnpx_ctx_create(int device, pnpx_ctx** out);
+int pnpx_ctx_destroy(pnpx_ctx* ctx);
+/* Pre-size the internal workspaces for batches up to B of H x W images (optional; otherwise they
+ * grow on first use, which synchronises the device once). */
+int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
+/* Bytes of device memory currently held by the context (weights + workspaces). */
+size_t pnpx_ctx_bytes(const pnpx_ctx* ctx);
+
+/* ---- denoiser prox: UNetDenoiser2D (tfpnp/pnp/denoiser/base.py:7-32, models/unet.py:34-66) ------- */
+/* Number of fp32 parameters of UNet(2,1) (11 773 857) = length of the blob below. */
+size_t pnpx_unet_num_params(void);
+/* params_host: the reference state_dict's 56 tensors concatenated in state_dict order
+ * (inc.conv.conv-0.conv2d.weight, ...bias, ..., outc.conv.weight, outc.conv.bias), each in its native
+ * [Cout,Cin,kh,kw] layout -- i.e. what torch.load('unet-nm.pt') holds (denoiser/base.py:15-16).
+ * Repacked on the host into the MFMA tile layout and uploaded. */
+int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params);
+/* out = clamp(UNet(cat[x, sigma*1]), 0, 1)   (denoiser/base.py:23-32).
+ * x, out: [B,1,H,W]; sigma: [B]; out_preclamp (nullable): UNet output before the clamp.
+ * H and W must be multiples of 16 (so that models/unet.py:109-113's F.pad is a no-op). */
+int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, float* out_preclamp,
+                      int B, int H, int W, void* stream);
+/* Per-layer timing of one denoise call with HIP events on `stream` (synchronises).  ms_out[i] for the
+ * i-th kernel launch of the forward pass, flops_out[i] its algorithmic FLOPs (0 for non-conv launches),
+ * names_out[i] a static string.  Returns the number of entries written (<= cap) in *n_out. */
+int pnpx_unet_profile(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, int B, int H, int W,
+                      void* stream, int cap, float* ms_out, double* flops_out, const char** names_out,
+                      int* n_out);
+
+/* ---- transforms (tfpnp/utils/transforms.py) ------------------------------------------------------ */
+/* fft2 / ifft2 (transforms.py:68-103): centered (ifftshift -> FFT -> fftshift), orthonormal, over the
+ * last two image dims of [n_img, H, W, 2].  centered=0 gives the plain torch.fft(x, 2, normalized=True)
+ * used by cdp_forward/backward (transforms.py:300,318).  H, W powers of two in [2, 1024]. */
+int pnpx_fft2(pnpx_ctx* ctx, const float* in, float* out, int n_img, int H, int W, int inverse,
+              int centered, void* stream);
+/* cdp_forward (transforms.py:282-301): x [B,1,H,W,2], mask [B,S,H,W,2] -> out [B,S,H,W,2]. */
+int pnpx_cdp_forward(pnpx_ctx* ctx, const float* x, const float* mask, float* out, int B, int S, int H,
+                     int W, void* stream);
+/* cdp_backward (transforms.py:304-320): y [B,S,H,W,2], mask [B,S,H,W,2] -> out [B,1,H,W,2] (mean over S). */
+int pnpx_cdp_backward(pnpx_ctx* ctx, const float* y, const float* mask, float* out, int B, int S, int H,
+                      int W, void* stream);
+/* spi_inverse (transforms.py:404-439): ztilde, K1 [B,1,H,W]; K, mu [B] -> out [B,1,H,W]. */
+int pnpx_spi_inverse(pnpx_ctx* ctx, const float* ztilde, const float* K1, const float* K, const float* mu,
+                     float* out, int B, int H, int W, void* stream);
+/* torch_psnr (tfpnp/env/base.py:237-242): output, gt [B,1,H,W] -> psnr [B]. */
+int pnpx_psnr(pnpx_ctx* ctx, const float* output, const float* gt, float* psnr, int B, int n_per_item,
+              void* stream);
+
+/* ---- solver loops: T inner iterations per call ---------------------------------------------------- */
+/* Hyper-parameter arrays are [B, param_stride] row-major (the policy's [B, action_pack] tensors,
+ * tfpnp/policy/network.py:164-175); iteration i reads column i.  vars_in is never modified; vars_out
+ * may not alias it. */
+
+/* ADMMSolver_CSMRI.forward (tasks/csmri/solver.py:29-57).
+ * vars [B,3,H,W,2] = cat(x,z,u); y0 [B,1,H,W,2]; mask [B,1,H,W] bytes. */
+int pnpx_csmri_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                    const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
+                    int H, int W, int T, void* stream);
+/* HQSSolver_CSMRI.forward (tasks/csmri/solver.py:64-89).  vars [B,2,H,W,2] = cat(x,z). */
+int pnpx_csmri_hqs(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                   const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
+                   int H, int W, int T, void* stream);
+/* PGSolver_CSMRI.forward (tasks/csmri/solver.py:96-120).  vars [B,1,H,W,2] = x. */
+int pnpx_csmri_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                  const uint8_t* mask, const float* sigma_d, const float* tau, int param_stride, int B,
+                  int H, int W, int T, void* stream);
+/* APGSolver_CSMRI.forward (tasks/csmri/solver.py:127-165).  vars [B,2,H,W,2] = cat(x,s). */
+int pnpx_csmri_apg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                   const uint8_t* mask, const float* sigma_d, const float* tau, const float* beta,
+                   int param_stride, int B, int H, int W, int T, void* stream);
+/* REDADMMSolver_CSMRI.forward (tasks/csmri/solver.py:172-204).  vars [B,3,H,W,2]. */
+int pnpx_csmri_redadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                       const uint8_t* mask, const float* sigma_d, const float* mu, const float* lamda,
+                       int param_stride, int B, int H, int W, int T, void* stream);
+/* IADMMSolver_PR.forward (tasks/pr/solver.py:37-76).
+ * vars [B,3,H,W,2]; y0 [B,S,H,W]; mask [B,S,H,W,2]. */
+int pnpx_pr_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                  const float* mask, const float* sigma_d, const float* mu, const float* tau,
+                  int param_stride, int B, int S, int H, int W, int T, void* stream);
+/* ADMMSolver_SPI.forward (tasks/spi/solver.py:17-52).
+ * vars [B,3,H,W] real; x0 [B,1,H,W]; Kmap [B,1,H,W] (K/10 broadcast, only [b,0,0,0] is read). */
+int pnpx_spi_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* x0,
+                  const float* Kmap, const float* sigma_d, const float* mu, int param_stride, int B, int H,
+                  int W, int T, void* stream);
+
+/* ---- CT: Radon pair standing in for torch_radon (tfpnp/utils/transforms.py:465-508) -------------- */
+/* Parallel beam, angles = linspace(0, 179/180*pi, n_view), det = ceil(sqrt(2)*R), unit spacing
+ * (transforms.py:487-491).  img [B,1,R,R] <-> sino [B,1,n_view,det].  Discretisation: DESIGN.md. */
+int pnpx_radon_det_count(int R);
+int pnpx_radon_forward(pnpx_ctx* ctx, const float* img, float* sino, int B, int R, int n_view, void* stream);
+int pnpx_radon_backprojection(pnpx_ctx* ctx, const float* sino, float* img, int B, int R, int n_view,
+                              void* stream);
+/* IADMMSolver_CT.forward (tasks/ct/solver.py:17-53); opnorm = Radon_norm.opnorm (transforms.py:470-474).
+ * vars [B,3,R,R] real; y0 [B,1,n_view,det]. */
+int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view,
+                  float opnorm, const float* sigma_d, const float* mu, const float* tau, int param_stride,
+                  int B, int R, int T, void* stream);
+/* PGSolver_CT.forward (tasks/ct/solver.py:61-87).  vars [B,1,R,R]. */
+int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view,
+               float opnorm, const float* sigma_d, const float* tau, int param_stride, int B, int R, int T,
+               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNPX_H */

@@ -1,0 +1,237 @@
+// C-ABI entry points of libpnpx.so: context, weights, denoiser, generic transforms.  (Solver loops live next to
+// their kernels in csmri.hip / tasks.hip.)
+#include <cstring>
+
+#include "common.h"
+#include "conv3x3.h"
+
+namespace pnpx {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
+  return PNPX_ERR_HIP;
+}
+
+int ctx_scratch(pnpx_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->scratch.bytes < bytes) {
+    PNPX_HIP(hipDeviceSynchronize());
+    if (ctx->scratch.p) PNPX_HIP(hipFree(ctx->scratch.p));
+    ctx->scratch = DeviceBuf();
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      set_error("scratch allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+      return PNPX_ERR_ALLOC;
+    }
+    ctx->scratch.p = p;
+    ctx->scratch.bytes = bytes;
+  }
+  *out = ctx->scratch.p;
+  return PNPX_OK;
+}
+
+// UNet(2,1) layer table in state_dict order (tfpnp/pnp/denoiser/models/unet.py:37-46).
+struct LayerSpec {
+  int cin, cout;
+};
+static void unet_layers(LayerSpec out[27]) {
+  const int blocks[9][2] = {{2, 32},    {32, 64},   {64, 128}, {128, 256}, {256, 512},
+                            {768, 256}, {384, 128}, {192, 64}, {96, 32}};
+  for (int b = 0; b < 9; ++b)
+    for (int j = 0; j < 3; ++j) out[3 * b + j] = LayerSpec{j == 0 ? blocks[b][0] : blocks[b][1], blocks[b][1]};
+}
+
+}  // namespace pnpx
+
+using namespace pnpx;
+
+#define LOCK_CTX(ctx)                         \
+  if (!(ctx)) {                               \
+    pnpx::set_error("null context");          \
+    return PNPX_ERR_ARG;                      \
+  }                                           \
+  std::lock_guard<std::mutex> _lk((ctx)->mu); \
+  PNPX_HIP(hipSetDevice((ctx)->device))
+
+extern "C" {
+
+const char* pnpx_version(void) { return "pnpx 0.1 (gfx950)"; }
+const char* pnpx_last_error(void) { return g_err.c_str(); }
+
+int pnpx_ctx_create(int device, pnpx_ctx** out) {
+  if (!out) {
+    set_error("pnpx_ctx_create: null out");
+    return PNPX_ERR_ARG;
+  }
+  int n = 0;
+  PNPX_HIP(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) {
+    set_error("pnpx_ctx_create: device %d out of range (%d visible)", device, n);
+    return PNPX_ERR_ARG;
+  }
+  PNPX_HIP(hipSetDevice(device));
+  pnpx_ctx* c = new pnpx_ctx();
+  c->device = device;
+  *out = c;
+  return PNPX_OK;
+}
+
+int pnpx_ctx_destroy(pnpx_ctx* ctx) {
+  if (!ctx) return PNPX_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  if (ctx->weights.p) (void)hipFree(ctx->weights.p);
+  if (ctx->arena.p) (void)hipFree(ctx->arena.p);
+  if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
+  for (auto& t : ctx->twiddle)
+    if (t) (void)hipFree(t);
+  for (auto e : ctx->events) (void)hipEventDestroy(e);
+  delete ctx;
+  return PNPX_OK;
+}
+
+int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W) {
+  LOCK_CTX(ctx);
+  if (B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) {
+    set_error("pnpx_ctx_reserve: need B>0 and H, W positive multiples of 16");
+    return PNPX_ERR_SHAPE;
+  }
+  return ctx_reserve_unet(ctx, B, H, W);
+}
+
+size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
+  return ctx ? ctx->weights.bytes + ctx->arena.bytes + ctx->scratch.bytes : 0;
+}
+
+size_t pnpx_unet_num_params(void) {
+  LayerSpec L[27];
+  unet_layers(L);
+  size_t n = 0;
+  for (int i = 0; i < 27; ++i) n += (size_t)L[i].cin * L[i].cout * 9 + L[i].cout;
+  return n + 32 + 1;
+}
+
+int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
+  LOCK_CTX(ctx);
+  if (!params_host || n_params != pnpx_unet_num_params()) {
+    set_error("pnpx_unet_load: expected %zu parameters, got %zu", pnpx_unet_num_params(), n_params);
+    return PNPX_ERR_ARG;
+  }
+  LayerSpec L[27];
+  unet_layers(L);
+  // device blob: packed conv weights (each 256-float aligned) + biases + outc, + slack for DMA over-read
+  std::vector<float> host;
+  size_t woff[27], boff[27];
+  auto align = [&]() { host.resize((host.size() + 255) & ~(size_t)255, 0.f); };
+  const float* src = params_host;
+  for (int i = 0; i < 27; ++i) {
+    const int mt = conv_pack_mt(L[i].cout), cc = conv_pack_cc(L[i].cin);
+    align();
+    woff[i] = host.size();
+    host.resize(host.size() + (size_t)L[i].cin * L[i].cout * 9);
+    pack_conv_weights(src, L[i].cout, L[i].cin, mt, cc, host.data() + woff[i]);
+    src += (size_t)L[i].cin * L[i].cout * 9;
+    align();
+    boff[i] = host.size();
+    host.insert(host.end(), src, src + L[i].cout);
+    src += L[i].cout;
+    ctx->conv[i].cin = L[i].cin;
+    ctx->conv[i].cout = L[i].cout;
+    ctx->conv[i].mt = mt;
+    ctx->conv[i].cc = cc;
+  }
+  align();
+  const size_t ow = host.size();
+  host.insert(host.end(), src, src + 32);
+  src += 32;
+  align();
+  const size_t ob = host.size();
+  host.push_back(*src);
+  host.resize(host.size() + 1024, 0.f);  // slack: the last weight block's 16-byte DMA may over-read
+  PNPX_HIP(hipDeviceSynchronize());
+  if (ctx->weights.p) PNPX_HIP(hipFree(ctx->weights.p));
+  ctx->weights = DeviceBuf();
+  ctx->has_weights = false;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, host.size() * sizeof(float));
+  if (e != hipSuccess) {
+    set_error("weight allocation of %zu bytes failed: %s", host.size() * sizeof(float), hipGetErrorString(e));
+    return PNPX_ERR_ALLOC;
+  }
+  PNPX_HIP(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  float* d = static_cast<float*>(p);
+  for (int i = 0; i < 27; ++i) {
+    ctx->conv[i].w = d + woff[i];
+    ctx->conv[i].b = d + boff[i];
+  }
+  ctx->outc_w = d + ow;
+  ctx->outc_b = d + ob;
+  ctx->weights.p = p;
+  ctx->weights.bytes = host.size() * sizeof(float);
+  ctx->has_weights = true;
+  return PNPX_OK;
+}
+
+int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, float* out_preclamp, int B,
+                      int H, int W, void* stream) {
+  LOCK_CTX(ctx);
+  if (!x || !sigma || !out) {
+    set_error("pnpx_unet_denoise: null pointer");
+    return PNPX_ERR_ARG;
+  }
+  return unet_denoise(ctx, x, sigma, 1, out, out_preclamp, B, H, W, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int pnpx_unet_profile(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, int B, int H, int W,
+                      void* stream, int cap, float* ms_out, double* flops_out, const char** names_out, int* n_out) {
+  LOCK_CTX(ctx);
+  if (!x || !sigma || !out || !ms_out || !flops_out || !names_out || !n_out || cap <= 0) {
+    set_error("pnpx_unet_profile: null pointer");
+    return PNPX_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // make sure the arena exists before timing (growth synchronises)
+  PNPX_TRY(unet_denoise(ctx, x, sigma, 1, out, nullptr, B, H, W, s, nullptr));
+  while (ctx->events.size() < 64) {
+    hipEvent_t e;
+    PNPX_HIP(hipEventCreate(&e));
+    ctx->events.push_back(e);
+  }
+  ProfileSink sink;
+  sink.events = &ctx->events;
+  PNPX_TRY(unet_denoise(ctx, x, sigma, 1, out, nullptr, B, H, W, s, &sink));
+  PNPX_HIP(hipStreamSynchronize(s));
+  int n = sink.n < cap ? sink.n : cap;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    PNPX_HIP(hipEventElapsedTime(&ms, ctx->events[i], ctx->events[i + 1]));
+    ms_out[i] = ms;
+    flops_out[i] = sink.flops[i];
+    names_out[i] = sink.names[i];
+  }
+  *n_out = n;
+  return PNPX_OK;
+}
+
+int pnpx_fft2(pnpx_ctx* ctx, const float* in, float* out, int n_img, int H, int W, int inverse, int centered,
+              void* stream) {
+  LOCK_CTX(ctx);
+  if (!in || !out) {
+    set_error("pnpx_fft2: null pointer");
+    return PNPX_ERR_ARG;
+  }
+  return fft2(ctx, in, out, n_img, H, W, inverse != 0, centered != 0, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

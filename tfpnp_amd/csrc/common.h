@@ -1,0 +1,105 @@
+// Internal declarations shared by the translation units of libpnpx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pnpx.h"
+
+namespace pnpx {
+
+// ---------------------------------------------------------------------------------------------------
+// Error plumbing: nothing throws across the C ABI.
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define PNPX_HIP(expr)                                                       \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) return ::pnpx::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+#define PNPX_TRY(expr)          \
+  do {                          \
+    int _s = (expr);            \
+    if (_s != PNPX_OK) return _s; \
+  } while (0)
+#define PNPX_LAUNCH_CHECK() PNPX_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------------
+// Padded planar activation layout used INSIDE the denoiser (never visible at the C ABI):
+//   tensor [B][C][Hp][Wp] fp32, interior pixel (y,x) at row y+1, column x+PADL.  All border cells are
+//   zero for the lifetime of the workspace (memset once, producers write interiors only), so 3x3
+//   convolutions read their zero padding straight from memory and need no bounds checks.
+constexpr int PADL = 4;
+__host__ __device__ inline int padded_w(int W) { return W + 2 * PADL; }
+__host__ __device__ inline int padded_h(int H) { return H + 2; }
+
+struct ActDesc {      // one activation tensor in the arena
+  size_t off = 0;     // float offset into the arena
+  int C = 0, H = 0, W = 0;
+  size_t per_image() const { return (size_t)C * padded_h(H) * padded_w(W); }
+};
+
+// ---------------------------------------------------------------------------------------------------
+struct ConvLayer {          // one 3x3 conv of the UNet, weights repacked for the MFMA kernel
+  int cin = 0, cout = 0;
+  int mt = 0, cc = 0;       // cout tile and cin chunk the packing was made for
+  float* w = nullptr;       // device: [cout/mt][cin/cc][9][cc][mt]
+  float* b = nullptr;       // device: [cout]
+};
+
+struct DeviceBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace pnpx
+
+struct pnpx_ctx {
+  int device = 0;
+  std::mutex mu;
+  // --- denoiser
+  bool has_weights = false;
+  pnpx::ConvLayer conv[27];
+  float* outc_w = nullptr;   // [32]
+  float* outc_b = nullptr;   // [1]
+  pnpx::DeviceBuf weights;   // single allocation holding all of the above
+  // --- UNet activation arena (capacity capB images of capH x capW)
+  pnpx::DeviceBuf arena;
+  int capB = 0, capH = 0, capW = 0;
+  // --- solver scratch (complex fields etc.), grown on demand
+  pnpx::DeviceBuf scratch;
+  // --- FFT twiddle tables, one per size log2(N) in [1,10]: device float2[N]
+  float2* twiddle[11] = {nullptr};
+  // --- events for pnpx_unet_profile
+  std::vector<hipEvent_t> events;
+};
+
+namespace pnpx {
+
+int ctx_reserve_unet(pnpx_ctx* ctx, int B, int H, int W);
+int ctx_scratch(pnpx_ctx* ctx, size_t bytes, void** out);
+int ctx_twiddle(pnpx_ctx* ctx, int N, const float2** out);
+
+struct ProfileSink {      // optional per-launch event recording for pnpx_unet_profile
+  std::vector<hipEvent_t>* events = nullptr;
+  std::vector<const char*> names;
+  std::vector<double> flops;
+  int n = 0;
+};
+
+// Denoiser forward on padded input already resident in the arena is internal; these are the pieces the
+// solver loops call.  x/sigma/out are unpadded [B,1,H,W] / [B] tensors (C-ABI layout).
+int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
+                 int B, int H, int W, hipStream_t s, ProfileSink* prof);
+
+// FFT building blocks (fft.hip)
+int fft2(pnpx_ctx* ctx, const float* in, float* out, int n_img, int H, int W, bool inverse, bool centered,
+         hipStream_t s);
+
+}  // namespace pnpx

@@ -1,0 +1,25 @@
+// Launch interface of the MFMA 3x3 convolution (conv3x3.hip).
+#pragma once
+#include "common.h"
+
+namespace pnpx {
+
+struct ConvArgs {
+  const float* in0;  // first input tensor (padded planar), C0 channels
+  const float* in1;  // second input tensor (channel-concatenated after in0), C1 channels (0 if none)
+  const float* wpk;  // packed weights [cout/MT][cin/CC][9][CC][MT]
+  const float* bias; // [cout]
+  float* out;        // padded planar, nct*MT channels
+  int C0, C1;
+  int H, W, Hp, Wp;
+  int tilesX, tilesY, nct;
+  float slope;       // LeakyReLU negative slope
+};
+
+int conv_pack_mt(int cout);
+int conv_pack_cc(int cin);
+void pack_conv_weights(const float* w, int cout, int cin, int mt, int cc, float* dst);
+int launch_conv3x3(const ConvLayer& L, const float* in0, int C0, const float* in1, int C1, float* out, int B,
+                   int H, int W, hipStream_t s);
+
+}  // namespace pnpx

@@ -1,0 +1,416 @@
+// CS-MRI solver loops on gfx950: ADMM / HQS / PG / APG / RED-ADMM (tasks/csmri/solver.py:24-204).
+//
+// Per inner iteration the data-fidelity step is three kernels (fft_lds.h):
+//   row pass (load functor builds the FFT input: x+u, x, s ...)  ->
+//   column pass (forward FFT along H, k-space pointwise op with y0/mask/mu, inverse FFT along H)  ->
+//   inverse row pass (store functor applies the primal/dual update and emits the next denoiser input).
+// The k-space image makes one HBM round trip between the row passes; fftshifts are sign flips.
+// Pointwise arithmetic uses explicit round-to-nearest mul/add/div (no FMA contraction) in the reference's
+// operation order, e.g. temp = ((mu * k) + y0) / (1 + mu)  (tasks/csmri/solver.py:50).
+#include "common.h"
+#include "fft_lds.h"
+
+namespace pnpx {
+
+namespace {
+
+__device__ __forceinline__ float mulr(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float addr(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float subr(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float divr(float a, float b) { return __fdiv_rn(a, b); }
+
+// vars tensors are [B, nvar, H, W, 2]; slot(v, s) = pointer to variable s of item 0, item stride nvar*HW
+struct Slot {
+  float2* p;
+  size_t istride;  // float2 per item
+  int W, HW;
+  __device__ float2& at(int b, int y, int x) const { return p[(size_t)b * istride + (size_t)y * W + x]; }
+};
+struct CSlot {
+  const float2* p;
+  size_t istride;
+  int W, HW;
+  __device__ float2 at(int b, int y, int x) const { return p[(size_t)b * istride + (size_t)y * W + x]; }
+};
+struct RealImg {  // [B,1,H,W]
+  float* p;
+  int W, HW;
+  __device__ float& at(int b, int y, int x) const { return p[(size_t)b * HW + (size_t)y * W + x]; }
+};
+
+// ------------------------------------------------------------------ load functors (row pass input)
+struct LoadXrPlusU {  // r2c(xr) + u
+  RealImg xr;
+  CSlot u;
+  __device__ float2 operator()(int b, int y, int x) const {
+    const float2 uu = u.at(b, y, x);
+    return make_float2(addr(xr.at(b, y, x), uu.x), uu.y);
+  }
+};
+struct LoadXr {  // r2c(xr)
+  RealImg xr;
+  __device__ float2 operator()(int b, int y, int x) const { return make_float2(xr.at(b, y, x), 0.f); }
+};
+struct LoadSlot {  // complex variable
+  CSlot v;
+  __device__ float2 operator()(int b, int y, int x) const { return v.at(b, y, x); }
+};
+struct LoadSlotPlusSlot {  // x + u, both complex
+  CSlot a, c;
+  __device__ float2 operator()(int b, int y, int x) const {
+    const float2 p = a.at(b, y, x), q = c.at(b, y, x);
+    return make_float2(addr(p.x, q.x), addr(p.y, q.y));
+  }
+};
+
+// ------------------------------------------------------------------ k-space functors (column pass)
+struct KSpace {
+  const float2* y0;      // [B,1,H,W,2]
+  const uint8_t* mask;   // [B,1,H,W]
+  const float* par;      // hyper-parameter column i: par[b*stride]
+  int stride, W, HW;
+};
+struct MidBlend {  // k[mask] = ((mu*k) + y0)[mask] / (1 + mu)      tasks/csmri/solver.py:49-51
+  KSpace k;
+  __device__ float2 operator()(int b, int ky, int kx, float2 v) const {
+    const size_t o = (size_t)b * k.HW + (size_t)ky * k.W + kx;
+    if (!k.mask[o]) return v;
+    const float mu = k.par[(size_t)b * k.stride];
+    const float2 y = k.y0[o];
+    const float den = addr(1.f, mu);
+    return make_float2(divr(addr(mulr(mu, v.x), y.x), den), divr(addr(mulr(mu, v.y), y.y), den));
+  }
+};
+struct MidResidual {  // temp = k - y0; temp[~mask] = 0               tasks/csmri/solver.py:109-110
+  KSpace k;
+  __device__ float2 operator()(int b, int ky, int kx, float2 v) const {
+    const size_t o = (size_t)b * k.HW + (size_t)ky * k.W + kx;
+    if (!k.mask[o]) return make_float2(0.f, 0.f);
+    const float2 y = k.y0[o];
+    return make_float2(subr(v.x, y.x), subr(v.y, y.y));
+  }
+};
+
+// ------------------------------------------------------------------ store functors (inverse row pass)
+struct StoreAdmm {  // z = ifft2c(k); u = u + x - z; emits Re(z - u_new) (+ x as complex on the last iteration)
+  Slot z, uo, xo;
+  CSlot ui;
+  RealImg xr, d;
+  int write_x;
+  __device__ void operator()(int b, int y, int x, float2 zv) const {
+    const float2 uu = ui.at(b, y, x);
+    const float xv = xr.at(b, y, x);
+    const float2 un = make_float2(subr(addr(uu.x, xv), zv.x), subr(addr(uu.y, 0.f), zv.y));
+    z.at(b, y, x) = zv;
+    uo.at(b, y, x) = un;
+    d.at(b, y, x) = subr(zv.x, un.x);
+    if (write_x) xo.at(b, y, x) = make_float2(xv, 0.f);
+  }
+};
+struct StoreAdmmCx {  // same with a complex x held in a slot (RED-ADMM); no denoiser input emitted
+  Slot z, uo;
+  CSlot ui, xc;
+  __device__ void operator()(int b, int y, int x, float2 zv) const {
+    const float2 uu = ui.at(b, y, x), xv = xc.at(b, y, x);
+    z.at(b, y, x) = zv;
+    uo.at(b, y, x) = make_float2(subr(addr(uu.x, xv.x), zv.x), subr(addr(uu.y, xv.y), zv.y));
+  }
+};
+struct StoreHqs {  // z = ifft2c(k); next denoiser input Re(z)
+  Slot z, xo;
+  RealImg xr, d;
+  int write_x;
+  __device__ void operator()(int b, int y, int x, float2 zv) const {
+    z.at(b, y, x) = zv;
+    d.at(b, y, x) = zv.x;
+    if (write_x) xo.at(b, y, x) = make_float2(xr.at(b, y, x), 0.f);
+  }
+};
+struct StoreGrad {  // d = Re(base - tau * g)                             tasks/csmri/solver.py:111-112,146
+  CSlot base;       // complex base point (x or s) ...
+  RealImg base_r;   // ... or a real one (use_real)
+  int use_real;
+  const float* tau;
+  int stride;
+  RealImg d;
+  __device__ void operator()(int b, int y, int x, float2 g) const {
+    const float bx = use_real ? base_r.at(b, y, x) : base.at(b, y, x).x;
+    d.at(b, y, x) = subr(bx, mulr(tau[(size_t)b * stride], g.x));
+  }
+};
+
+// ------------------------------------------------------------------ pointwise kernels
+__global__ void real_of_diff_kernel(const float2* __restrict__ a, const float2* __restrict__ c, size_t istride,
+                                    float* __restrict__ d, int HW, int B) {  // d = Re(a - c) (c may be null)
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  const float av = a[b * istride + r].x;
+  d[i] = c ? subr(av, c[b * istride + r].x) : av;
+}
+__global__ void real_to_slot_kernel(const float* __restrict__ xr, float2* __restrict__ dst, size_t istride, int HW,
+                                    int B) {  // dst = r2c(xr)
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  dst[b * istride + r] = make_float2(xr[i], 0.f);
+}
+__global__ void copy_slot_kernel(const float2* __restrict__ src, float2* __restrict__ dst, size_t istride, int HW,
+                                 int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  dst[b * istride + r] = src[b * istride + r];
+}
+// APG extrapolation: s = x + beta*(x - x_prev), x = r2c(xr)                tasks/csmri/solver.py:149-159
+__global__ void apg_update_kernel(const float* __restrict__ xr, const float2* xprev, float2* xout,
+                                  float2* __restrict__ sout, size_t istride,
+                                  const float* __restrict__ beta, int stride, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  const float be = beta[b * stride];
+  const float2 xp = xprev[b * istride + r];
+  const float xv = xr[i];
+  sout[b * istride + r] = make_float2(addr(xv, mulr(be, subr(xv, xp.x))), addr(0.f, mulr(be, subr(0.f, xp.y))));
+  xout[b * istride + r] = make_float2(xv, 0.f);
+}
+// RED x-update: x = (lamda*x_half + mu*(z-u)) / (mu + lamda)               tasks/csmri/solver.py:188-190
+__global__ void red_update_kernel(const float* __restrict__ xh, const float2* __restrict__ z,
+                                  const float2* __restrict__ u, float2* xout, size_t istride,
+                                  const float* __restrict__ mu, const float* __restrict__ lam, int stride, int HW,
+                                  int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  const float m = mu[b * stride], l = lam[b * stride];
+  const float2 zv = z[b * istride + r], uv = u[b * istride + r];
+  const float den = addr(m, l);
+  xout[b * istride + r] = make_float2(divr(addr(mulr(l, xh[i]), mulr(m, subr(zv.x, uv.x))), den),
+                                      divr(addr(mulr(l, 0.f), mulr(m, subr(zv.y, uv.y))), den));
+}
+
+struct Scratch {
+  float* d;    // [B,1,H,W] denoiser input
+  float* xr;   // [B,1,H,W] denoiser output
+  float2* k;   // [B,H,W] complex k-space / row-pass intermediate
+};
+
+int get_scratch(pnpx_ctx* ctx, int B, int H, int W, Scratch* S) {
+  const size_t hw = (size_t)H * W * B;
+  void* p;
+  PNPX_TRY(ctx_scratch(ctx, hw * 16 + 1024, &p));
+  S->k = static_cast<float2*>(p);
+  S->d = reinterpret_cast<float*>(S->k + hw);
+  S->xr = S->d + hw;
+  return PNPX_OK;
+}
+
+inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+int check_common(const void* a, const void* b, const void* c, const void* d, const void* e, int B, int H, int W,
+                 int T, int stride) {
+  if (!a || !b || !c || !d || !e || B <= 0 || T < 0 || stride < T) {
+    set_error("csmri: bad argument (null pointer, B<=0 or param_stride < T)");
+    return PNPX_ERR_ARG;
+  }
+  (void)H;
+  (void)W;
+  return PNPX_OK;
+}
+
+}  // namespace
+
+}  // namespace pnpx
+
+using namespace pnpx;
+
+#define LOCK_CTX(ctx)                                  \
+  if (!(ctx)) {                                        \
+    pnpx::set_error("null context");                   \
+    return PNPX_ERR_ARG;                               \
+  }                                                    \
+  std::lock_guard<std::mutex> _lk((ctx)->mu);          \
+  PNPX_HIP(hipSetDevice((ctx)->device))
+
+extern "C" int pnpx_csmri_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                               const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
+                               int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HW = H * W;
+  const size_t is = 3 * (size_t)HW;
+  Scratch S;
+  PNPX_TRY(get_scratch(ctx, B, H, W, &S));
+  FftPlan2D P;
+  PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
+  const float2* vin = reinterpret_cast<const float2*>(vars_in);
+  float2* vout = reinterpret_cast<float2*>(vars_out);
+  if (T == 0) {
+    PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+    return PNPX_OK;
+  }
+  // d0 = Re(z - u)                                                   tasks/csmri/solver.py:45
+  hipLaunchKernelGGL(real_of_diff_kernel, g1((size_t)HW * B), dim3(256), 0, s, vin + HW, vin + 2 * HW, is, S.d, HW, B);
+  PNPX_LAUNCH_CHECK();
+  RealImg xr{S.xr, W, HW}, d{S.d, W, HW};
+  Slot xo{vout, is, W, HW}, zo{vout + HW, is, W, HW}, uo{vout + 2 * HW, is, W, HW};
+  StoreC kst{S.k, H, W};
+  LoadC kld{S.k, H, W};
+  for (int i = 0; i < T; ++i) {
+    PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    CSlot ui{(i == 0 ? vin : vout) + 2 * HW, is, W, HW};
+    PNPX_TRY((launch_rows<false>(P, LoadXrPlusU{xr, ui}, kst, s)));
+    KSpace ks{reinterpret_cast<const float2*>(y0), mask, mu + i, param_stride, W, HW};
+    PNPX_TRY((launch_cols<false, true>(P, kld, MidBlend{ks}, kst, s)));
+    PNPX_TRY((launch_rows<true>(P, kld, StoreAdmm{zo, uo, xo, ui, xr, d, i == T - 1}, s)));
+  }
+  return PNPX_OK;
+}
+
+extern "C" int pnpx_csmri_hqs(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                              const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
+                              int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HW = H * W;
+  const size_t is = 2 * (size_t)HW;
+  Scratch S;
+  PNPX_TRY(get_scratch(ctx, B, H, W, &S));
+  FftPlan2D P;
+  PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
+  const float2* vin = reinterpret_cast<const float2*>(vars_in);
+  float2* vout = reinterpret_cast<float2*>(vars_out);
+  if (T == 0) {
+    PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+    return PNPX_OK;
+  }
+  hipLaunchKernelGGL(real_of_diff_kernel, g1((size_t)HW * B), dim3(256), 0, s, vin + HW, (const float2*)nullptr, is,
+                     S.d, HW, B);
+  PNPX_LAUNCH_CHECK();
+  RealImg xr{S.xr, W, HW}, d{S.d, W, HW};
+  Slot xo{vout, is, W, HW}, zo{vout + HW, is, W, HW};
+  StoreC kst{S.k, H, W};
+  LoadC kld{S.k, H, W};
+  for (int i = 0; i < T; ++i) {
+    PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    PNPX_TRY((launch_rows<false>(P, LoadXr{xr}, kst, s)));
+    KSpace ks{reinterpret_cast<const float2*>(y0), mask, mu + i, param_stride, W, HW};
+    PNPX_TRY((launch_cols<false, true>(P, kld, MidBlend{ks}, kst, s)));
+    PNPX_TRY((launch_rows<true>(P, kld, StoreHqs{zo, xo, xr, d, i == T - 1}, s)));
+  }
+  return PNPX_OK;
+}
+
+extern "C" int pnpx_csmri_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                             const uint8_t* mask, const float* sigma_d, const float* tau, int param_stride, int B,
+                             int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HW = H * W;
+  const size_t is = (size_t)HW;
+  Scratch S;
+  PNPX_TRY(get_scratch(ctx, B, H, W, &S));
+  FftPlan2D P;
+  PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
+  const float2* vin = reinterpret_cast<const float2*>(vars_in);
+  float2* vout = reinterpret_cast<float2*>(vars_out);
+  if (T == 0) {
+    PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+    return PNPX_OK;
+  }
+  RealImg xr{S.xr, W, HW}, d{S.d, W, HW};
+  StoreC kst{S.k, H, W};
+  LoadC kld{S.k, H, W};
+  CSlot x0{vin, is, W, HW};
+  for (int i = 0; i < T; ++i) {
+    // gradient step on x (complex x0 on the first iteration, r2c(denoised) afterwards)
+    if (i == 0) PNPX_TRY((launch_rows<false>(P, LoadSlot{x0}, kst, s)));
+    else PNPX_TRY((launch_rows<false>(P, LoadXr{xr}, kst, s)));
+    KSpace ks{reinterpret_cast<const float2*>(y0), mask, tau + i, param_stride, W, HW};
+    PNPX_TRY((launch_cols<false, true>(P, kld, MidResidual{ks}, kst, s)));
+    PNPX_TRY((launch_rows<true>(P, kld, StoreGrad{x0, xr, i != 0, tau + i, param_stride, d}, s)));
+    PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+  }
+  hipLaunchKernelGGL(real_to_slot_kernel, g1((size_t)HW * B), dim3(256), 0, s, S.xr, vout, is, HW, B);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+
+extern "C" int pnpx_csmri_apg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                              const uint8_t* mask, const float* sigma_d, const float* tau, const float* beta,
+                              int param_stride, int B, int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
+  if (!beta || !tau) {
+    set_error("csmri_apg: null tau/beta");
+    return PNPX_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HW = H * W;
+  const size_t is = 2 * (size_t)HW;
+  Scratch S;
+  PNPX_TRY(get_scratch(ctx, B, H, W, &S));
+  FftPlan2D P;
+  PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
+  const float2* vin = reinterpret_cast<const float2*>(vars_in);
+  float2* vout = reinterpret_cast<float2*>(vars_out);
+  PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+  (void)vin;
+  RealImg xr{S.xr, W, HW}, d{S.d, W, HW};
+  StoreC kst{S.k, H, W};
+  LoadC kld{S.k, H, W};
+  CSlot sc{vout + HW, is, W, HW};
+  for (int i = 0; i < T; ++i) {
+    PNPX_TRY((launch_rows<false>(P, LoadSlot{sc}, kst, s)));
+    KSpace ks{reinterpret_cast<const float2*>(y0), mask, tau + i, param_stride, W, HW};
+    PNPX_TRY((launch_cols<false, true>(P, kld, MidResidual{ks}, kst, s)));
+    PNPX_TRY((launch_rows<true>(P, kld, StoreGrad{sc, xr, 0, tau + i, param_stride, d}, s)));
+    PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    hipLaunchKernelGGL(apg_update_kernel, g1((size_t)HW * B), dim3(256), 0, s, S.xr, vout, vout, vout + HW, is,
+                       beta + i, param_stride, HW, B);
+    PNPX_LAUNCH_CHECK();
+  }
+  return PNPX_OK;
+}
+
+extern "C" int pnpx_csmri_redadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                                  const uint8_t* mask, const float* sigma_d, const float* mu, const float* lamda,
+                                  int param_stride, int B, int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
+  if (!mu || !lamda) {
+    set_error("csmri_redadmm: null mu/lamda");
+    return PNPX_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HW = H * W;
+  const size_t is = 3 * (size_t)HW;
+  Scratch S;
+  PNPX_TRY(get_scratch(ctx, B, H, W, &S));
+  FftPlan2D P;
+  PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
+  float2* vout = reinterpret_cast<float2*>(vars_out);
+  PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+  StoreC kst{S.k, H, W};
+  LoadC kld{S.k, H, W};
+  Slot zo{vout + HW, is, W, HW}, uo{vout + 2 * HW, is, W, HW};
+  CSlot xc{vout, is, W, HW}, uc{vout + 2 * HW, is, W, HW};
+  for (int i = 0; i < T; ++i) {
+    hipLaunchKernelGGL(real_of_diff_kernel, g1((size_t)HW * B), dim3(256), 0, s, vout, (const float2*)nullptr, is, S.d,
+                       HW, B);
+    PNPX_LAUNCH_CHECK();
+    PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    hipLaunchKernelGGL(red_update_kernel, g1((size_t)HW * B), dim3(256), 0, s, S.xr, vout + HW, vout + 2 * HW, vout, is,
+                       mu + i, lamda + i, param_stride, HW, B);
+    PNPX_LAUNCH_CHECK();
+    PNPX_TRY((launch_rows<false>(P, LoadSlotPlusSlot{xc, uc}, kst, s)));
+    KSpace ks{reinterpret_cast<const float2*>(y0), mask, mu + i, param_stride, W, HW};
+    PNPX_TRY((launch_cols<false, true>(P, kld, MidBlend{ks}, kst, s)));
+    PNPX_TRY((launch_rows<true>(P, kld, StoreAdmmCx{zo, uo, uc, xc}, s)));
+  }
+  return PNPX_OK;
+}

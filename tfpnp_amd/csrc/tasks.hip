@@ -1,0 +1,572 @@
+// Phase retrieval (CDP), single-photon imaging (Poisson prox), sparse-view CT (Radon pair) and PSNR on gfx950.
+//   tasks/pr/solver.py:37-76, tasks/spi/solver.py:17-52, tasks/ct/solver.py:17-87,
+//   tfpnp/utils/transforms.py:282-320 (cdp), :404-439 (spi_inverse), :447-508 (Radon wrapper),
+//   tfpnp/env/base.py:237-242 (torch_psnr).
+#include <cmath>
+
+#include "common.h"
+#include "fft_lds.h"
+
+namespace pnpx {
+namespace {
+
+__device__ __forceinline__ float mulr(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float addr(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float subr(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float divr(float a, float b) { return __fdiv_rn(a, b); }
+
+inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// =================================================================================== phase retrieval
+// FFT batch index img = b*S + s.
+struct LoadCdp {  // complex_mul(x[b], mask[b,s])                       transforms.py:297-299
+  const float2* x;     // item b at x + b*xstride
+  size_t xstride;
+  const float2* mask;  // [B,S,H,W]
+  int S, W, HW;
+  __device__ float2 operator()(int img, int y, int xx) const {
+    const int b = img / S;
+    const size_t r = (size_t)y * W + xx;
+    const float2 a = x[(size_t)b * xstride + r], m = mask[(size_t)img * HW + r];
+    return make_float2(subr(mulr(a.x, m.x), mulr(a.y, m.y)), addr(mulr(a.x, m.y), mulr(a.y, m.x)));
+  }
+};
+struct MidPrResidual {  // (|Az| - y0) / |Az| * Az, no epsilon            tasks/pr/solver.py:64-67
+  const float* y0;      // [B,S,H,W]
+  int W, HW;
+  __device__ float2 operator()(int img, int ky, int kx, float2 v) const {
+    const float yh = sqrtf(addr(mulr(v.x, v.x), mulr(v.y, v.y)));
+    const float q = divr(subr(yh, y0[(size_t)img * HW + (size_t)ky * W + kx]), yh);
+    return make_float2(mulr(q, v.x), mulr(q, v.y));
+  }
+};
+
+// g = mean_s(complex_mul(I_s, conj(mask_s)))                              transforms.py:318-320
+__device__ __forceinline__ float2 cdp_adjoint_px(const float2* I, const float2* mask, int b, int S, int HW, size_t r) {
+  float2 acc = make_float2(0.f, 0.f);
+  for (int s = 0; s < S; ++s) {
+    const size_t o = ((size_t)b * S + s) * HW + r;
+    const float2 a = I[o], m = mask[o];
+    const float my = -m.y;
+    acc.x = addr(acc.x, subr(mulr(a.x, m.x), mulr(a.y, my)));
+    acc.y = addr(acc.y, addr(mulr(a.x, my), mulr(a.y, m.x)));
+  }
+  return make_float2(divr(acc.x, (float)S), divr(acc.y, (float)S));
+}
+__global__ void cdp_adjoint_kernel(const float2* __restrict__ I, const float2* __restrict__ mask,
+                                   float2* __restrict__ out, int S, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const int b = (int)(i / HW);
+  out[i] = cdp_adjoint_px(I, mask, b, S, HW, i - (size_t)b * HW);
+}
+// z = z - tau*(g + mu*(z - (x+u))); u = u + x - z; d = Re(z - u)           tasks/pr/solver.py:69-72
+__global__ void pr_update_kernel(const float2* __restrict__ I, const float2* __restrict__ mask,
+                                 const float* __restrict__ xr, const float2* zin, const float2* uin, float2* xout,
+                                 float2* zout, float2* uout, size_t istride, float* __restrict__ d,
+                                 const float* __restrict__ mu, const float* __restrict__ tau, int stride, int S, int HW,
+                                 int B, int write_x) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const int b = (int)(i / HW);
+  const size_t r = i - (size_t)b * HW;
+  const float2 g = cdp_adjoint_px(I, mask, b, S, HW, r);
+  const float m = mu[(size_t)b * stride], t = tau[(size_t)b * stride];
+  const float2 z = zin[(size_t)b * istride + r], u = uin[(size_t)b * istride + r];
+  const float xv = xr[i];
+  const float2 zn = make_float2(subr(z.x, mulr(t, addr(g.x, mulr(m, subr(z.x, addr(xv, u.x)))))),
+                                subr(z.y, mulr(t, addr(g.y, mulr(m, subr(z.y, addr(0.f, u.y)))))));
+  const float2 un = make_float2(subr(addr(u.x, xv), zn.x), subr(addr(u.y, 0.f), zn.y));
+  zout[(size_t)b * istride + r] = zn;
+  uout[(size_t)b * istride + r] = un;
+  d[i] = subr(zn.x, un.x);
+  if (write_x) xout[(size_t)b * istride + r] = make_float2(xv, 0.f);
+}
+__global__ void real_of_diff_kernel(const float2* __restrict__ a, const float2* __restrict__ c, size_t istride,
+                                    float* __restrict__ d, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  d[i] = subr(a[b * istride + r].x, c[b * istride + r].x);
+}
+
+// =================================================================================== SPI
+// spi_inverse for one pixel                                                transforms.py:404-439
+__device__ __forceinline__ float spi_inverse_px(float zt, float K1, float K, float mu) {
+  const float K0 = subr(mulr(K, K), K1);
+  float z;
+  if (K1 == 0.f) {
+    z = subr(zt, divr(K0, mu));
+  } else {
+    float bmin = 1e-5f, bmax = 1.1f;
+    float bave = divr(addr(bmin, bmax), 2.0f);
+    bool live = true;
+#pragma unroll 1
+    for (int it = 0; it < 10; ++it) {
+      const float tmp = addr(subr(subr(divr(K1, subr(expf(bave), 1.f)), mulr(mu, bave)), K0), mulr(mu, zt));
+      if (live) {
+        if (tmp > 0.f) bmin = bave;
+        else if (tmp < 0.f) bmax = bave;
+        else if (tmp == 0.f) live = false;  // freeze-on-exact-zero branch (transforms.py:430-432)
+        if (live) bave = divr(addr(bmin, bmax), 2.0f);
+      }
+    }
+    z = bave;
+  }
+  return fminf(fmaxf(z, 0.f), 1.f);
+}
+__global__ void spi_inverse_kernel(const float* __restrict__ zt, const float* __restrict__ K1,
+                                   const float* __restrict__ K, const float* __restrict__ mu, float* __restrict__ out,
+                                   int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW;
+  out[i] = spi_inverse_px(zt[i], K1[i], K[b], mu[b]);
+}
+// z = spi_inverse(x+u, K1, K, mu); u = u + x - z; d = z - u                tasks/spi/solver.py:41-47
+__global__ void spi_step_kernel(const float* xin, const float* uin, size_t istride, const float* __restrict__ x0,
+                                const float* __restrict__ Kmap, float* zout, float* uout, float* __restrict__ d,
+                                const float* __restrict__ mu, int stride, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  const float K = mulr(Kmap[b * HW], 10.f);
+  const float K1 = mulr(x0[i], mulr(K, K));
+  const float x = xin[b * istride + r], u = uin[b * istride + r];
+  const float z = spi_inverse_px(addr(x, u), K1, K, mu[b * stride]);
+  const float un = subr(addr(u, x), z);
+  zout[b * istride + r] = z;
+  uout[b * istride + r] = un;
+  d[i] = subr(z, un);
+}
+__global__ void copy_real_slot_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t istride, int HW,
+                                      int B) {  // dst slot <- contiguous [B,HW]
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  dst[b * istride + r] = src[i];
+}
+
+// =================================================================================== PSNR
+// partial sums of (clamp(o,0,1) - g)^2 per item                            tfpnp/env/base.py:237-242
+constexpr int PSNR_CHUNKS = 32;
+__global__ void psnr_partial_kernel(const float* __restrict__ o, const float* __restrict__ g, float* __restrict__ part,
+                                    int n) {
+  const int b = blockIdx.y, c = blockIdx.x;
+  const int per = (n + PSNR_CHUNKS - 1) / PSNR_CHUNKS;
+  const int lo = c * per, hi = min(n, lo + per);
+  float acc = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const float v = fminf(fmaxf(o[(size_t)b * n + i], 0.f), 1.f) - g[(size_t)b * n + i];
+    acc = fmaf(v, v, acc);
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);  // wavefront (64-lane) reduction
+  __shared__ float w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[b * PSNR_CHUNKS + c] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+__global__ void psnr_final_kernel(const float* __restrict__ part, float* __restrict__ psnr, int n, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int c = 0; c < PSNR_CHUNKS; ++c) s += part[b * PSNR_CHUNKS + c];
+  const float mse = s / (float)n;
+  psnr[b] = 10.f * log10f(1.f / mse);
+}
+
+// =================================================================================== CT (own discretisation)
+// Ray-driven forward projector: one thread per (b, view, detector).  See oracle/pnp_oracle.py:radon_forward and
+// DESIGN.md for the geometry.  cs = [n_view] (cos, sin) pairs computed on the host in double precision.
+__global__ void radon_forward_kernel(const float* __restrict__ img, size_t istride, const float* __restrict__ sub,
+                                     float* __restrict__ sino, const float2* __restrict__ cs, int R, int V, int det,
+                                     int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * V * det) return;
+  const int s = (int)(i % det);
+  const int v = (int)((i / det) % V);
+  const int b = (int)(i / ((size_t)det * V));
+  const float c = cs[v].x, sn = cs[v].y;
+  const float half = (float)det / 2.f - 0.5f, off = (float)R / 2.f - 0.5f;
+  const float sp = subr((float)s, half);
+  const float* im = img + (size_t)b * istride;
+  const float sc = mulr(sp, c), ss = mulr(sp, sn);
+  float acc = 0.f;
+  for (int k = 0; k < det; ++k) {
+    const float t = subr((float)k, half);
+    const float px = addr(subr(sc, mulr(t, sn)), off);
+    const float py = addr(addr(ss, mulr(t, c)), off);
+    const float fx0 = floorf(px), fy0 = floorf(py);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    if (x0 < -1 || x0 >= R || y0 < -1 || y0 >= R) continue;
+    const float fx = subr(px, fx0), fy = subr(py, fy0);
+    const float wx0 = subr(1.f, fx), wy0 = subr(1.f, fy);
+    float sm = 0.f;
+    const bool xa = x0 >= 0, xb = x0 + 1 < R, ya = y0 >= 0, yb = y0 + 1 < R;
+    if (ya && xa) sm = addr(sm, mulr(im[(size_t)y0 * R + x0], mulr(wx0, wy0)));
+    if (ya && xb) sm = addr(sm, mulr(im[(size_t)y0 * R + x0 + 1], mulr(fx, wy0)));
+    if (yb && xa) sm = addr(sm, mulr(im[(size_t)(y0 + 1) * R + x0], mulr(wx0, fy)));
+    if (yb && xb) sm = addr(sm, mulr(im[(size_t)(y0 + 1) * R + x0 + 1], mulr(fx, fy)));
+    acc = addr(acc, sm);
+  }
+  sino[i] = sub ? subr(acc, sub[i]) : acc;
+}
+// Pixel-driven backprojection: one thread per pixel, linear interpolation along the detector.
+__global__ void radon_backproject_kernel(const float* __restrict__ sino, float* __restrict__ img,
+                                         const float2* __restrict__ cs, int R, int V, int det, int B, float scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * R * R) return;
+  const int x = (int)(i % R), y = (int)((i / R) % R);
+  const int b = (int)(i / ((size_t)R * R));
+  const float off = (float)R / 2.f - 0.5f, half = (float)det / 2.f - 0.5f;
+  const float xs = subr((float)x, off), ys = subr((float)y, off);
+  float acc = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float sp = addr(addr(mulr(xs, cs[v].x), mulr(ys, cs[v].y)), half);
+    const float f0 = floorf(sp);
+    const int s0 = (int)f0;
+    const float f = subr(sp, f0);
+    const float* row = sino + ((size_t)b * V + v) * det;
+    if (s0 >= 0 && s0 < det) acc = addr(acc, mulr(row[s0], subr(1.f, f)));
+    if (s0 + 1 >= 0 && s0 + 1 < det) acc = addr(acc, mulr(row[s0 + 1], f));
+  }
+  img[i] = scale == 1.f ? acc : divr(acc, scale);
+}
+// z = z - tau*(g + mu*(z - (x+u))); u = u + x - z; d = z - u                tasks/ct/solver.py:46-49
+__global__ void ct_update_kernel(const float* __restrict__ g, const float* __restrict__ xr, const float* zin,
+                                 const float* uin, float* xout, float* zout, float* uout, size_t istride,
+                                 float* __restrict__ d, const float* __restrict__ mu, const float* __restrict__ tau,
+                                 int stride, int HW, int B, int write_x) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  const float m = mu[b * stride], t = tau[b * stride];
+  const float z = zin[b * istride + r], u = uin[b * istride + r], xv = xr[i];
+  const float zn = subr(z, mulr(t, addr(g[i], mulr(m, subr(z, addr(xv, u))))));
+  const float un = subr(addr(u, xv), zn);
+  zout[b * istride + r] = zn;
+  uout[b * istride + r] = un;
+  d[i] = subr(zn, un);
+  if (write_x) xout[b * istride + r] = xv;
+}
+// z = x - tau * g                                                          tasks/ct/solver.py:80
+__global__ void ct_pg_step_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ d,
+                                  const float* __restrict__ tau, int stride, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  d[i] = subr(x[i], mulr(tau[(i / HW) * stride], g[i]));
+}
+__global__ void real_diff_slots_kernel(const float* __restrict__ a, const float* __restrict__ c, size_t istride,
+                                       float* __restrict__ d, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  d[i] = subr(a[b * istride + r], c[b * istride + r]);
+}
+
+int radon_table(int R, int V, std::vector<float2>* cs, int* det) {
+  *det = (int)std::ceil(std::sqrt(2.0) * R);
+  cs->resize(V);
+  const double stop = 179.0 / 180.0 * M_PI;
+  for (int v = 0; v < V; ++v) {
+    const double a = (V > 1) ? (double)v * (stop / (double)(V - 1)) : 0.0;   // numpy.linspace
+    const float af = (float)a;                                               // .astype(float32)
+    (*cs)[v] = make_float2((float)std::cos((double)af), (float)std::sin((double)af));
+  }
+  return PNPX_OK;
+}
+
+// scratch carve-up helper
+struct Carver {
+  char* p;
+  template <class T>
+  T* take(size_t n) {
+    T* r = reinterpret_cast<T*>(p);
+    p += (n * sizeof(T) + 255) & ~(size_t)255;
+    return r;
+  }
+};
+
+}  // namespace
+}  // namespace pnpx
+
+using namespace pnpx;
+
+#define LOCK_CTX(ctx)                         \
+  if (!(ctx)) {                               \
+    pnpx::set_error("null context");          \
+    return PNPX_ERR_ARG;                      \
+  }                                           \
+  std::lock_guard<std::mutex> _lk((ctx)->mu); \
+  PNPX_HIP(hipSetDevice((ctx)->device))
+#define REQUIRE(cond, msg)     \
+  if (!(cond)) {               \
+    pnpx::set_error(msg);      \
+    return PNPX_ERR_ARG;       \
+  }
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------- CDP
+int pnpx_cdp_forward(pnpx_ctx* ctx, const float* x, const float* mask, float* out, int B, int S, int H, int W,
+                     void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE(x && mask && out && B > 0 && S > 0, "pnpx_cdp_forward: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  FftPlan2D P;
+  PNPX_TRY(make_fft_plan(ctx, B * S, H, W, false, &P));
+  const int HW = H * W;
+  LoadCdp ld{reinterpret_cast<const float2*>(x), (size_t)HW, reinterpret_cast<const float2*>(mask), S, W, HW};
+  StoreC so{reinterpret_cast<float2*>(out), H, W};
+  LoadC lo{reinterpret_cast<const float2*>(out), H, W};
+  PNPX_TRY((launch_rows<false>(P, ld, so, s)));
+  PNPX_TRY((launch_cols<false, false>(P, lo, MidNone(), so, s)));
+  return PNPX_OK;
+}
+
+int pnpx_cdp_backward(pnpx_ctx* ctx, const float* y, const float* mask, float* out, int B, int S, int H, int W,
+                      void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE(y && mask && out && B > 0 && S > 0, "pnpx_cdp_backward: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t n = (size_t)B * S * H * W;
+  void* p;
+  PNPX_TRY(ctx_scratch(ctx, n * sizeof(float2) + 1024, &p));
+  PNPX_TRY(fft2(ctx, y, static_cast<float*>(p), B * S, H, W, true, false, s));
+  hipLaunchKernelGGL(cdp_adjoint_kernel, g1((size_t)B * H * W), dim3(256), 0, s, static_cast<const float2*>(p),
+                     reinterpret_cast<const float2*>(mask), reinterpret_cast<float2*>(out), S, H * W, B);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+
+int pnpx_pr_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const float* mask,
+                  const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int S, int H, int W,
+                  int T, void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE(vars_in && vars_out && y0 && mask && sigma_d && mu && tau && B > 0 && S > 0 && T >= 0 && param_stride >= T,
+          "pnpx_pr_iadmm: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HW = H * W;
+  const size_t is = 3 * (size_t)HW, n = (size_t)HW * B;
+  const float2* vin = reinterpret_cast<const float2*>(vars_in);
+  float2* vout = reinterpret_cast<float2*>(vars_out);
+  if (T == 0) {
+    PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+    return PNPX_OK;
+  }
+  void* p;
+  PNPX_TRY(ctx_scratch(ctx, n * S * sizeof(float2) + 2 * n * sizeof(float) + 4096, &p));
+  Carver cv{static_cast<char*>(p)};
+  float2* k = cv.take<float2>(n * S);
+  float* d = cv.take<float>(n);
+  float* xr = cv.take<float>(n);
+  FftPlan2D P;
+  PNPX_TRY(make_fft_plan(ctx, B * S, H, W, false, &P));
+  StoreC kst{k, H, W};
+  LoadC kld{k, H, W};
+  hipLaunchKernelGGL(real_of_diff_kernel, g1(n), dim3(256), 0, s, vin + HW, vin + 2 * HW, is, d, HW, B);
+  PNPX_LAUNCH_CHECK();
+  for (int i = 0; i < T; ++i) {
+    PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, xr, nullptr, B, H, W, s, nullptr));
+    const float2* zi = (i == 0 ? vin : vout) + HW;
+    const float2* ui = (i == 0 ? vin : vout) + 2 * HW;
+    LoadCdp ld{zi, is, reinterpret_cast<const float2*>(mask), S, W, HW};
+    PNPX_TRY((launch_rows<false>(P, ld, kst, s)));
+    PNPX_TRY((launch_cols<false, true>(P, kld, MidPrResidual{y0, W, HW}, kst, s)));
+    PNPX_TRY((launch_rows<true>(P, kld, kst, s)));
+    hipLaunchKernelGGL(pr_update_kernel, g1(n), dim3(256), 0, s, k, reinterpret_cast<const float2*>(mask), xr, zi, ui,
+                       vout, vout + HW, vout + 2 * HW, is, d, mu + i, tau + i, param_stride, S, HW, B, i == T - 1);
+    PNPX_LAUNCH_CHECK();
+  }
+  return PNPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------- SPI
+int pnpx_spi_inverse(pnpx_ctx* ctx, const float* ztilde, const float* K1, const float* K, const float* mu, float* out,
+                     int B, int H, int W, void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE(ztilde && K1 && K && mu && out && B > 0 && H > 0 && W > 0, "pnpx_spi_inverse: bad argument");
+  hipLaunchKernelGGL(spi_inverse_kernel, g1((size_t)B * H * W), dim3(256), 0, static_cast<hipStream_t>(stream), ztilde,
+                     K1, K, mu, out, H * W, B);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+
+int pnpx_spi_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* x0, const float* Kmap,
+                  const float* sigma_d, const float* mu, int param_stride, int B, int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE(vars_in && vars_out && x0 && Kmap && sigma_d && mu && B > 0 && T >= 0 && param_stride >= T,
+          "pnpx_spi_admm: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HW = H * W;
+  const size_t is = 3 * (size_t)HW, n = (size_t)HW * B;
+  if (T == 0) {
+    PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float) * is * B, hipMemcpyDeviceToDevice, s));
+    return PNPX_OK;
+  }
+  void* p;
+  PNPX_TRY(ctx_scratch(ctx, 2 * n * sizeof(float) + 4096, &p));
+  Carver cv{static_cast<char*>(p)};
+  float* d = cv.take<float>(n);
+  float* xr = cv.take<float>(n);
+  for (int i = 0; i < T; ++i) {
+    // x of iteration i: state x on the first pass, the previous denoiser output (already in the x slot) later
+    const float* xin = (i == 0) ? vars_in : vars_out;
+    const float* uin = ((i == 0) ? vars_in : vars_out) + 2 * HW;
+    hipLaunchKernelGGL(spi_step_kernel, g1(n), dim3(256), 0, s, xin, uin, is, x0, Kmap, vars_out + HW,
+                       vars_out + 2 * HW, d, mu + i, param_stride, HW, B);
+    PNPX_LAUNCH_CHECK();
+    PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, xr, nullptr, B, H, W, s, nullptr));
+    hipLaunchKernelGGL(copy_real_slot_kernel, g1(n), dim3(256), 0, s, xr, vars_out, is, HW, B);
+    PNPX_LAUNCH_CHECK();
+  }
+  return PNPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------- PSNR
+int pnpx_psnr(pnpx_ctx* ctx, const float* output, const float* gt, float* psnr, int B, int n_per_item, void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE(output && gt && psnr && B > 0 && n_per_item > 0, "pnpx_psnr: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  void* p;
+  PNPX_TRY(ctx_scratch(ctx, (size_t)B * PSNR_CHUNKS * sizeof(float) + 1024, &p));
+  // NOTE: uses the tail of nothing else -- solver loops never run concurrently with psnr on one ctx (mutex).
+  hipLaunchKernelGGL(psnr_partial_kernel, dim3(PSNR_CHUNKS, B), dim3(256), 0, s, output, gt, static_cast<float*>(p),
+                     n_per_item);
+  PNPX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(psnr_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, static_cast<const float*>(p), psnr,
+                     n_per_item, B);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+
+// ------------------------------------------------------------------------------------------- CT
+int pnpx_radon_det_count(int R) { return (int)std::ceil(std::sqrt(2.0) * R); }
+
+static int upload_cs(pnpx_ctx* ctx, int R, int V, hipStream_t s, Carver* cv, const float2** cs_dev, int* det) {
+  std::vector<float2> cs;
+  PNPX_TRY(radon_table(R, V, &cs, det));
+  float2* d = cv->take<float2>(V);
+  // small synchronous upload (host table is a local): hipMemcpy waits, so the vector may die afterwards
+  PNPX_HIP(hipMemcpyAsync(d, cs.data(), sizeof(float2) * V, hipMemcpyHostToDevice, s));
+  PNPX_HIP(hipStreamSynchronize(s));
+  (void)ctx;
+  *cs_dev = d;
+  return PNPX_OK;
+}
+
+int pnpx_radon_forward(pnpx_ctx* ctx, const float* img, float* sino, int B, int R, int n_view, void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE(img && sino && B > 0 && R > 0 && n_view > 0, "pnpx_radon_forward: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  void* p;
+  PNPX_TRY(ctx_scratch(ctx, sizeof(float2) * n_view + 4096, &p));
+  Carver cv{static_cast<char*>(p)};
+  const float2* cs;
+  int det;
+  PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &cs, &det));
+  hipLaunchKernelGGL(radon_forward_kernel, g1((size_t)B * n_view * det), dim3(256), 0, s, img, (size_t)R * R,
+                     (const float*)nullptr, sino, cs, R, n_view, det, B);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+
+int pnpx_radon_backprojection(pnpx_ctx* ctx, const float* sino, float* img, int B, int R, int n_view, void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE(img && sino && B > 0 && R > 0 && n_view > 0, "pnpx_radon_backprojection: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  void* p;
+  PNPX_TRY(ctx_scratch(ctx, sizeof(float2) * n_view + 4096, &p));
+  Carver cv{static_cast<char*>(p)};
+  const float2* cs;
+  int det;
+  PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &cs, &det));
+  hipLaunchKernelGGL(radon_backproject_kernel, g1((size_t)B * R * R), dim3(256), 0, s, sino, img, cs, R, n_view, det,
+                     B, 1.f);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+
+int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
+                  const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int R, int T,
+                  void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE(vars_in && vars_out && y0 && sigma_d && mu && tau && B > 0 && R > 0 && n_view > 0 && T >= 0 &&
+              param_stride >= T && opnorm > 0.f,
+          "pnpx_ct_iadmm: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HW = R * R;
+  const size_t is = 3 * (size_t)HW, n = (size_t)HW * B;
+  if (T == 0) {
+    PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float) * is * B, hipMemcpyDeviceToDevice, s));
+    return PNPX_OK;
+  }
+  const int det = pnpx_radon_det_count(R);
+  void* p;
+  PNPX_TRY(ctx_scratch(ctx, (3 * n + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 8192, &p));
+  Carver cv{static_cast<char*>(p)};
+  const float2* cs;
+  int det2;
+  PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &cs, &det2));
+  float* d = cv.take<float>(n);
+  float* xr = cv.take<float>(n);
+  float* g = cv.take<float>(n);
+  float* sino = cv.take<float>((size_t)B * n_view * det);
+  const float op2 = (float)((double)opnorm * (double)opnorm);  // backprojection / opnorm**2   transforms.py:476-477
+  hipLaunchKernelGGL(real_diff_slots_kernel, g1(n), dim3(256), 0, s, vars_in + HW, vars_in + 2 * HW, is, d, HW, B);
+  PNPX_LAUNCH_CHECK();
+  for (int i = 0; i < T; ++i) {
+    PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, xr, nullptr, B, R, R, s, nullptr));
+    const float* zi = ((i == 0) ? vars_in : vars_out) + HW;
+    const float* ui = ((i == 0) ? vars_in : vars_out) + 2 * HW;
+    hipLaunchKernelGGL(radon_forward_kernel, g1((size_t)B * n_view * det), dim3(256), 0, s, zi, is, y0, sino, cs, R,
+                       n_view, det, B);
+    PNPX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(radon_backproject_kernel, g1(n), dim3(256), 0, s, sino, g, cs, R, n_view, det, B, op2);
+    PNPX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ct_update_kernel, g1(n), dim3(256), 0, s, g, xr, zi, ui, vars_out, vars_out + HW,
+                       vars_out + 2 * HW, is, d, mu + i, tau + i, param_stride, HW, B, i == T - 1);
+    PNPX_LAUNCH_CHECK();
+  }
+  return PNPX_OK;
+}
+
+int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
+               const float* sigma_d, const float* tau, int param_stride, int B, int R, int T, void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE(vars_in && vars_out && y0 && sigma_d && tau && B > 0 && R > 0 && n_view > 0 && T >= 0 &&
+              param_stride >= T && opnorm > 0.f,
+          "pnpx_ct_pg: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int HW = R * R;
+  const size_t n = (size_t)HW * B;
+  if (T == 0) {
+    PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+    return PNPX_OK;
+  }
+  const int det = pnpx_radon_det_count(R);
+  void* p;
+  PNPX_TRY(ctx_scratch(ctx, (2 * n + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 8192, &p));
+  Carver cv{static_cast<char*>(p)};
+  const float2* cs;
+  int det2;
+  PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &cs, &det2));
+  float* d = cv.take<float>(n);
+  float* g = cv.take<float>(n);
+  float* sino = cv.take<float>((size_t)B * n_view * det);
+  const float op2 = (float)((double)opnorm * (double)opnorm);
+  for (int i = 0; i < T; ++i) {
+    const float* xi = (i == 0) ? vars_in : vars_out;
+    hipLaunchKernelGGL(radon_forward_kernel, g1((size_t)B * n_view * det), dim3(256), 0, s, xi, (size_t)HW, y0, sino,
+                       cs, R, n_view, det, B);
+    PNPX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(radon_backproject_kernel, g1(n), dim3(256), 0, s, sino, g, cs, R, n_view, det, B, op2);
+    PNPX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ct_pg_step_kernel, g1(n), dim3(256), 0, s, g, xi, d, tau + i, param_stride, HW, B);
+    PNPX_LAUNCH_CHECK();
+    PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, vars_out, nullptr, B, R, R, s, nullptr));
+  }
+  return PNPX_OK;
+}
+
+}  // extern "C"

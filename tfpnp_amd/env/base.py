@@ -1,0 +1,68 @@
+"""The caller contract of the hot path: a minimal PnPEnv (tfpnp/env/base.py:121-191, 237-242).
+
+Only what SURVEY.md section 8(b) lists is reproduced: live-row gather (`idx_left`), the solver call, state /
+output write-back, delta-PSNR reward and the idx_left shrink.  Observation packing for the RL policy, the
+policy itself and training are out of scope.  `metric_fn` runs natively (pnpx_psnr).
+"""
+import torch
+
+from .. import ops
+
+
+def torch_psnr(output, gt):
+    """tfpnp/env/base.py:237-242 -> [B,1]"""
+    return ops.psnr(output, gt)
+
+
+class PnPEnv:
+    def __init__(self, solver, max_episode_step, aux_keys=None):
+        self.solver = solver
+        self.max_episode_step = max_episode_step
+        self.cur_step = 0
+        self.state = None
+        self.idx_left = None
+        self.last_metric = 0
+        self.metric_fn = torch_psnr
+        self.aux_keys = aux_keys
+
+    def reset(self, data):
+        """data: dict of device tensors with at least x0, gt, output + the solver's aux inputs.  base.py:121-155"""
+        self.cur_step = 0
+        data = dict(data)
+        data['solver'] = self.solver.reset(data)
+        data['output'] = data['output'].clone()
+        self.state = data
+        B = data['gt'].shape[0]
+        self.idx_left = torch.arange(0, B, device=data['gt'].device)
+        self.last_metric = self._compute_metric()
+        return self.state
+
+    def step(self, action):
+        """base.py:157-191.  action: dict of [n_live, action_pack] tensors + 'idx_stop' [n_live]."""
+        self.cur_step += 1
+        il = self.idx_left
+        with torch.no_grad():
+            aux = tuple(a[il, ...] for a in self.solver.filter_aux_inputs(self.state))
+            inputs = (self.state['solver'][il, ...], aux)
+            parameters = self.solver.filter_hyperparameter(action)
+            solver_state = self.solver(inputs, parameters)
+        self.state['output'][il, ...] = self.solver.get_output(solver_state)
+        self.state['solver'][il, ...] = solver_state
+        reward = self._compute_reward()
+        idx_stop = action['idx_stop']
+        self.idx_left = il[idx_stop == 0]
+        all_done = len(self.idx_left) == 0
+        done = idx_stop.detach()
+        if self.cur_step == self.max_episode_step:
+            all_done = True
+            done = torch.ones_like(idx_stop)
+        return reward, all_done, {'done': done}
+
+    def _compute_metric(self):
+        return self.metric_fn(self.state['output'], self.state['gt'])
+
+    def _compute_reward(self):
+        metric = self._compute_metric()
+        reward = metric - self.last_metric
+        self.last_metric = metric
+        return reward

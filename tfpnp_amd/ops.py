@@ -1,0 +1,366 @@
+"""Tensor-level wrappers over the C ABI (include/pnpx.h): torch tensors in, torch tensors out.
+
+PyTorch is plumbing here (device memory, streams); every op below is one libpnpx.so call on the caller's
+current HIP stream.  All ops require contiguous fp32 tensors on a ROCm device; anything else raises.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PnpxError, check
+
+
+class Context:
+    """One pnpx_ctx: a device, (optionally) packed denoiser weights, and the native workspaces."""
+
+    def __init__(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise PnpxError(f"tfpnp_amd runs on MI355X (ROCm 'cuda' devices) only, got {device}; there is no CPU path")
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        h = C.c_void_p()
+        check(_lib.lib().pnpx_ctx_create(self.device.index, C.byref(h)))
+        self._h = h
+        self._has_weights = False
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise PnpxError("context already destroyed")
+        return self._h
+
+    def load_unet(self, state_dict):
+        """state_dict: mapping with the reference's 56 key names -> tensors/ndarrays (any device)."""
+        from .synth import unet_param_specs
+        chunks = []
+        for key, shape in unet_param_specs():
+            if key not in state_dict:
+                raise PnpxError(f"denoiser state_dict is missing '{key}'")
+            v = state_dict[key]
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if tuple(v.shape) != tuple(shape):
+                raise PnpxError(f"'{key}' has shape {tuple(v.shape)}, expected {tuple(shape)}")
+            chunks.append(np.ascontiguousarray(v, dtype=np.float32).reshape(-1))
+        flat = np.concatenate(chunks)
+        check(_lib.lib().pnpx_unet_load(self.handle, flat.ctypes.data_as(C.c_void_p), flat.size))
+        self._has_weights = True
+
+    def reserve(self, B, H, W):
+        check(_lib.lib().pnpx_ctx_reserve(self.handle, B, H, W))
+
+    def bytes(self):
+        return int(_lib.lib().pnpx_ctx_bytes(self.handle))
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().pnpx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+_default_lock = threading.Lock()
+
+
+def default_context(device):
+    """Weight-less per-device context for the stateless transforms (fft2, cdp, psnr ...)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise PnpxError(f"tfpnp_amd has no CPU path (tensor on {device})")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    with _default_lock:
+        if idx not in _default_ctx:
+            _default_ctx[idx] = Context(torch.device("cuda", idx))
+        return _default_ctx[idx]
+
+
+# ------------------------------------------------------------------------------------------------- helpers
+def _f32(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise PnpxError(f"{name}: expected a torch.Tensor")
+    if t.device.type != "cuda":
+        raise PnpxError(f"{name}: tensor is on {t.device}; tfpnp_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise PnpxError(f"{name}: expected float32, got {t.dtype}")
+    return t.detach().contiguous()
+
+
+def _mask_u8(mask, name="mask"):
+    if mask.device.type != "cuda":
+        raise PnpxError(f"{name}: tensor is on {mask.device}; tfpnp_amd has no CPU path")
+    m = mask.detach()
+    if m.dtype == torch.bool:
+        return m.contiguous().view(torch.uint8)
+    return (m != 0).contiguous().view(torch.uint8)
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _params(B, *ps):
+    """Hyper-parameter tensors [B,T] (or [B]) -> contiguous fp32 [B,T], common T and row stride."""
+    out = []
+    T = None
+    for i, p in enumerate(ps):
+        p = _f32(p, f"parameter {i}")
+        if p.dim() == 1:
+            p = p.view(-1, 1)
+        if p.dim() != 2 or p.shape[0] != B:
+            raise PnpxError(f"hyper-parameter {i} must be [B, iter_num] with B={B}, got {tuple(p.shape)}")
+        T = p.shape[1] if T is None else T
+        if p.shape[1] != T:
+            raise PnpxError("hyper-parameters disagree on iter_num")
+        out.append(p)
+    return out, T
+
+
+# ------------------------------------------------------------------------------------------------- denoiser
+def unet_denoise(ctx, x, sigma, return_preclamp=False):
+    x = _f32(x, "x")
+    sigma = _f32(sigma, "sigma").reshape(-1)
+    if x.dim() != 4 or x.shape[1] != 1:
+        raise PnpxError(f"denoiser input must be [B,1,H,W], got {tuple(x.shape)}")
+    B, _, H, W = x.shape
+    if sigma.numel() != B:
+        raise PnpxError(f"sigma must have {B} entries, got {sigma.numel()}")
+    out = torch.empty_like(x)
+    pre = torch.empty_like(x) if return_preclamp else None
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pnpx_unet_denoise(ctx.handle, _p(x), _p(sigma), _p(out), _p(pre) if pre is not None else None,
+                                           B, H, W, _stream(x)))
+    return (out, pre) if return_preclamp else out
+
+
+def unet_profile(ctx, x, sigma):
+    """[(name, ms, flops)] per kernel launch of one denoiser forward (HIP events on the current stream)."""
+    x = _f32(x, "x")
+    sigma = _f32(sigma, "sigma").reshape(-1)
+    B, _, H, W = x.shape
+    out = torch.empty_like(x)
+    cap = 64
+    ms = (C.c_float * cap)()
+    fl = (C.c_double * cap)()
+    names = (C.c_char_p * cap)()
+    n = C.c_int(0)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pnpx_unet_profile(ctx.handle, _p(x), _p(sigma), _p(out), B, H, W, _stream(x), cap, ms, fl,
+                                           names, C.byref(n)))
+    return [(names[i].decode(), float(ms[i]), float(fl[i])) for i in range(n.value)]
+
+
+# ------------------------------------------------------------------------------------------------- transforms
+def fft2(x, inverse=False, centered=True, ctx=None):
+    x = _f32(x, "data")
+    if x.dim() < 3 or x.shape[-1] != 2:
+        raise AssertionError("fft2 expects [..., H, W, 2]")  # the reference asserts data.size(-1) == 2
+    H, W = x.shape[-3], x.shape[-2]
+    n_img = x.numel() // (H * W * 2)
+    out = torch.empty_like(x)
+    ctx = ctx or default_context(x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pnpx_fft2(ctx.handle, _p(x), _p(out), n_img, H, W, int(inverse), int(centered), _stream(x)))
+    return out
+
+
+def cdp_forward(x, mask, ctx=None):
+    mask = _f32(mask, "mask")
+    if mask.shape[-1] != 2:
+        raise AssertionError("mask must be complex [..., 2]")
+    x = _f32(x, "data")
+    if x.dim() == 4:
+        x = torch.stack([x, torch.zeros_like(x)], -1)
+    B, S, H, W, _ = mask.shape
+    out = torch.empty_like(mask)
+    ctx = ctx or default_context(x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pnpx_cdp_forward(ctx.handle, _p(x), _p(mask), _p(out), B, S, H, W, _stream(x)))
+    return out
+
+
+def cdp_backward(y, mask, ctx=None):
+    mask = _f32(mask, "mask")
+    y = _f32(y, "data")
+    B, S, H, W, _ = mask.shape
+    out = torch.empty((B, 1, H, W, 2), device=y.device, dtype=torch.float32)
+    ctx = ctx or default_context(y.device)
+    with torch.cuda.device(y.device):
+        check(_lib.lib().pnpx_cdp_backward(ctx.handle, _p(y), _p(mask), _p(out), B, S, H, W, _stream(y)))
+    return out
+
+
+def spi_inverse(ztilde, K1, K, mu, ctx=None):
+    ztilde = _f32(ztilde, "ztilde")
+    B, _, H, W = ztilde.shape
+    K1 = _f32(K1, "K1").expand_as(ztilde).contiguous()
+    K = _f32(K, "K").reshape(B, -1)[:, 0].contiguous()
+    mu = _f32(mu, "mu").reshape(B, -1)[:, 0].contiguous()
+    out = torch.empty_like(ztilde)
+    ctx = ctx or default_context(ztilde.device)
+    with torch.cuda.device(ztilde.device):
+        check(_lib.lib().pnpx_spi_inverse(ctx.handle, _p(ztilde), _p(K1), _p(K), _p(mu), _p(out), B, H, W,
+                                          _stream(ztilde)))
+    return out
+
+
+def psnr(output, gt, ctx=None):
+    output = _f32(output, "output")
+    gt = _f32(gt, "gt")
+    B = output.shape[0]
+    n = output.numel() // B
+    if gt.numel() != output.numel():
+        raise PnpxError("psnr: output and gt differ in size")
+    out = torch.empty((B, 1), device=output.device, dtype=torch.float32)
+    ctx = ctx or default_context(output.device)
+    with torch.cuda.device(output.device):
+        check(_lib.lib().pnpx_psnr(ctx.handle, _p(output), _p(gt), _p(out), B, n, _stream(output)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- solver loops
+def _vars(variables, nvar, complex_):
+    v = _f32(variables, "variables")
+    want = 5 if complex_ else 4
+    if v.dim() != want or v.shape[1] != nvar or (complex_ and v.shape[-1] != 2):
+        raise PnpxError(f"solver state must be [B,{nvar},H,W{',2' if complex_ else ''}], got {tuple(v.shape)}")
+    return v
+
+
+def _csmri_common(fn_name, nvar, ctx, variables, y0, mask, params, iter_num):
+    v = _vars(variables, nvar, True)
+    B, _, H, W, _ = v.shape
+    y0 = _f32(y0, "y0")
+    m = _mask_u8(mask)
+    if y0.numel() != B * H * W * 2 or m.numel() != B * H * W:
+        raise PnpxError("y0/mask do not match the state's [B,H,W]")
+    ps, T = _params(B, *params)
+    if iter_num is not None:
+        if iter_num > T:
+            raise PnpxError(f"iter_num {iter_num} exceeds the {T} hyper-parameter columns provided")
+        T = iter_num
+    out = torch.empty_like(v)
+    stride = ps[0].shape[1]
+    fn = getattr(_lib.lib(), fn_name)
+    with torch.cuda.device(v.device):
+        check(fn(ctx.handle, _p(v), _p(out), _p(y0), _p(m), *[_p(p) for p in ps], stride, B, H, W, T, _stream(v)))
+    return out
+
+
+def csmri_admm(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
+    return _csmri_common("pnpx_csmri_admm", 3, ctx, variables, y0, mask, (sigma_d, mu), iter_num)
+
+
+def csmri_hqs(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
+    return _csmri_common("pnpx_csmri_hqs", 2, ctx, variables, y0, mask, (sigma_d, mu), iter_num)
+
+
+def csmri_pg(ctx, variables, y0, mask, sigma_d, tau, iter_num=None):
+    return _csmri_common("pnpx_csmri_pg", 1, ctx, variables, y0, mask, (sigma_d, tau), iter_num)
+
+
+def csmri_apg(ctx, variables, y0, mask, sigma_d, tau, beta, iter_num=None):
+    return _csmri_common("pnpx_csmri_apg", 2, ctx, variables, y0, mask, (sigma_d, tau, beta), iter_num)
+
+
+def csmri_redadmm(ctx, variables, y0, mask, sigma_d, mu, lamda, iter_num=None):
+    return _csmri_common("pnpx_csmri_redadmm", 3, ctx, variables, y0, mask, (sigma_d, mu, lamda), iter_num)
+
+
+def pr_iadmm(ctx, variables, y0, mask, sigma_d, mu, tau, iter_num=None):
+    v = _vars(variables, 3, True)
+    B, _, H, W, _ = v.shape
+    y0 = _f32(y0, "y0")
+    mask = _f32(mask, "mask")
+    S = mask.shape[1]
+    if tuple(mask.shape) != (B, S, H, W, 2) or tuple(y0.shape) != (B, S, H, W):
+        raise PnpxError("pr_iadmm: y0 must be [B,S,H,W] and mask [B,S,H,W,2]")
+    ps, T = _params(B, sigma_d, mu, tau)
+    T = T if iter_num is None else iter_num
+    out = torch.empty_like(v)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().pnpx_pr_iadmm(ctx.handle, _p(v), _p(out), _p(y0), _p(mask), *[_p(p) for p in ps],
+                                       ps[0].shape[1], B, S, H, W, T, _stream(v)))
+    return out
+
+
+def spi_admm(ctx, variables, x0, Kmap, sigma_d, mu, iter_num=None):
+    v = _vars(variables, 3, False)
+    B, _, H, W = v.shape
+    x0 = _f32(x0, "x0")
+    Kmap = _f32(Kmap, "K")
+    if x0.numel() != B * H * W or Kmap.numel() != B * H * W:
+        raise PnpxError("spi_admm: x0 and K must be [B,1,H,W]")
+    ps, T = _params(B, sigma_d, mu)
+    T = T if iter_num is None else iter_num
+    out = torch.empty_like(v)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().pnpx_spi_admm(ctx.handle, _p(v), _p(out), _p(x0), _p(Kmap), *[_p(p) for p in ps],
+                                       ps[0].shape[1], B, H, W, T, _stream(v)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- CT
+def radon_det_count(R):
+    return int(_lib.lib().pnpx_radon_det_count(int(R)))
+
+
+def radon_forward(img, n_view, ctx=None):
+    img = _f32(img, "img")
+    B, _, R, R2 = img.shape
+    if R != R2:
+        raise PnpxError("radon_forward: square images only")
+    out = torch.empty((B, 1, n_view, radon_det_count(R)), device=img.device, dtype=torch.float32)
+    ctx = ctx or default_context(img.device)
+    with torch.cuda.device(img.device):
+        check(_lib.lib().pnpx_radon_forward(ctx.handle, _p(img), _p(out), B, R, n_view, _stream(img)))
+    return out
+
+
+def radon_backprojection(sino, R, ctx=None):
+    sino = _f32(sino, "sino")
+    B, _, V, det = sino.shape
+    if det != radon_det_count(R):
+        raise PnpxError(f"sinogram has {det} detectors, resolution {R} needs {radon_det_count(R)}")
+    out = torch.empty((B, 1, R, R), device=sino.device, dtype=torch.float32)
+    ctx = ctx or default_context(sino.device)
+    with torch.cuda.device(sino.device):
+        check(_lib.lib().pnpx_radon_backprojection(ctx.handle, _p(sino), _p(out), B, R, V, _stream(sino)))
+    return out
+
+
+def ct_iadmm(ctx, variables, y0, n_view, opnorm, sigma_d, mu, tau, iter_num=None):
+    v = _vars(variables, 3, False)
+    B, _, R, _ = v.shape
+    y0 = _f32(y0, "y0")
+    ps, T = _params(B, sigma_d, mu, tau)
+    T = T if iter_num is None else iter_num
+    out = torch.empty_like(v)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().pnpx_ct_iadmm(ctx.handle, _p(v), _p(out), _p(y0), int(n_view), float(opnorm),
+                                       *[_p(p) for p in ps], ps[0].shape[1], B, R, T, _stream(v)))
+    return out
+
+
+def ct_pg(ctx, variables, y0, n_view, opnorm, sigma_d, tau, iter_num=None):
+    v = _vars(variables, 1, False)
+    B, _, R, _ = v.shape
+    y0 = _f32(y0, "y0")
+    ps, T = _params(B, sigma_d, tau)
+    T = T if iter_num is None else iter_num
+    out = torch.empty_like(v)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().pnpx_ct_pg(ctx.handle, _p(v), _p(out), _p(y0), int(n_view), float(opnorm),
+                                    *[_p(p) for p in ps], ps[0].shape[1], B, R, T, _stream(v)))
+    return out

@@ -1,0 +1,52 @@
+"""UNetDenoiser2D on MI355X -- drop-in for tfpnp/pnp/denoiser/base.py:7-32.
+
+Same call surface: `denoiser(x[B,1,H,W], sigma[B]) -> clamp(UNet(cat[x, sigma*1]), 0, 1)`, weights frozen,
+loaded from a state_dict with the reference's key names (`inc.conv.conv-0.conv2d.weight` ...).  The forward
+pass is one libpnpx.so call (hand-written gfx950 kernels); there is no PyTorch/CPU fallback.
+"""
+import os
+
+import torch
+
+from ... import ops
+from ..._lib import PnpxError
+
+CURRENT_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+class UNetDenoiser2D(torch.nn.Module):
+    def __init__(self, ckpt_path=None, state_dict=None):
+        super().__init__()
+        if state_dict is None:
+            if ckpt_path is None:
+                ckpt_path = os.path.join(CURRENT_DIR, 'pretrained', 'unet-nm.pt')
+                if not os.path.exists(ckpt_path):
+                    # same error contract as the reference (denoiser/base.py:12-13)
+                    raise ValueError('Default ckpt not found, you have to provide a ckpt path')
+            state_dict = torch.load(ckpt_path, map_location='cpu')
+        self._state = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else torch.as_tensor(v))
+                       for k, v in state_dict.items()}
+        self._ctx = {}  # device index -> ops.Context holding the packed weights
+
+    def state_dict(self, *a, **k):  # the frozen weights, reference key names
+        return dict(self._state)
+
+    def context(self, device):
+        """The native context (packed weights + workspaces) for `device`; created on first use."""
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise PnpxError(f'UNetDenoiser2D runs on MI355X only (tensor on {device}); there is no CPU path')
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in self._ctx:
+            ctx = ops.Context(torch.device('cuda', idx))
+            ctx.load_unet(self._state)
+            self._ctx[idx] = ctx
+        return self._ctx[idx]
+
+    def forward(self, x, sigma):
+        # x: [B,1,H,W]; sigma: [B]      (denoiser/base.py:23-32)
+        return ops.unet_denoise(self.context(x.device), x, sigma)
+
+    def forward_preclamp(self, x, sigma):
+        """(clamped, pre-clamp) outputs -- the pre-clamp UNet output is what the parity tests compare."""
+        return ops.unet_denoise(self.context(x.device), x, sigma, return_preclamp=True)
