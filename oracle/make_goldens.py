@@ -124,7 +124,15 @@ def main():
         sol = spi.ADMMSolver_SPI(den)
         v0 = sol.reset({"x0": t(d["x0"])})
         st = sol((v0, (t(d["x0"]), t(d["K"]))), (t(sg), t(m)))
-        save("spi_B2_64x64", spi_inverse=zi, admm_T4=st, in_sha=sha(zt, K1, d["x0"], sg, m))
+        # states after every single iteration (teacher-forcing fixtures: the bisection prox is discontinuous,
+        # so free-running multi-iteration parity is only meaningful up to its 1.1/2**10 quantum)
+        steps = {}
+        v = v0
+        for i in range(4):
+            v = sol((v, (t(d["x0"]), t(d["K"]))), (t(sg[:, i:i + 1]), t(m[:, i:i + 1])))
+            steps[f"admm_step{i + 1}"] = v
+        assert torch.equal(v, st)
+        save("spi_B2_64x64", spi_inverse=zi, admm_T4=st, in_sha=sha(zt, K1, d["x0"], sg, m), **steps)
 
         # (6) PSNR
         print("[6] psnr")

@@ -222,8 +222,21 @@ def test_spi_golden(den):
     m = rs.uniform(50, 120, (B, 4)).astype(np.float32)
     sol = spi.ADMMSolver_SPI(den)
     x0 = g(d["x0"])
+    # The 10-step bisection prox is a DISCONTINUOUS map (output quantum 1.1/2**10): an fp32-round-off
+    # difference in its input flips a bracket decision at a few pixels, and the (random-weight, expansive) UNet
+    # spreads each flip over its receptive field.  Parity is therefore checked per iteration with the
+    # reference's own state as input (teacher forcing): bit-exact z/u up to rare flips, 1e-4 on everything.
+    prev = sol.reset({"x0": x0})
+    for i in range(4):
+        st = sol((prev, (x0, g(d["K"]))), (g(sg[:, i:i + 1]), g(m[:, i:i + 1])))
+        ref = gd[f"admm_step{i + 1}"]
+        assert rel(st, ref) < TOL
+        zdiff = np.abs(st[:, 1].cpu().numpy() - ref[:, 1])
+        assert np.mean(zdiff > 0) < 1e-3 and zdiff.max() <= 1.1 / 1024 + 1e-6
+        prev = g(ref)
+    # free-running 4 iterations: equal up to the amplification of those quantised flips
     st = sol((sol.reset({"x0": x0}), (x0, g(d["K"]))), (g(sg), g(m)))
-    assert rel(st, gd["admm_T4"]) < TOL
+    assert rel(st, gd["admm_T4"]) < 5e-3
 
 
 # ------------------------------------------------------------------------------------------- PSNR / env

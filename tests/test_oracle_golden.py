@@ -104,6 +104,10 @@ def test_spi(den):
     x0 = t(d["x0"])
     st = O.spi_admm(den, O.admm_reset(x0), x0, t(d["K"]), t(sg), t(m))
     assert rel(st, g["admm_T4"]) < 5e-6
+    v = O.admm_reset(x0)
+    for i in range(4):
+        v = O.spi_admm(den, v, x0, t(d["K"]), t(sg[:, i:i + 1]), t(m[:, i:i + 1]))
+        assert rel(v, g[f"admm_step{i + 1}"]) < 5e-6
 
 
 def test_psnr():

@@ -7,6 +7,8 @@ import ctypes as C
 import os
 import threading
 
+import torch  # noqa: F401  -- must come first: libpnpx.so has to bind to the HIP runtime PyTorch already loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpnpx.so")
 

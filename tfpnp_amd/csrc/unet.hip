@@ -27,14 +27,17 @@ __global__ void prep_input_kernel(const float* __restrict__ x, const float* __re
   d[(size_t)Hp * Wp] = sigma[(size_t)b * sigma_stride];
 }
 
-// MaxPool2d(2) (models/unet.py:82-85), floor semantics.
-__global__ void maxpool2_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int H, int W) {
+// MaxPool2d(2) (models/unet.py:82-85), floor semantics.  One thread per output pixel, flat index.
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       size_t n_out, int H, int W) {
   const int Ho = H / 2, Wo = W / 2;
   const int Hp = padded_h(H), Wp = padded_w(W), Hpo = padded_h(Ho), Wpo = padded_w(Wo);
-  const int xo = blockIdx.x * blockDim.x + threadIdx.x;
-  const int yo = blockIdx.y;
-  const size_t bc = blockIdx.z;  // b*C + c
-  if (xo >= Wo) return;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const int xo = (int)(i % Wo);
+  const size_t t = i / Wo;
+  const int yo = (int)(t % Ho);
+  const size_t bc = t / Ho;
   const float* s = src + bc * Hp * Wp + (size_t)(2 * yo + 1) * Wp + 2 * xo + PADL;
   const float2 r0 = *reinterpret_cast<const float2*>(s);
   const float2 r1 = *reinterpret_cast<const float2*>(s + Wp);
@@ -43,14 +46,16 @@ __global__ void maxpool2_kernel(const float* __restrict__ src, float* __restrict
 
 // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (models/unet.py:99): src = dst*(in-1)/(out-1),
 // i0 = floor(src), i1 = i0 + (i0 < in-1), weights (1-l, l); same association as ATen's CPU kernel.
-__global__ void upsample2x_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int h, int w,
-                                  float sy, float sx) {
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         size_t n_out, int h, int w, float sy, float sx) {
   const int H = 2 * h, W = 2 * w;
   const int hp = padded_h(h), wp = padded_w(w), Hp = padded_h(H), Wp = padded_w(W);
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y;
-  const size_t bc = blockIdx.z;
-  if (x >= W) return;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const int x = (int)(i % W);
+  const size_t t = i / W;
+  const int y = (int)(t % H);
+  const size_t bc = t / H;
   const float fy = sy * y, fx = sx * x;
   const int y0 = (int)fy, x0 = (int)fx;
   const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
@@ -206,8 +211,9 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
   PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0]));
   for (int l = 1; l < 5; ++l) {
     const ActDesc& src = P.x[l - 1];
-    hipLaunchKernelGGL(maxpool2_kernel, grid2d(src.W / 2, src.H / 2, (size_t)B * src.C, bx), dim3(bx), 0, s,
-                       ptr(src), ptr(P.p[l]), src.C, src.H, src.W);
+    const size_t n_pool = (size_t)B * src.C * (src.H / 2) * (src.W / 2);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((n_pool + 255) / 256)), dim3(256), 0, s, ptr(src),
+                       ptr(P.p[l]), n_pool, src.H, src.W);
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(rec.mark("maxpool2", 0));
     PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l]));
@@ -218,8 +224,9 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     const int h = below->H, w = below->W;
     const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
-    hipLaunchKernelGGL(upsample2x_kernel, grid2d(2 * w, 2 * h, (size_t)B * below->C, bx), dim3(bx), 0, s,
-                       ptr(*below), ptr(P.u[l]), below->C, h, w, sy, sx);
+    const size_t n_up = (size_t)B * below->C * (2 * h) * (2 * w);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((n_up + 255) / 256)), dim3(256), 0, s, ptr(*below),
+                       ptr(P.u[l]), n_up, h, w, sy, sx);
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(rec.mark("upsample2x", 0));
     PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l]));
