@@ -51,8 +51,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--ratio", type=int, default=4, help="radial mask undersampling (4 or 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16, help="items in the bounded CPU-baseline sample")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=24, help="items in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
