@@ -46,6 +46,9 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx);
 /* Pre-size the internal workspaces for batches up to B of H x W images (optional; otherwise they
  * grow on first use, which synchronises the device once). */
 int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
+/* Tuning / diagnostics.  "conv_mode": 1 (default) = half-split f16 MFMA convolutions (fp32-class accuracy, 3 MFMAs
+ * per product, csrc/conv_hs.hip); 0 = plain fp32 MFMA convolutions (csrc/conv3x3.hip).  Both meet the 1e-4 bar. */
+int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value);
 /* Bytes of device memory currently held by the context (weights + workspaces). */
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx);
 

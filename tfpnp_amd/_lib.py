@@ -31,6 +31,7 @@ _SIGNATURES = {
     "pnpx_ctx_create": (C.c_int, [C.c_int, C.POINTER(c_void_p)]),
     "pnpx_ctx_destroy": (C.c_int, [c_void_p]),
     "pnpx_ctx_reserve": (C.c_int, [c_void_p, C.c_int, C.c_int, C.c_int]),
+    "pnpx_ctx_set_option": (C.c_int, [c_void_p, C.c_char_p, C.c_int]),
     "pnpx_ctx_bytes": (C.c_size_t, [c_void_p]),
     "pnpx_unet_num_params": (C.c_size_t, []),
     "pnpx_unet_load": (C.c_int, [c_void_p, c_void_p, C.c_size_t]),

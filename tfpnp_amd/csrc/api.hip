@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include "conv3x3.h"
+#include "conv_hs.h"
 
 namespace pnpx {
 
@@ -110,6 +111,16 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W) {
   return ctx_reserve_unet(ctx, B, H, W);
 }
 
+int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
+  LOCK_CTX(ctx);
+  if (key && !std::strcmp(key, "conv_mode") && (value == CONV_F32 || value == CONV_HS)) {
+    ctx->conv_mode = value;
+    return PNPX_OK;
+  }
+  set_error("pnpx_ctx_set_option: unknown option '%s' or bad value %d", key ? key : "(null)", value);
+  return PNPX_ERR_ARG;
+}
+
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
   return ctx ? ctx->weights.bytes + ctx->arena.bytes + ctx->scratch.bytes : 0;
 }
@@ -151,6 +162,25 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
     ctx->conv[i].mt = mt;
     ctx->conv[i].cc = cc;
   }
+  // half-split (f16 hi/lo) packing of the same convolutions for conv_hs.hip
+  size_t hoff[27];
+  float hscale[27];
+  for (int i = 0; i < 27; ++i) {
+    const int mt = conv_hs_mt(L[i].cout);
+    const int cin_pad = (L[i].cin + 15) / 16 * 16;
+    align();
+    hoff[i] = host.size();
+    const size_t n16 = (size_t)L[i].cout * cin_pad * 9 * 2;       // f16 elements (hi + lo)
+    host.resize(host.size() + (n16 + 1) / 2, 0.f);
+    const float* wsrc = params_host;
+    for (int k = 0; k < i; ++k) wsrc += (size_t)L[k].cin * L[k].cout * 9 + L[k].cout;
+    hscale[i] = pack_conv_weights_hs(wsrc, L[i].cout, L[i].cin, mt, reinterpret_cast<uint16_t*>(host.data() + hoff[i]));
+    ctx->conv_hs[i].cin = L[i].cin;
+    ctx->conv_hs[i].cout = L[i].cout;
+    ctx->conv_hs[i].cin_pad = cin_pad;
+    ctx->conv_hs[i].mt = mt;
+    ctx->conv_hs[i].inv_scale = 1.0f / (hscale[i] * HS_ASCALE);
+  }
   align();
   const size_t ow = host.size();
   host.insert(host.end(), src, src + 32);
@@ -174,6 +204,7 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
   for (int i = 0; i < 27; ++i) {
     ctx->conv[i].w = d + woff[i];
     ctx->conv[i].b = d + boff[i];
+    ctx->conv_hs[i].w = reinterpret_cast<char*>(d + hoff[i]);
   }
   ctx->outc_w = d + ow;
   ctx->outc_b = d + ob;

@@ -58,6 +58,14 @@ struct DeviceBuf {
   size_t bytes = 0;
 };
 
+struct ConvLayerHsDev {     // the same conv packed for the half-split f16 kernel (conv_hs.hip)
+  int cin = 0, cout = 0, cin_pad = 0, mt = 0;
+  char* w = nullptr;        // device: [cout/mt][cin_pad/16][9][hi,lo][2][mt][8] f16
+  float inv_scale = 1.f;    // 1 / (weight scale * activation scale)
+};
+
+enum ConvMode { CONV_F32 = 0, CONV_HS = 1 };
+
 }  // namespace pnpx
 
 struct pnpx_ctx {
@@ -66,6 +74,9 @@ struct pnpx_ctx {
   // --- denoiser
   bool has_weights = false;
   pnpx::ConvLayer conv[27];
+  pnpx::ConvLayerHsDev conv_hs[27];
+  int conv_mode = pnpx::CONV_HS;   // which conv kernel family the denoiser runs (pnpx_ctx_set_option)
+  int arena_mode = -1;             // layout the arena was zero-initialised for
   float* outc_w = nullptr;   // [32]
   float* outc_b = nullptr;   // [1]
   pnpx::DeviceBuf weights;   // single allocation holding all of the above

@@ -17,7 +17,9 @@
 //   [9][CC][MT] weight slice are copied global->LDS by LDS-DMA (global_load_lds, no VGPR round trip):
 //   inputs as a dword gather (LDS image is planar [cc][hy][hx], so a lane's 32 pixels are bank-conflict
 //   free for every tap), weights as a linear 16-byte copy of a block pre-packed on the host.
-//   Two LDS stages: chunk c+1 is in flight while chunk c is multiplied; one barrier per chunk.
+//   Two LDS stages: chunk c+1 is in flight while chunk c is multiplied; one barrier per chunk.  The DMA issue
+//   instructions of chunk c+1 are interleaved with the taps of chunk c (PMC: with all copies issued up front
+//   the MFMA pipe idled 18-30 % because co-resident workgroups run in lockstep and issue at the same time).
 // Zero padding comes from the padded activation layout (common.h): no bounds checks on loads.  Tiles that
 // overhang the image read whatever follows in the arena and mask their stores (columns of D are
 // independent, so garbage inputs only reach masked outputs).
@@ -93,23 +95,24 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   const size_t tile_org = (size_t)y0 * a.Wp + x0 + (PADL - 1);
   const float* wbase = a.wpk + (size_t)ct * nch * G::W_ELEMS;
 
-  auto stage = [&](int buf, int chunk) {
+  // One K-chunk's copies are NS DMA "slots" per wave: NI input gathers (4 B/lane) + NWJ weight copies (16 B/lane).
+  // Issuing them costs the wave tens of cycles each, so they are spread over the 9 taps of the PREVIOUS chunk's
+  // multiply (slot s is issued before tap s % 9): the MFMA pipe keeps running underneath.
+  constexpr int NWJ = (G::W_INSTR + 3) / 4;
+  constexpr int NS = G::NI + NWJ;
+  auto chunk_src = [&](int chunk) -> const float* {
     const int c0 = chunk * CC;
     const float* src = (c0 < a.C0) ? a.in0 + ((size_t)b * a.C0 + c0) * HpWp
                                    : a.in1 + ((size_t)b * a.C1 + (c0 - a.C0)) * HpWp;
-    src += tile_org;
-    float* lin = lds + buf * G::STAGE;
-#pragma unroll
-    for (int k = 0; k < G::NI; ++k) {
-      const int instr = wave + 4 * k;
-      if (instr < G::IN_INSTR) glds4(src + ioff[k], lin + instr * 64);
-    }
-    const float* wsrc = wbase + (size_t)chunk * G::W_ELEMS;
-    float* lw = lin + G::IN_PAD;
-#pragma unroll
-    for (int j0 = 0; j0 < G::W_INSTR; j0 += 4) {
-      const int j = j0 + wave;
-      if (j < G::W_INSTR) glds16(wsrc + j * 256 + lane * 4, lw + j * 256);
+    return src + tile_org;
+  };
+  auto issue_slot = [&](int slot, const float* src, const float* wsrc, float* lstage) {
+    if (slot < G::NI) {
+      const int instr = wave + 4 * slot;
+      if (instr < G::IN_INSTR) glds4(src + ioff[slot], lstage + instr * 64);
+    } else {
+      const int j = wave + 4 * (slot - G::NI);
+      if (j < G::W_INSTR) glds16(wsrc + j * 256 + lane * 4, lstage + G::IN_PAD + j * 256);
     }
   };
 
@@ -126,16 +129,27 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   const int b_lane = khalf * G::PLANE + (wave * NBW * G::MBH + py) * G::LW + px;
   const int a_lane = khalf * MT + l31;
 
-  stage(0, 0);
+  {
+    const float* src = chunk_src(0);
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) issue_slot(sl, src, wbase, lds);
+  }
   for (int ch = 0; ch < nch; ++ch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (ch + 1 < nch) stage((ch + 1) & 1, ch + 1);
+    const bool more = ch + 1 < nch;
+    const float* nsrc = more ? chunk_src(ch + 1) : nullptr;
+    const float* nw = wbase + (size_t)(ch + 1) * G::W_ELEMS;
+    float* nstage = lds + ((ch + 1) & 1) * G::STAGE;
     const float* lin = lds + (ch & 1) * G::STAGE + b_lane;
     const float* lw = lds + (ch & 1) * G::STAGE + G::IN_PAD + a_lane;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
+      if (more) {
+#pragma unroll
+        for (int sl = tap; sl < NS; sl += 9) issue_slot(sl, nsrc, nw, nstage);
+      }
 #pragma unroll
       for (int cp = 0; cp < CC / 2; ++cp) {
         float av[G::MTB], bv[NBW];

@@ -9,6 +9,7 @@
 // never materialised (the conv kernel reads two source tensors).
 #include "common.h"
 #include "conv3x3.h"
+#include "conv_hs.h"
 
 namespace pnpx {
 
@@ -86,32 +87,143 @@ __global__ void outc_residual_kernel(const float* __restrict__ feat, const float
   out[o] = fminf(fmaxf(v, 0.f), 1.f);
 }
 
+// ----------------------------------------------------------------------------------------- HS8 kernels
+// Same four ops on the half-split layout of conv_hs.hip: records of 32 B = hi[8] | lo[8] f16 per (group, pixel),
+// values scaled by HS_ASCALE, tensor [B][G][H+2][W+2] records with a zero border.  One thread per record.
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+struct HsRec {
+  h8v hi, lo;
+};
+__device__ __forceinline__ void hs_unpack(const HsRec& r, float v[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)r.hi[e] + (float)r.lo[e];
+}
+__device__ __forceinline__ HsRec hs_pack(const float v[8]) {
+  HsRec r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    r.hi[e] = (_Float16)v[e];
+    r.lo[e] = (_Float16)(v[e] - (float)r.hi[e]);
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void prep_input_hs_kernel(const float* __restrict__ x, const float* __restrict__ sigma,
+                                                            int sigma_stride, HsRec* __restrict__ dst, int H, int W,
+                                                            size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int xx = (int)(i % W);
+  const size_t t = i / W;
+  const int y = (int)(t % H);
+  const size_t b = t / H;
+  float v[8] = {x[i] * HS_ASCALE, sigma[b * sigma_stride] * HS_ASCALE, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  dst[(b * 2 * (H + 2) + (y + 1)) * (W + 2) + xx + 1] = hs_pack(v);   // group 0 of 2; group 1 stays zero
+}
+
+__global__ __launch_bounds__(256) void maxpool2_hs_kernel(const HsRec* __restrict__ src, HsRec* __restrict__ dst,
+                                                          size_t n_out, int H, int W) {
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const int xo = (int)(i % Wo);
+  const size_t t = i / Wo;
+  const int yo = (int)(t % Ho);
+  const size_t bg = t / Ho;
+  const HsRec* s = src + (bg * (H + 2) + (2 * yo + 1)) * (W + 2) + 2 * xo + 1;
+  float a[8], c[8], d[8], e[8], o[8];
+  hs_unpack(s[0], a);
+  hs_unpack(s[1], c);
+  hs_unpack(s[W + 2], d);
+  hs_unpack(s[W + 3], e);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = fmaxf(fmaxf(a[k], c[k]), fmaxf(d[k], e[k]));
+  dst[(bg * (Ho + 2) + (yo + 1)) * (Wo + 2) + xo + 1] = hs_pack(o);
+}
+
+__global__ __launch_bounds__(256) void upsample2x_hs_kernel(const HsRec* __restrict__ src, HsRec* __restrict__ dst,
+                                                            size_t n_out, int h, int w, float sy, float sx) {
+  const int H = 2 * h, W = 2 * w;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const int x = (int)(i % W);
+  const size_t t = i / W;
+  const int y = (int)(t % H);
+  const size_t bg = t / H;
+  const float fy = sy * y, fx = sx * x;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly = fy - y0, lx = fx - x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const HsRec* s = src + bg * (h + 2) * (w + 2) + 1;
+  float v00[8], v01[8], v10[8], v11[8], o[8];
+  hs_unpack(s[(size_t)(y0 + 1) * (w + 2) + x0], v00);
+  hs_unpack(s[(size_t)(y0 + 1) * (w + 2) + x1], v01);
+  hs_unpack(s[(size_t)(y1 + 1) * (w + 2) + x0], v10);
+  hs_unpack(s[(size_t)(y1 + 1) * (w + 2) + x1], v11);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
+  dst[(bg * (H + 2) + (y + 1)) * (W + 2) + x + 1] = hs_pack(o);
+}
+
+__global__ __launch_bounds__(256) void outc_residual_hs_kernel(const HsRec* __restrict__ feat, const float* __restrict__ x,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ out, float* __restrict__ out_pre, int H,
+                                                               int W, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int xx = (int)(i % W);
+  const size_t t = i / W;
+  const int y = (int)(t % H);
+  const size_t b = t / H;
+  const size_t plane = (size_t)(H + 2) * (W + 2);
+  const HsRec* f = feat + b * 4 * plane + (size_t)(y + 1) * (W + 2) + xx + 1;
+  float acc = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v[8];
+    hs_unpack(f[g * plane], v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = fmaf(w[g * 8 + k], v[k], acc);
+  }
+  const float r = x[i] + (acc * (1.f / HS_ASCALE) + bias[0]);
+  if (out_pre) out_pre[i] = r;
+  out[i] = fminf(fmaxf(r, 0.f), 1.f);
+}
+
 // ----------------------------------------------------------------------------------------- arena plan
+struct Act {              // one activation tensor in the arena
+  size_t off = 0;         // byte offset
+  int C = 0, H = 0, W = 0;
+};
 struct UNetPlan {
   // per level l (resolution H>>l, W>>l, channels 32<<l)
-  ActDesc in0;            // 2 ch @ level 0
-  ActDesc a[5], b[5];     // ConvBlock temporaries
-  ActDesc x[5];           // encoder outputs x1..x5 (skips)
-  ActDesc p[5];           // pooled inputs of level l (l >= 1): channels 16<<l
-  ActDesc u[4];           // upsampled decoder inputs at level l (l <= 3): channels 64<<l
-  ActDesc y[4];           // decoder outputs at level l (l <= 3)
-  size_t total = 0;       // floats, for capB images
-  int capB = 0;
+  Act in0;                // network input (2 channels; 16 in HS mode, the upper 14 zero) @ level 0
+  Act a[5], b[5];         // ConvBlock temporaries
+  Act x[5];               // encoder outputs x1..x5 (skips)
+  Act p[5];               // pooled inputs of level l (l >= 1): channels 16<<l
+  Act u[4];               // upsampled decoder inputs at level l (l <= 3): channels 64<<l
+  Act y[4];               // decoder outputs at level l (l <= 3)
+  size_t total = 0;       // bytes, for capB images
 };
 
-static UNetPlan make_plan(int capB, int H, int W) {
+static size_t act_bytes_per_image(int mode, int C, int h, int w) {
+  if (mode == CONV_HS) return (size_t)((C + 7) / 8) * (h + 2) * (w + 2) * 32;
+  return (size_t)C * padded_h(h) * padded_w(w) * sizeof(float);
+}
+
+static UNetPlan make_plan(int mode, int capB, int H, int W) {
   UNetPlan P;
-  P.capB = capB;
   size_t off = 0;
-  auto add = [&](ActDesc& d, int C, int h, int w) {
+  auto add = [&](Act& d, int C, int h, int w) {
     d.off = off;
     d.C = C;
     d.H = h;
     d.W = w;
-    off += d.per_image() * (size_t)capB;
-    off = (off + 63) & ~(size_t)63;
+    off += act_bytes_per_image(mode, C, h, w) * (size_t)capB;
+    off = (off + 255) & ~(size_t)255;
   };
-  add(P.in0, 2, H, W);
+  add(P.in0, mode == CONV_HS ? 16 : 2, H, W);
   for (int l = 0; l < 5; ++l) {
     const int h = H >> l, w = W >> l, c = 32 << l;
     add(P.a[l], c, h, w);
@@ -123,32 +235,38 @@ static UNetPlan make_plan(int capB, int H, int W) {
       add(P.y[l], c, h, w);
     }
   }
-  P.total = off + (1u << 18);  // 1 MiB slack: overhanging tiles read (never write) past their tensor
+  P.total = off + (1u << 20);  // 1 MiB slack: overhanging tiles read (never write) past their tensor
   return P;
 }
 
 int ctx_reserve_unet(pnpx_ctx* ctx, int B, int H, int W) {
-  if (B <= ctx->capB && H == ctx->capH && W == ctx->capW) return PNPX_OK;
-  const int nb = (H == ctx->capH && W == ctx->capW) ? (B > ctx->capB ? B : ctx->capB) : B;
-  UNetPlan P = make_plan(nb, H, W);
+  const int mode = ctx->conv_mode;
+  if (B <= ctx->capB && H == ctx->capH && W == ctx->capW && mode == ctx->arena_mode) return PNPX_OK;
+  const bool same_geom = (H == ctx->capH && W == ctx->capW);
+  const int nb = same_geom ? (B > ctx->capB ? B : ctx->capB) : B;
+  UNetPlan P = make_plan(mode, nb, H, W);
   PNPX_HIP(hipSetDevice(ctx->device));
   PNPX_HIP(hipDeviceSynchronize());
-  if (ctx->arena.p) PNPX_HIP(hipFree(ctx->arena.p));
-  ctx->arena = DeviceBuf();
-  ctx->capB = ctx->capH = ctx->capW = 0;
-  void* p = nullptr;
-  hipError_t e = hipMalloc(&p, P.total * sizeof(float));
-  if (e != hipSuccess) {
-    set_error("arena allocation of %zu bytes failed: %s", P.total * sizeof(float), hipGetErrorString(e));
-    return PNPX_ERR_ALLOC;
+  if (ctx->arena.bytes < P.total) {
+    if (ctx->arena.p) PNPX_HIP(hipFree(ctx->arena.p));
+    ctx->arena = DeviceBuf();
+    ctx->capB = ctx->capH = ctx->capW = 0;
+    ctx->arena_mode = -1;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, P.total);
+    if (e != hipSuccess) {
+      set_error("arena allocation of %zu bytes failed: %s", P.total, hipGetErrorString(e));
+      return PNPX_ERR_ALLOC;
+    }
+    ctx->arena.p = p;
+    ctx->arena.bytes = P.total;
   }
-  PNPX_HIP(hipMemset(p, 0, P.total * sizeof(float)));  // borders stay zero for the arena's lifetime
+  PNPX_HIP(hipMemset(ctx->arena.p, 0, P.total));  // borders stay zero until the layout changes
   PNPX_HIP(hipDeviceSynchronize());
-  ctx->arena.p = p;
-  ctx->arena.bytes = P.total * sizeof(float);
   ctx->capB = nb;
   ctx->capH = H;
   ctx->capW = W;
+  ctx->arena_mode = mode;
   return PNPX_OK;
 }
 
@@ -169,7 +287,7 @@ struct Recorder {
   }
 };
 
-inline dim3 grid2d(int W, int H, size_t Z, int bx) { return dim3((W + bx - 1) / bx, H, (unsigned)Z); }
+inline dim3 g1d(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
 
@@ -184,24 +302,46 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     return PNPX_ERR_SHAPE;
   }
   PNPX_TRY(ctx_reserve_unet(ctx, B, H, W));
-  const UNetPlan P = make_plan(ctx->capB, H, W);
-  float* A = static_cast<float*>(ctx->arena.p);
-  auto ptr = [&](const ActDesc& d) { return A + d.off; };
+  const int mode = ctx->conv_mode;
+  const bool hs = (mode == CONV_HS);
+  const UNetPlan P = make_plan(mode, ctx->capB, H, W);
+  char* A = static_cast<char*>(ctx->arena.p);
+  auto cptr = [&](const Act& d) { return A + d.off; };
+  auto fptr = [&](const Act& d) { return reinterpret_cast<float*>(A + d.off); };
+  auto rptr = [&](const Act& d) { return reinterpret_cast<HsRec*>(A + d.off); };
   Recorder rec{prof, s};
   if (prof) PNPX_HIP(hipEventRecord((*prof->events)[0], s));
 
-  const int bx = 64;
-  hipLaunchKernelGGL(prep_input_kernel, grid2d(W, H, B, bx), dim3(bx), 0, s, x, sigma, sigma_stride, ptr(P.in0), H, W,
-                     padded_h(H), padded_w(W));
+  const size_t npix = (size_t)B * H * W;
+  if (hs) {
+    hipLaunchKernelGGL(prep_input_hs_kernel, g1d(npix), dim3(256), 0, s, x, sigma, sigma_stride, rptr(P.in0), H, W, npix);
+  } else {
+    hipLaunchKernelGGL(prep_input_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, x, sigma, sigma_stride,
+                       fptr(P.in0), H, W, padded_h(H), padded_w(W));
+  }
   PNPX_LAUNCH_CHECK();
   PNPX_TRY(rec.mark("prep_input", 0));
 
-  auto conv = [&](int li, const ActDesc& i0, const ActDesc* i1, const ActDesc& o) -> int {
+  auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o) -> int {
     const ConvLayer& L = ctx->conv[li];
-    PNPX_TRY(launch_conv3x3(L, ptr(i0), i0.C, i1 ? ptr(*i1) : nullptr, i1 ? i1->C : 0, ptr(o), B, o.H, o.W, s));
+    if (hs) {
+      const ConvLayerHsDev& D = ctx->conv_hs[li];
+      ConvLayerHs Lh;
+      Lh.cin = D.cin;
+      Lh.cout = D.cout;
+      Lh.cin_pad = D.cin_pad;
+      Lh.mt = D.mt;
+      Lh.w = D.w;
+      Lh.b = L.b;
+      Lh.inv_scale = D.inv_scale;
+      PNPX_TRY(launch_conv_hs(Lh, cptr(i0), i0.C / 8, i1 ? cptr(*i1) : nullptr, i1 ? i1->C / 8 : 0, cptr(o), B, o.H,
+                              o.W, s));
+    } else {
+      PNPX_TRY(launch_conv3x3(L, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, i1 ? i1->C : 0, fptr(o), B, o.H, o.W, s));
+    }
     return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);
   };
-  auto block = [&](int li, const ActDesc& i0, const ActDesc* i1, int lvl, const ActDesc& o) -> int {
+  auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o) -> int {
     PNPX_TRY(conv(li, i0, i1, P.a[lvl]));
     PNPX_TRY(conv(li + 1, P.a[lvl], nullptr, P.b[lvl]));
     return conv(li + 2, P.b[lvl], nullptr, o);
@@ -210,30 +350,43 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
   // encoder
   PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0]));
   for (int l = 1; l < 5; ++l) {
-    const ActDesc& src = P.x[l - 1];
-    const size_t n_pool = (size_t)B * src.C * (src.H / 2) * (src.W / 2);
-    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((n_pool + 255) / 256)), dim3(256), 0, s, ptr(src),
-                       ptr(P.p[l]), n_pool, src.H, src.W);
+    const Act& src = P.x[l - 1];
+    if (hs) {
+      const size_t n_pool = (size_t)B * (src.C / 8) * (src.H / 2) * (src.W / 2);
+      hipLaunchKernelGGL(maxpool2_hs_kernel, g1d(n_pool), dim3(256), 0, s, rptr(src), rptr(P.p[l]), n_pool, src.H, src.W);
+    } else {
+      const size_t n_pool = (size_t)B * src.C * (src.H / 2) * (src.W / 2);
+      hipLaunchKernelGGL(maxpool2_kernel, g1d(n_pool), dim3(256), 0, s, fptr(src), fptr(P.p[l]), n_pool, src.H, src.W);
+    }
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(rec.mark("maxpool2", 0));
     PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l]));
   }
   // decoder
-  const ActDesc* below = &P.x[4];
+  const Act* below = &P.x[4];
   for (int l = 3; l >= 0; --l) {
     const int h = below->H, w = below->W;
     const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
-    const size_t n_up = (size_t)B * below->C * (2 * h) * (2 * w);
-    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((n_up + 255) / 256)), dim3(256), 0, s, ptr(*below),
-                       ptr(P.u[l]), n_up, h, w, sy, sx);
+    if (hs) {
+      const size_t n_up = (size_t)B * (below->C / 8) * (2 * h) * (2 * w);
+      hipLaunchKernelGGL(upsample2x_hs_kernel, g1d(n_up), dim3(256), 0, s, rptr(*below), rptr(P.u[l]), n_up, h, w, sy, sx);
+    } else {
+      const size_t n_up = (size_t)B * below->C * (2 * h) * (2 * w);
+      hipLaunchKernelGGL(upsample2x_kernel, g1d(n_up), dim3(256), 0, s, fptr(*below), fptr(P.u[l]), n_up, h, w, sy, sx);
+    }
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(rec.mark("upsample2x", 0));
     PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l]));
     below = &P.y[l];
   }
-  hipLaunchKernelGGL(outc_residual_kernel, grid2d(W, H, B, bx), dim3(bx), 0, s, ptr(P.y[0]), x, ctx->outc_w,
-                     ctx->outc_b, out, out_pre, H, W);
+  if (hs) {
+    hipLaunchKernelGGL(outc_residual_hs_kernel, g1d(npix), dim3(256), 0, s, rptr(P.y[0]), x, ctx->outc_w, ctx->outc_b,
+                       out, out_pre, H, W, npix);
+  } else {
+    hipLaunchKernelGGL(outc_residual_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, fptr(P.y[0]), x, ctx->outc_w,
+                       ctx->outc_b, out, out_pre, H, W);
+  }
   PNPX_LAUNCH_CHECK();
   PNPX_TRY(rec.mark("outc_residual_clamp", 2.0 * 32 * (double)H * W * B));
   return PNPX_OK;

@@ -48,6 +48,10 @@ class Context:
         check(_lib.lib().pnpx_unet_load(self.handle, flat.ctypes.data_as(C.c_void_p), flat.size))
         self._has_weights = True
 
+    def set_option(self, key, value):
+        """e.g. set_option('conv_mode', 0) selects the plain-fp32 MFMA convolutions (default 1 = half-split f16)."""
+        check(_lib.lib().pnpx_ctx_set_option(self.handle, key.encode(), int(value)))
+
     def reserve(self, B, H, W):
         check(_lib.lib().pnpx_ctx_reserve(self.handle, B, H, W))
 

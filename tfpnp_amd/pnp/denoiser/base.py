@@ -15,8 +15,10 @@ CURRENT_DIR = os.path.dirname(os.path.abspath(__file__))
 
 
 class UNetDenoiser2D(torch.nn.Module):
-    def __init__(self, ckpt_path=None, state_dict=None):
+    def __init__(self, ckpt_path=None, state_dict=None, conv_mode=None):
+        """conv_mode: None/1 = half-split f16 MFMA convolutions (default), 0 = plain fp32 MFMA convolutions."""
         super().__init__()
+        self.conv_mode = conv_mode
         if state_dict is None:
             if ckpt_path is None:
                 ckpt_path = os.path.join(CURRENT_DIR, 'pretrained', 'unet-nm.pt')
@@ -40,6 +42,8 @@ class UNetDenoiser2D(torch.nn.Module):
         if idx not in self._ctx:
             ctx = ops.Context(torch.device('cuda', idx))
             ctx.load_unet(self._state)
+            if self.conv_mode is not None:
+                ctx.set_option('conv_mode', self.conv_mode)
             self._ctx[idx] = ctx
         return self._ctx[idx]
 

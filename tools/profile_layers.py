@@ -8,7 +8,8 @@ from tfpnp_amd.pnp import UNetDenoiser2D
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = torch.device("cuda:0")
-den = UNetDenoiser2D(state_dict=synth.make_unet_params(0))
+MODE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+den = UNetDenoiser2D(state_dict=synth.make_unet_params(0), conv_mode=MODE)
 x = torch.rand(B, 1, H, H, device=dev)
 s = torch.full((B,), 0.1, device=dev)
 ctx = den.context(dev)
