@@ -23,7 +23,7 @@ struct ConvHsArgs {
   char* out;         // HS8 tensor, nct*MT/8 groups
   int G0, G1;
   int H, W, Hp, Wp;
-  int tilesX, tilesY, nct;
+  int tilesX, tilesY, nct, B;
   float inv_scale, slope;
 };
 

@@ -21,6 +21,8 @@
 // are single conflict-free ds_read_b128 (pixel / cout stride 16 B), tap shifts are immediates.
 // Epilogue: bias + LeakyReLU in fp32, re-split to hi/lo, v_permlane32_swap pairs the two half-waves' 4-channel
 // pieces into whole 8-channel records, one coalesced 32-byte record store per lane and group pair.
+#include <type_traits>
+
 #include "common.h"
 #include "conv_hs.h"
 
@@ -46,18 +48,21 @@ struct HsGeom {
   static constexpr int LH = TH + 2;
   static constexpr int PLANE = LW * LH;                 // pixels per LDS plane
   static constexpr int IN_LOADS = 4 * PLANE;            // 16-byte lane loads per chunk (2 groups x hi/lo)
-  static constexpr int IN_INSTR = (IN_LOADS + 63) / 64;
-  static constexpr int IN_BYTES = IN_INSTR * 64 * 16;
-  static constexpr int NI = (IN_INSTR + 3) / 4;
+  static constexpr int NI = (IN_LOADS + 255) / 256;     // DMA slots per wave (4 waves x 64 lanes x 16 B each)
+  static constexpr int IN_BYTES = NI * 4096;            // padded: every wave issues every slot, no branches
   static constexpr int W_BYTES = 9 * 2 * 2 * MT * 16;   // [tap][hi,lo][kg][MT] x 16 B
-  static constexpr int W_INSTR = W_BYTES / 1024;        // 64 lanes x 16 B; MT multiple of 32 -> exact
-  static constexpr int NWJ = (W_INSTR + 3) / 4;
-  static constexpr int STAGE = IN_BYTES + W_BYTES;
+  static constexpr int NWJ = (W_BYTES + 4095) / 4096;
+  static constexpr int W_PAD = NWJ * 4096;
+  static constexpr int STAGE = IN_BYTES + W_PAD;
   static constexpr int LDS_BYTES = 2 * STAGE;
   static constexpr int MTB = MT / 32;
   static constexpr int NS = NI + NWJ;
 };
 
+// Persistent kernel: a workgroup walks tiles blockIdx.x, +gridDim.x, ... and runs ONE software pipeline over the
+// flattened (tile, K-chunk) steps: the DMA of step s+1 (possibly the next tile's first chunk) is issued while
+// step s is multiplied, so the load latency is exposed once per workgroup, not once per tile, and the epilogue
+// stores of a tile overlap the next tile's first loads.
 template <int MT, int NBW, int MBW>
 __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
   using G = HsGeom<MT, NBW, MBW>;
@@ -66,19 +71,11 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  int t = blockIdx.x;
-  const int ct = t % a.nct;
-  t /= a.nct;
-  const int tx = t % a.tilesX;
-  t /= a.tilesX;
-  const int ty = t % a.tilesY;
-  const int b = t / a.tilesY;
-  const int x0 = tx * G::TW, y0 = ty * G::TH;
   const int HpWp = a.Hp * a.Wp;
   const int nch = (a.G0 + a.G1) / 2;
+  const int ntiles = a.nct * a.tilesX * a.tilesY * a.B;
 
-  // per-thread byte offsets of the halo gather (identical for every chunk)
+  // per-thread byte offsets of the halo gather (identical for every chunk and tile)
   int ioff[G::NI];
 #pragma unroll
   for (int k = 0; k < G::NI; ++k) {
@@ -89,32 +86,50 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
     const int hx = r - hy * G::LW;
     ioff[k] = (idx < G::IN_LOADS) ? (((q >> 1) * HpWp + hy * a.Wp + hx) * 32 + (q & 1) * 16) : 0;
   }
-  const size_t tile_org = ((size_t)y0 * a.Wp + x0) * 32;
-  const char* wbase = a.wpk + (size_t)ct * nch * G::W_BYTES;
 
-  auto chunk_src = [&](int chunk) -> const char* {
+  struct Tile {
+    int ct, b, x0, y0;
+  };
+  auto decode = [&](int t) {
+    Tile T;
+    T.ct = t % a.nct;
+    t /= a.nct;
+    const int tx = t % a.tilesX;
+    t /= a.tilesX;
+    const int ty = t % a.tilesY;
+    T.b = t / a.tilesY;
+    T.x0 = tx * G::TW;
+    T.y0 = ty * G::TH;
+    return T;
+  };
+  auto chunk_src = [&](const Tile& T, int chunk) -> const char* {
     const int g0 = chunk * 2;
-    const char* src = (g0 < a.G0) ? a.in0 + ((size_t)b * a.G0 + g0) * HpWp * 32
-                                  : a.in1 + ((size_t)b * a.G1 + (g0 - a.G0)) * HpWp * 32;
-    return src + tile_org;
+    const char* src = (g0 < a.G0) ? a.in0 + ((size_t)T.b * a.G0 + g0) * HpWp * 32
+                                  : a.in1 + ((size_t)T.b * a.G1 + (g0 - a.G0)) * HpWp * 32;
+    return src + ((size_t)T.y0 * a.Wp + T.x0) * 32;
+  };
+  auto chunk_w = [&](const Tile& T, int chunk) -> const char* {
+    return a.wpk + ((size_t)T.ct * nch + chunk) * G::W_BYTES;
   };
   auto issue_slot = [&](int slot, const char* src, const char* wsrc, char* lstage) {
     if (slot < G::NI) {
-      const int instr = wave + 4 * slot;
-      if (instr < G::IN_INSTR) glds16b(src + ioff[slot], lstage + instr * 1024);
+      glds16b(src + ioff[slot], lstage + (wave + 4 * slot) * 1024);
     } else {
       const int j = wave + 4 * (slot - G::NI);
-      if (j < G::W_INSTR) glds16b(wsrc + j * 1024 + lane * 16, lstage + G::IN_BYTES + j * 1024);
+      glds16b(wsrc + j * 1024 + lane * 16, lstage + G::IN_BYTES + j * 1024);
     }
   };
 
   f32x16 acc[G::MTB][NBW];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int m = 0; m < G::MTB; ++m)
+    for (int m = 0; m < G::MTB; ++m)
 #pragma unroll
-    for (int n = 0; n < NBW; ++n)
+      for (int n = 0; n < NBW; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  };
+  zero_acc();
 
   const int l31 = lane & 31, kg = lane >> 5;
   const int py = l31 / MBW, px = l31 - py * MBW;
@@ -122,103 +137,149 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
   const int b_lane = (kg * 2 * G::PLANE + (wave * NBW * G::MBH + py) * G::LW + px) * 16;
   const int a_lane = G::IN_BYTES + (kg * MT + l31) * 16;
 
-  {
-    const char* src = chunk_src(0);
+  // one K-chunk of multiply; MORE: also issue the next step's DMA slots.  Explicit software pipeline over the
+  // 9 taps: the fragments of tap t+1 are read from LDS before the MFMAs of tap t are issued, and the DMA slots of
+  // this tap sit BEHIND those reads (the compiler keeps ds_reads in order with LDS-DMA, so a DMA at the top of a
+  // tap would pin the next reads right in front of their first use).
+  struct Frags {
+    h8 ah[G::MTB], al[G::MTB], bh[NBW], bl[NBW];
+  };
+  auto load_frags = [&](Frags& f, const char* la, const char* lb, int tap) {
+    const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-    for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, wbase, lds);
-  }
-  for (int ch = 0; ch < nch; ++ch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const bool more = ch + 1 < nch;
-    const char* nsrc = more ? chunk_src(ch + 1) : nullptr;
-    const char* nw = wbase + (size_t)(ch + 1) * G::W_BYTES;
-    char* nstage = lds + ((ch + 1) & 1) * G::STAGE;
-    const char* lb = lds + (ch & 1) * G::STAGE + b_lane;
-    const char* la = lds + (ch & 1) * G::STAGE + a_lane;
+    for (int m = 0; m < G::MTB; ++m) {
+      f.ah[m] = *reinterpret_cast<const h8*>(la + ((tap * 2 + 0) * 2 * MT + m * 32) * 16);
+      f.al[m] = *reinterpret_cast<const h8*>(la + ((tap * 2 + 1) * 2 * MT + m * 32) * 16);
+    }
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+      f.bh[n] = *reinterpret_cast<const h8*>(lb + ((n * G::MBH + dy) * G::LW + dx) * 16);
+      f.bl[n] = *reinterpret_cast<const h8*>(lb + (G::PLANE + (n * G::MBH + dy) * G::LW + dx) * 16);
+    }
+  };
+  auto body = [&](auto more_tag, int stage, const char* nsrc, const char* nw) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    char* nstage = lds + (stage ^ 1) * G::STAGE;
+    const char* lb = lds + stage * G::STAGE + b_lane;
+    const char* la = lds + stage * G::STAGE + a_lane;
+    Frags fr[2];
+    load_frags(fr[0], la, lb, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
-      if (more) {
+      const Frags& f = fr[tap & 1];
+      if (tap + 1 < 9) load_frags(fr[(tap + 1) & 1], la, lb, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads here (the scheduler would sink them to their use)
+#pragma unroll
+      for (int m = 0; m < G::MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bh[n], acc[m][n], 0, 0, 0);
+      if constexpr (MORE) {
 #pragma unroll
         for (int sl = tap; sl < G::NS; sl += 9) issue_slot(sl, nsrc, nw, nstage);
       }
-      h8 ah[G::MTB], al[G::MTB], bh[NBW], bl[NBW];
 #pragma unroll
-      for (int m = 0; m < G::MTB; ++m) {
-        ah[m] = *reinterpret_cast<const h8*>(la + ((tap * 2 + 0) * 2 * MT + m * 32) * 16);
-        al[m] = *reinterpret_cast<const h8*>(la + ((tap * 2 + 1) * 2 * MT + m * 32) * 16);
-      }
+      for (int m = 0; m < G::MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < G::MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[m], f.bh[n], acc[m][n], 0, 0, 0);
+    }
+  };
+
+  const int Gout = a.nct * (MT / 8);
+  auto epilogue = [&](const Tile& T) {
+#pragma unroll
+    for (int m = 0; m < G::MTB; ++m) {
+      float bias[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bias[r] = a.bias[T.ct * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
 #pragma unroll
       for (int n = 0; n < NBW; ++n) {
-        bh[n] = *reinterpret_cast<const h8*>(lb + ((n * G::MBH + dy) * G::LW + dx) * 16);
-        bl[n] = *reinterpret_cast<const h8*>(lb + (G::PLANE + (n * G::MBH + dy) * G::LW + dx) * 16);
+        const int y = T.y0 + (wave * NBW + n) * G::MBH + py;
+        const int x = T.x0 + px;
+        const bool ok = (y < a.H) && (x < a.W);
+        // hi/lo pairs packed two channels per dword: hp[q][0..1] = channels (r&3)=0..3 of 8-channel group q
+        unsigned hp[4][2], lp[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float v0 = acc[m][n][q * 4 + e * 2] * a.inv_scale + bias[q * 4 + e * 2];
+            float v1 = acc[m][n][q * 4 + e * 2 + 1] * a.inv_scale + bias[q * 4 + e * 2 + 1];
+            v0 = (v0 > 0.f ? v0 : v0 * a.slope) * HS_ASCALE;
+            v1 = (v1 > 0.f ? v1 : v1 * a.slope) * HS_ASCALE;
+            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+            const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+            h2 hh = {h0, h1}, ll = {l0, l1};
+            hp[q][e] = __builtin_bit_cast(unsigned, hh);
+            lp[q][e] = __builtin_bit_cast(unsigned, ll);
+          }
+        // pair groups (0,1) and (2,3): after the swaps lanes 0-31 hold all 8 channels of the even group,
+        // lanes 32-63 all 8 channels of the odd group (vdst = even-group register, src = odd-group register).
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          unsigned rec[8];  // hi[0..3] dwords, lo[0..3] dwords of one 32-byte record
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            auto sh = __builtin_amdgcn_permlane32_swap(hp[2 * qp][e], hp[2 * qp + 1][e], false, false);
+            auto sl = __builtin_amdgcn_permlane32_swap(lp[2 * qp][e], lp[2 * qp + 1][e], false, false);
+            rec[e] = sh[0];
+            rec[2 + e] = sh[1];
+            rec[4 + e] = sl[0];
+            rec[6 + e] = sl[1];
+          }
+          if (ok) {
+            const int g = T.ct * (MT / 8) + m * 4 + 2 * qp + kg;
+            uint4* o =
+                reinterpret_cast<uint4*>(a.out + ((((size_t)T.b * Gout + g) * a.Hp + (y + 1)) * a.Wp + (x + 1)) * 32);
+            o[0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+            o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+          }
+        }
       }
-#pragma unroll
-      for (int m = 0; m < G::MTB; ++m)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < G::MTB; ++m)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-      for (int m = 0; m < G::MTB; ++m)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
     }
-  }
+  };
 
-  // ---- epilogue
-  const int Gout = a.nct * (MT / 8);
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  Tile cur = decode(tile);
+  int ch = 0, stage = 0;
+  {
+    const char* src = chunk_src(cur, 0);
+    const char* w = chunk_w(cur, 0);
 #pragma unroll
-  for (int m = 0; m < G::MTB; ++m) {
-    float bias[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bias[r] = a.bias[ct * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
-#pragma unroll
-    for (int n = 0; n < NBW; ++n) {
-      const int y = y0 + (wave * NBW + n) * G::MBH + py;
-      const int x = x0 + px;
-      const bool ok = (y < a.H) && (x < a.W);
-      // hi/lo pairs packed two channels per dword: hp[q][0..1] = channels (r&3)=0..3 of 8-channel group q
-      unsigned hp[4][2], lp[4][2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          float v0 = acc[m][n][q * 4 + e * 2] * a.inv_scale + bias[q * 4 + e * 2];
-          float v1 = acc[m][n][q * 4 + e * 2 + 1] * a.inv_scale + bias[q * 4 + e * 2 + 1];
-          v0 = (v0 > 0.f ? v0 : v0 * a.slope) * HS_ASCALE;
-          v1 = (v1 > 0.f ? v1 : v1 * a.slope) * HS_ASCALE;
-          const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-          const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
-          h2 hh = {h0, h1}, ll = {l0, l1};
-          hp[q][e] = __builtin_bit_cast(unsigned, hh);
-          lp[q][e] = __builtin_bit_cast(unsigned, ll);
-        }
-      // pair groups (0,1) and (2,3): after the swaps lanes 0-31 hold all 8 channels of the even group,
-      // lanes 32-63 all 8 channels of the odd group (vdst = even-group register, src = odd-group register).
-#pragma unroll
-      for (int qp = 0; qp < 2; ++qp) {
-        unsigned rec[8];  // hi[0..3] dwords, lo[0..3] dwords of one 32-byte record
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          auto sh = __builtin_amdgcn_permlane32_swap(hp[2 * qp][e], hp[2 * qp + 1][e], false, false);
-          auto sl = __builtin_amdgcn_permlane32_swap(lp[2 * qp][e], lp[2 * qp + 1][e], false, false);
-          rec[e] = sh[0];
-          rec[2 + e] = sh[1];
-          rec[4 + e] = sl[0];
-          rec[6 + e] = sl[1];
-        }
-        if (ok) {
-          const int g = ct * (MT / 8) + m * 4 + 2 * qp + kg;
-          uint4* o = reinterpret_cast<uint4*>(a.out + ((((size_t)b * Gout + g) * a.Hp + (y + 1)) * a.Wp + (x + 1)) * 32);
-          o[0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-          o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
-        }
-      }
+    for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, w, lds);
+  }
+  while (true) {
+    int ntile = tile, nchk = ch + 1;
+    if (nchk == nch) {
+      nchk = 0;
+      ntile = tile + gridDim.x;
     }
+    const bool has_next = ntile < ntiles;
+    Tile nxt = cur;
+    if (nchk == 0 && has_next) nxt = decode(ntile);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (has_next) {
+      body(std::true_type{}, stage, chunk_src(nxt, nchk), chunk_w(nxt, nchk));
+    } else {
+      body(std::false_type{}, stage, nullptr, nullptr);
+    }
+    if (ch == nch - 1) {
+      epilogue(cur);
+      zero_acc();
+    }
+    if (!has_next) break;
+    tile = ntile;
+    ch = nchk;
+    cur = nxt;
+    stage ^= 1;
   }
 }
 
@@ -234,7 +295,12 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
   ConvHsArgs a = a0;
   a.tilesX = (a.W + G::TW - 1) / G::TW;
   a.tilesY = (a.H + G::TH - 1) / G::TH;
-  const long long grid = (long long)a.nct * a.tilesX * a.tilesY * B;
+  a.B = B;
+  const long long ntiles = (long long)a.nct * a.tilesX * a.tilesY * B;
+  // persistent: one workgroup per CU slot (LDS footprint decides how many fit), each walks ntiles/grid tiles
+  const int per_cu = (G::LDS_BYTES <= 80 * 1024) ? 2 : 1;
+  long long grid = 256LL * per_cu;
+  if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, s, a);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
@@ -288,6 +354,7 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.inv_scale = L.inv_scale;
   a.slope = 0.2f;
   a.tilesX = a.tilesY = 0;
+  a.B = B;
   if (L.mt == 64) return launch_hs_mt<64>(a, B, s);
   if (L.mt == 32) return launch_hs_mt<32>(a, B, s);
   set_error("conv_hs: no kernel for mt=%d", L.mt);
