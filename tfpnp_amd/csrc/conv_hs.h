@@ -21,6 +21,13 @@ struct ConvHsArgs {
   const char* wpk;
   const float* bias;
   char* out;         // HS8 tensor, nct*MT/8 groups
+  char* pool_out;    // optional: fused MaxPool2d(2) of the output, HS8 [B][G][H/2+2][W/2+2] (W >= 32 tiles only)
+  // optional fused tail of the network (last conv only, cout == 32): out = clamp(x + outc(v) + b)
+  const float* outc_w;   // [32] or null
+  const float* outc_b;   // [1]
+  const float* x_in;     // [B,1,H,W] network input (residual)
+  float* out_img;        // [B,1,H,W]
+  float* out_pre;        // [B,1,H,W] or null
   int G0, G1;
   int H, W, Hp, Wp;
   int tilesX, tilesY, nct, B;
@@ -29,7 +36,17 @@ struct ConvHsArgs {
 
 int conv_hs_mt(int cout);
 float pack_conv_weights_hs(const float* w, int cout, int cin, int mt, uint16_t* dst);
+struct ConvHsFuse {       // optional fused epilogue work
+  char* pool_out = nullptr;
+  const float* outc_w = nullptr;
+  const float* outc_b = nullptr;
+  const float* x_in = nullptr;
+  float* out_img = nullptr;
+  float* out_pre = nullptr;
+};
+// true when launch_conv_hs will honour ConvHsFuse::pool_out for this geometry
+bool conv_hs_can_pool(int H, int W);
 int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in1, int G1, char* out, int B, int H,
-                   int W, hipStream_t s);
+                   int W, const ConvHsFuse& fuse, hipStream_t s);
 
 }  // namespace pnpx

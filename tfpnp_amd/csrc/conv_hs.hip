@@ -21,6 +21,7 @@
 // are single conflict-free ds_read_b128 (pixel / cout stride 16 B), tap shifts are immediates.
 // Epilogue: bias + LeakyReLU in fp32, re-split to hi/lo, v_permlane32_swap pairs the two half-waves' 4-channel
 // pieces into whole 8-channel records, one coalesced 32-byte record store per lane and group pair.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -38,7 +39,7 @@ __device__ __forceinline__ void glds16b(const char* src, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
 }
 
-template <int MT, int NBW, int MBW>
+template <int MT, int NBW, int MBW, int NSTAGE = 2>
 struct HsGeom {
   static constexpr int MBH = 32 / MBW;
   static constexpr int NBLK = 4 * NBW;
@@ -48,13 +49,14 @@ struct HsGeom {
   static constexpr int LH = TH + 2;
   static constexpr int PLANE = LW * LH;                 // pixels per LDS plane
   static constexpr int IN_LOADS = 4 * PLANE;            // 16-byte lane loads per chunk (2 groups x hi/lo)
-  static constexpr int NI = (IN_LOADS + 255) / 256;     // DMA slots per wave (4 waves x 64 lanes x 16 B each)
-  static constexpr int IN_BYTES = NI * 4096;            // padded: every wave issues every slot, no branches
-  static constexpr int W_BYTES = 9 * 2 * 2 * MT * 16;   // [tap][hi,lo][kg][MT] x 16 B
-  static constexpr int NWJ = (W_BYTES + 4095) / 4096;
-  static constexpr int W_PAD = NWJ * 4096;
-  static constexpr int STAGE = IN_BYTES + W_PAD;
-  static constexpr int LDS_BYTES = 2 * STAGE;
+  static constexpr int IN_INSTR = (IN_LOADS + 63) / 64; // wave-level DMA instructions (1 KiB each)
+  static constexpr int NI = (IN_INSTR + 3) / 4;         // DMA slots per wave
+  static constexpr int IN_BYTES = IN_INSTR * 1024;
+  static constexpr int W_BYTES = 9 * 2 * 2 * MT * 16;   // [tap][hi,lo][kg][MT] x 16 B (multiple of 1 KiB)
+  static constexpr int W_INSTR = W_BYTES / 1024;
+  static constexpr int NWJ = (W_INSTR + 3) / 4;
+  static constexpr int STAGE = IN_BYTES + W_BYTES;
+  static constexpr int LDS_BYTES = NSTAGE * STAGE;
   static constexpr int MTB = MT / 32;
   static constexpr int NS = NI + NWJ;
 };
@@ -63,9 +65,9 @@ struct HsGeom {
 // flattened (tile, K-chunk) steps: the DMA of step s+1 (possibly the next tile's first chunk) is issued while
 // step s is multiplied, so the load latency is exposed once per workgroup, not once per tile, and the epilogue
 // stores of a tile overlap the next tile's first loads.
-template <int MT, int NBW, int MBW>
-__global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
-  using G = HsGeom<MT, NBW, MBW>;
+template <int MT, int NBW, int MBW, int NSTAGE>
+__global__ __launch_bounds__(256, (NBW == 4 ? 1 : 2)) void conv_hs_kernel(ConvHsArgs a) {
+  using G = HsGeom<MT, NBW, MBW, NSTAGE>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   const int tid = threadIdx.x;
@@ -112,11 +114,14 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
     return a.wpk + ((size_t)T.ct * nch + chunk) * G::W_BYTES;
   };
   auto issue_slot = [&](int slot, const char* src, const char* wsrc, char* lstage) {
+    // the (wave-uniform) guards are compile-time true except on the last slot of each kind
     if (slot < G::NI) {
-      glds16b(src + ioff[slot], lstage + (wave + 4 * slot) * 1024);
+      const int instr = wave + 4 * slot;
+      if (4 * slot + 3 < G::IN_INSTR || instr < G::IN_INSTR) glds16b(src + ioff[slot], lstage + instr * 1024);
     } else {
       const int j = wave + 4 * (slot - G::NI);
-      glds16b(wsrc + j * 1024 + lane * 16, lstage + G::IN_BYTES + j * 1024);
+      if (4 * (slot - G::NI) + 3 < G::W_INSTR || j < G::W_INSTR)
+        glds16b(wsrc + j * 1024 + lane * 16, lstage + G::IN_BYTES + j * 1024);
     }
   };
 
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
   };
   auto body = [&](auto more_tag, int stage, const char* nsrc, const char* nw) {
     constexpr bool MORE = decltype(more_tag)::value;
-    char* nstage = lds + (stage ^ 1) * G::STAGE;
+    char* nstage = lds + (NSTAGE == 2 ? (stage ^ 1) * G::STAGE : 0);
     const char* lb = lds + stage * G::STAGE + b_lane;
     const char* la = lds + stage * G::STAGE + a_lane;
     Frags fr[2];
@@ -192,53 +197,113 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
   };
 
   const int Gout = a.nct * (MT / 8);
+  // pack 16 activated values (rows of one 32x32 accumulator, already scaled by HS_ASCALE) into 32-byte HS8 records:
+  // after the permlane swaps lanes 0-31 hold all 8 channels of the even group of each pair, lanes 32-63 of the odd.
+  auto store_records = [&](const float (&v)[16], char* base, size_t pix_rec, int g_first, size_t group_stride_rec,
+                           bool ok) {
+    unsigned hp[4][2], lp[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float v0 = v[q * 4 + e * 2], v1 = v[q * 4 + e * 2 + 1];
+        const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+        const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+        h2 hh = {h0, h1}, ll = {l0, l1};
+        hp[q][e] = __builtin_bit_cast(unsigned, hh);
+        lp[q][e] = __builtin_bit_cast(unsigned, ll);
+      }
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {
+      unsigned rec[8];  // hi[0..3] dwords, lo[0..3] dwords of one record
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        auto sh = __builtin_amdgcn_permlane32_swap(hp[2 * qp][e], hp[2 * qp + 1][e], false, false);
+        auto sl = __builtin_amdgcn_permlane32_swap(lp[2 * qp][e], lp[2 * qp + 1][e], false, false);
+        rec[e] = sh[0];
+        rec[2 + e] = sh[1];
+        rec[4 + e] = sl[0];
+        rec[6 + e] = sl[1];
+      }
+      if (ok) {
+        uint4* o = reinterpret_cast<uint4*>(base + ((size_t)(g_first + 2 * qp + kg) * group_stride_rec + pix_rec) * 32);
+        o[0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+      }
+    }
+  };
+
   auto epilogue = [&](const Tile& T) {
+    const size_t img_rec = (size_t)T.b * Gout * HpWp;
+    // fused MaxPool2d(2) output (models/unet.py:82-85): [B][Gout][H/2+2][W/2+2] records
+    const int Hpo = a.H / 2 + 2, Wpo = a.W / 2 + 2;
+    const bool do_pool = (MBW == 32) && (NBW >= 2) && (a.pool_out != nullptr);
+    [[maybe_unused]] float odot[NBW];   // fused 1x1 out-conv partial sums (MT == 32 only)
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) odot[n] = 0.f;
 #pragma unroll
     for (int m = 0; m < G::MTB; ++m) {
       float bias[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) bias[r] = a.bias[T.ct * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
+      float v[NBW][16];
 #pragma unroll
-      for (int n = 0; n < NBW; ++n) {
-        const int y = T.y0 + (wave * NBW + n) * G::MBH + py;
-        const int x = T.x0 + px;
-        const bool ok = (y < a.H) && (x < a.W);
-        // hi/lo pairs packed two channels per dword: hp[q][0..1] = channels (r&3)=0..3 of 8-channel group q
-        unsigned hp[4][2], lp[4][2];
+      for (int n = 0; n < NBW; ++n)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 16; ++r) {
+          const float t = acc[m][n][r] * a.inv_scale + bias[r];
+          v[n][r] = (t > 0.f ? t : t * a.slope) * HS_ASCALE;
+        }
+      if constexpr (MT == 32) {
+        if (a.outc_w) {   // out = clamp(x + outc(v) ...): accumulate this lane's 16 channels
+          float w16[16];
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            float v0 = acc[m][n][q * 4 + e * 2] * a.inv_scale + bias[q * 4 + e * 2];
-            float v1 = acc[m][n][q * 4 + e * 2 + 1] * a.inv_scale + bias[q * 4 + e * 2 + 1];
-            v0 = (v0 > 0.f ? v0 : v0 * a.slope) * HS_ASCALE;
-            v1 = (v1 > 0.f ? v1 : v1 * a.slope) * HS_ASCALE;
-            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
-            const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
-            h2 hh = {h0, h1}, ll = {l0, l1};
-            hp[q][e] = __builtin_bit_cast(unsigned, hh);
-            lp[q][e] = __builtin_bit_cast(unsigned, ll);
+          for (int r = 0; r < 16; ++r) w16[r] = a.outc_w[(r & 3) + 8 * (r >> 2) + 4 * kg];
+#pragma unroll
+          for (int n = 0; n < NBW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) odot[n] = fmaf(w16[r], v[n][r], odot[n]);
+        }
+      }
+      if (!(MT == 32 && a.outc_w)) {
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+          const int y = T.y0 + (wave * NBW + n) * G::MBH + py;
+          const int x = T.x0 + px;
+          store_records(v[n], a.out, img_rec + (size_t)(y + 1) * a.Wp + (x + 1), T.ct * (MT / 8) + m * 4, HpWp,
+                        (y < a.H) && (x < a.W));
+        }
+      }
+      if constexpr (MBW == 32 && NBW >= 2) {
+        if (do_pool) {
+#pragma unroll
+          for (int n = 0; n < NBW; n += 2) {
+            float pm[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float t = fmaxf(v[n][r], v[n + 1][r]);              // vertical pair: rows y, y+1
+              pm[r] = fmaxf(t, __shfl_xor(t, 1, 64));                   // horizontal pair: lanes x, x^1
+            }
+            const int y = T.y0 + (wave * NBW + n), x = T.x0 + px;       // y even, both rows inside or both outside
+            const bool ok = (y + 1 < a.H) && (x + 1 < a.W) && ((px & 1) == 0);
+            store_records(pm, a.pool_out, (size_t)T.b * Gout * Hpo * Wpo + (size_t)(y / 2 + 1) * Wpo + (x / 2 + 1),
+                          T.ct * (MT / 8) + m * 4, (size_t)Hpo * Wpo, ok);
           }
-        // pair groups (0,1) and (2,3): after the swaps lanes 0-31 hold all 8 channels of the even group,
-        // lanes 32-63 all 8 channels of the odd group (vdst = even-group register, src = odd-group register).
+        }
+      }
+    }
+    if constexpr (MT == 32) {
+      if (a.outc_w) {   // finish the fused 1x1 conv + residual + clamp (models/unet.py:63-66, denoiser/base.py:32)
 #pragma unroll
-        for (int qp = 0; qp < 2; ++qp) {
-          unsigned rec[8];  // hi[0..3] dwords, lo[0..3] dwords of one 32-byte record
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            auto sh = __builtin_amdgcn_permlane32_swap(hp[2 * qp][e], hp[2 * qp + 1][e], false, false);
-            auto sl = __builtin_amdgcn_permlane32_swap(lp[2 * qp][e], lp[2 * qp + 1][e], false, false);
-            rec[e] = sh[0];
-            rec[2 + e] = sh[1];
-            rec[4 + e] = sl[0];
-            rec[6 + e] = sl[1];
-          }
-          if (ok) {
-            const int g = T.ct * (MT / 8) + m * 4 + 2 * qp + kg;
-            uint4* o =
-                reinterpret_cast<uint4*>(a.out + ((((size_t)T.b * Gout + g) * a.Hp + (y + 1)) * a.Wp + (x + 1)) * 32);
-            o[0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-            o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+        for (int n = 0; n < NBW; ++n) {
+          const float tot = odot[n] + __shfl_xor(odot[n], 32, 64);     // the other 16 channels live in lane ^ 32
+          const int y = T.y0 + (wave * NBW + n) * G::MBH + py;
+          const int x = T.x0 + px;
+          if (kg == 0 && y < a.H && x < a.W) {
+            const size_t o = ((size_t)T.b * a.H + y) * a.W + x;
+            const float r = a.x_in[o] + (tot * (1.f / HS_ASCALE) + a.outc_b[0]);
+            if (a.out_pre) a.out_pre[o] = r;
+            a.out_img[o] = fminf(fmaxf(r, 0.f), 1.f);
           }
         }
       }
@@ -266,10 +331,22 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
     if (nchk == 0 && has_next) nxt = decode(ntile);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (has_next) {
-      body(std::true_type{}, stage, chunk_src(nxt, nchk), chunk_w(nxt, nchk));
+    if (NSTAGE == 2) {
+      if (has_next) {
+        body(std::true_type{}, stage, chunk_src(nxt, nchk), chunk_w(nxt, nchk));
+      } else {
+        body(std::false_type{}, stage, nullptr, nullptr);
+      }
     } else {
-      body(std::false_type{}, stage, nullptr, nullptr);
+      // single LDS stage: several workgroups share a CU and cover each other's load latency
+      body(std::false_type{}, 0, nullptr, nullptr);
+      __syncthreads();
+      if (has_next) {
+        const char* src = chunk_src(nxt, nchk);
+        const char* w = chunk_w(nxt, nchk);
+#pragma unroll
+        for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, w, lds);
+      }
     }
     if (ch == nch - 1) {
       epilogue(cur);
@@ -279,16 +356,16 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
     tile = ntile;
     ch = nchk;
     cur = nxt;
-    stage ^= 1;
+    if (NSTAGE == 2) stage ^= 1;
   }
 }
 
-template <int MT, int NBW, int MBW>
-static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
-  using G = HsGeom<MT, NBW, MBW>;
+template <int MT, int NBW, int MBW, int NSTAGE>
+static int launch_hs_cfg(const ConvHsArgs& a0, int B, int per_cu, hipStream_t s) {
+  using G = HsGeom<MT, NBW, MBW, NSTAGE>;
   static bool attr_set = false;
   if (!attr_set) {
-    PNPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW>),
+    PNPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NSTAGE>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     attr_set = true;
   }
@@ -297,13 +374,33 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
   a.tilesY = (a.H + G::TH - 1) / G::TH;
   a.B = B;
   const long long ntiles = (long long)a.nct * a.tilesX * a.tilesY * B;
-  // persistent: one workgroup per CU slot (LDS footprint decides how many fit), each walks ntiles/grid tiles
-  const int per_cu = (G::LDS_BYTES <= 80 * 1024) ? 2 : 1;
+  // persistent: per_cu workgroups per CU (bounded by the LDS footprint), each walks ntiles/grid tiles
+  int fit = (160 * 1024) / G::LDS_BYTES;
+  if (NBW == 4) fit = 1;   // register budget: 1 wave per SIMD
+  if (fit > 2) fit = 2;    // __launch_bounds__(256, 2)
+  if (per_cu > fit) per_cu = fit;
+  if (per_cu < 1) per_cu = 1;
   long long grid = 256LL * per_cu;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NSTAGE>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, s, a);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
+}
+
+struct HsChoice {
+  int nbw, nstage, per_cu;
+};
+
+template <int MT, int MBW>
+static int launch_hs_mbw(const ConvHsArgs& a, int B, HsChoice c, hipStream_t s) {
+  if (c.nstage == 1) {
+    if (c.nbw == 4) return launch_hs_cfg<MT, 4, MBW, 1>(a, B, c.per_cu, s);
+    if (c.nbw == 2) return launch_hs_cfg<MT, 2, MBW, 1>(a, B, c.per_cu, s);
+    return launch_hs_cfg<MT, 1, MBW, 1>(a, B, c.per_cu, s);
+  }
+  if (c.nbw == 4) return launch_hs_cfg<MT, 4, MBW, 2>(a, B, c.per_cu, s);
+  if (c.nbw == 2) return launch_hs_cfg<MT, 2, MBW, 2>(a, B, c.per_cu, s);
+  return launch_hs_cfg<MT, 1, MBW, 2>(a, B, c.per_cu, s);
 }
 
 template <int MT>
@@ -313,27 +410,38 @@ static int launch_hs_mt(const ConvHsArgs& a, int B, hipStream_t s) {
     const int th = 4 * nbw * (32 / mbw);
     return (long long)a.nct * ((a.W + mbw - 1) / mbw) * ((a.H + th - 1) / th) * B;
   };
-  // one workgroup per CU is resident: want >= ~3 waves of 256 workgroups, else shrink the tile
-  int nbw = 4;
-  if (blocks(4) < 700) nbw = 2;
-  if (nbw == 2 && blocks(2) < 700) nbw = 1;
-  if (mbw == 32) {
-    if (nbw == 4) return launch_hs_cfg<MT, 4, 32>(a, B, s);
-    if (nbw == 2) return launch_hs_cfg<MT, 2, 32>(a, B, s);
-    return launch_hs_cfg<MT, 1, 32>(a, B, s);
+  // want >= ~3 tiles per resident workgroup, else shrink the tile
+  HsChoice c{4, 2, 1};
+  if (blocks(4) < 700) c.nbw = 2;
+  if (c.nbw == 2 && blocks(2) < 700) c.nbw = 1;
+  // Production configurations are double-buffered with >= 100 KB of LDS per workgroup, i.e. exactly one resident
+  // workgroup per CU by construction.  Two co-resident workgroups per CU (single-stage or 80-KiB variants,
+  // reachable through the PNPX_HS_* hook below) were 3-6 % faster on some layers, but the <MT=32, NBW=2> instance
+  // then produced rare stale 1-KiB operand pieces (a handful of tiles per launch; root cause not identified --
+  // see DESIGN.md "open issues"), so co-residency is not used.
+  if (MT == 32) c = HsChoice{4, 2, 1};
+  // experiment hook: PNPX_HS_<MT>_<W>="nbw,nstage,per_cu"
+  char key[64];
+  snprintf(key, sizeof(key), "PNPX_HS_%d_%d", MT, a.W);
+  if (const char* e = getenv(key)) {
+    int x, y, z;
+    if (sscanf(e, "%d,%d,%d", &x, &y, &z) == 3) c = HsChoice{x, y, z};
   }
-  if (mbw == 16) {
-    if (nbw == 4) return launch_hs_cfg<MT, 4, 16>(a, B, s);
-    if (nbw == 2) return launch_hs_cfg<MT, 2, 16>(a, B, s);
-    return launch_hs_cfg<MT, 1, 16>(a, B, s);
+  snprintf(key, sizeof(key), "PNPX_HS_%d_%d_G%d", MT, a.W, a.G0 + a.G1);
+  if (const char* e = getenv(key)) {
+    int x, y, z;
+    if (sscanf(e, "%d,%d,%d", &x, &y, &z) == 3) c = HsChoice{x, y, z};
   }
-  if (nbw == 4) return launch_hs_cfg<MT, 4, 8>(a, B, s);
-  if (nbw == 2) return launch_hs_cfg<MT, 2, 8>(a, B, s);
-  return launch_hs_cfg<MT, 1, 8>(a, B, s);
+  if (a.pool_out && c.nbw < 2) c.nbw = 2;   // the fused 2x2 pool pairs two rows held by one wave
+  if (mbw == 32) return launch_hs_mbw<MT, 32>(a, B, c, s);
+  if (mbw == 16) return launch_hs_mbw<MT, 16>(a, B, c, s);
+  return launch_hs_mbw<MT, 8>(a, B, c, s);
 }
 
+bool conv_hs_can_pool(int H, int W) { return W >= 32 && (W % 2) == 0 && (H % 2) == 0; }
+
 int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in1, int G1, char* out, int B, int H,
-                   int W, hipStream_t s) {
+                   int W, const ConvHsFuse& fuse, hipStream_t s) {
   if ((G0 + G1) * 8 != L.cin_pad || (G0 & 1) || (G1 & 1)) {
     set_error("conv_hs: channel groups %d+%d incompatible with packed layer (cin_pad %d)", G0, G1, L.cin_pad);
     return PNPX_ERR_SHAPE;
@@ -346,6 +454,16 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.wpk = L.w;
   a.bias = L.b;
   a.out = out;
+  a.pool_out = conv_hs_can_pool(H, W) ? fuse.pool_out : nullptr;
+  a.outc_w = (L.mt == 32 && L.cout == 32) ? fuse.outc_w : nullptr;
+  a.outc_b = fuse.outc_b;
+  a.x_in = fuse.x_in;
+  a.out_img = fuse.out_img;
+  a.out_pre = fuse.out_pre;
+  if (fuse.outc_w && !a.outc_w) {
+    set_error("conv_hs: fused out-conv needs a 32-channel layer");
+    return PNPX_ERR_SHAPE;
+  }
   a.H = H;
   a.W = W;
   a.Hp = H + 2;

@@ -7,6 +7,8 @@
 //   out = clamp(in[:, :1] + Conv1x1(y), 0, 1).
 // Activations live in the context's arena in the padded planar layout of common.h.  The channel concat is
 // never materialised (the conv kernel reads two source tensors).
+#include <cstdlib>
+
 #include "common.h"
 #include "conv3x3.h"
 #include "conv_hs.h"
@@ -322,7 +324,7 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
   PNPX_LAUNCH_CHECK();
   PNPX_TRY(rec.mark("prep_input", 0));
 
-  auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o) -> int {
+  auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o, const ConvHsFuse& fuse = ConvHsFuse()) -> int {
     const ConvLayer& L = ctx->conv[li];
     if (hs) {
       const ConvLayerHsDev& D = ctx->conv_hs[li];
@@ -335,22 +337,36 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
       Lh.b = L.b;
       Lh.inv_scale = D.inv_scale;
       PNPX_TRY(launch_conv_hs(Lh, cptr(i0), i0.C / 8, i1 ? cptr(*i1) : nullptr, i1 ? i1->C / 8 : 0, cptr(o), B, o.H,
-                              o.W, s));
+                              o.W, fuse, s));
     } else {
       PNPX_TRY(launch_conv3x3(L, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, i1 ? i1->C : 0, fptr(o), B, o.H, o.W, s));
     }
     return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);
   };
-  auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o) -> int {
+  auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o,
+                   const ConvHsFuse& fuse = ConvHsFuse()) -> int {
     PNPX_TRY(conv(li, i0, i1, P.a[lvl]));
     PNPX_TRY(conv(li + 1, P.a[lvl], nullptr, P.b[lvl]));
-    return conv(li + 2, P.b[lvl], nullptr, o);
+    return conv(li + 2, P.b[lvl], nullptr, o, fuse);
   };
 
-  // encoder
-  PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0]));
+  // encoder.  HS mode: the last conv of each encoder block also writes its 2x2 max-pooled output (fused epilogue)
+  // whenever the level is wide enough for the 32-pixel tiles; otherwise a separate pool kernel runs.
+  const bool no_pool_fuse = getenv("PNPX_NO_POOL_FUSE") != nullptr, no_outc_fuse = getenv("PNPX_NO_OUTC_FUSE") != nullptr;
+  auto pool_fused = [&](int l) { return hs && !no_pool_fuse && l < 4 && conv_hs_can_pool(P.x[l].H, P.x[l].W); };
+  {
+    ConvHsFuse f;
+    if (pool_fused(0)) f.pool_out = cptr(P.p[1]);
+    PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0], f));
+  }
   for (int l = 1; l < 5; ++l) {
     const Act& src = P.x[l - 1];
+    if (pool_fused(l - 1)) {
+      ConvHsFuse f;
+      if (pool_fused(l)) f.pool_out = cptr(P.p[l + 1]);
+      PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l], f));
+      continue;
+    }
     if (hs) {
       const size_t n_pool = (size_t)B * (src.C / 8) * (src.H / 2) * (src.W / 2);
       hipLaunchKernelGGL(maxpool2_hs_kernel, g1d(n_pool), dim3(256), 0, s, rptr(src), rptr(P.p[l]), n_pool, src.H, src.W);
@@ -360,7 +376,11 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     }
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(rec.mark("maxpool2", 0));
-    PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l]));
+    {
+      ConvHsFuse f;
+      if (pool_fused(l)) f.pool_out = cptr(P.p[l + 1]);
+      PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l], f));
+    }
   }
   // decoder
   const Act* below = &P.x[4];
@@ -377,9 +397,20 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     }
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(rec.mark("upsample2x", 0));
-    PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l]));
+    {
+      ConvHsFuse f;
+      if (hs && l == 0 && !no_outc_fuse) {   // the network tail (1x1 conv + residual + clamp) rides on the last conv's epilogue
+        f.outc_w = ctx->outc_w;
+        f.outc_b = ctx->outc_b;
+        f.x_in = x;
+        f.out_img = out;
+        f.out_pre = out_pre;
+      }
+      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l], f));
+    }
     below = &P.y[l];
   }
+  if (hs && !no_outc_fuse) return PNPX_OK;
   if (hs) {
     hipLaunchKernelGGL(outc_residual_hs_kernel, g1d(npix), dim3(256), 0, s, rptr(P.y[0]), x, ctx->outc_w, ctx->outc_b,
                        out, out_pre, H, W, npix);
