@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, (NBW == 4 ? 1 : 2)) void conv_hs_kernel(ConvHs
     for (int tap = 0; tap < 9; ++tap) {
       const Frags& f = fr[tap & 1];
       if (tap + 1 < 9) load_frags(fr[(tap + 1) & 1], la, lb, tap + 1);
-      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads here (the scheduler would sink them to their use)
+      if constexpr (NBW == 1) __builtin_amdgcn_sched_barrier(0);   // small tiles: keep the prefetch reads up front
 #pragma unroll
       for (int m = 0; m < G::MTB; ++m)
 #pragma unroll
@@ -193,6 +193,21 @@ __global__ __launch_bounds__(256, (NBW == 4 ? 1 : 2)) void conv_hs_kernel(ConvHs
 #pragma unroll
         for (int n = 0; n < NBW; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[m], f.bh[n], acc[m][n], 0, 0, 0);
+      // schedule of this tap: the next tap's fragment reads are drip-fed between this tap's MFMAs (one ds_read per
+      // MFMA) instead of being issued as one burst that lets the matrix pipe run dry
+      if constexpr (NBW >= 2) {
+        constexpr int NRD = 2 * G::MTB + 2 * NBW;   // ds_read_b128 per tap
+        constexpr int NMF = 3 * G::MTB * NBW;
+        if (tap + 1 < 9) {
+#pragma unroll
+          for (int i = 0; i < NRD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+          }
+          if (MORE) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);   // this tap's DMA slots (VMEM read)
+          __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+        }
+      }
     }
   };
 
