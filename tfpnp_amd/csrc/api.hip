@@ -234,7 +234,7 @@ int pnpx_unet_profile(pnpx_ctx* ctx, const float* x, const float* sigma, float* 
   hipStream_t s = static_cast<hipStream_t>(stream);
   // make sure the arena exists before timing (growth synchronises)
   PNPX_TRY(unet_denoise(ctx, x, sigma, 1, out, nullptr, B, H, W, s, nullptr));
-  while (ctx->events.size() < 64) {
+  while (ctx->events.size() < 1024) {
     hipEvent_t e;
     PNPX_HIP(hipEventCreate(&e));
     ctx->events.push_back(e);

@@ -293,6 +293,110 @@ inline dim3 g1d(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
 
+// Half-split forward pass.  Levels 0 and 1 (the memory-bound, shallow-K layers) can be processed in sub-batches so
+// that a ConvBlock's temporaries are re-read soon after they were written (PNPX_SUBBATCH images at level 0, twice
+// that at level 1; 0 = whole batch).  Measured (tools/time_denoiser.py, B=48, 256^2): 6.58 ms whole batch, 6.38 ms
+// at 24, worse below 12 (launch count, thinner grids) -- the Infinity Cache does not turn these layers around, the
+// gain is small; 24 is the default.  Deeper levels always run the whole batch.
+static int unet_forward_hs(pnpx_ctx* ctx, const UNetPlan& P, const float* x, const float* sigma, int sigma_stride,
+                           float* out, float* out_pre, int B, int H, int W, hipStream_t s, Recorder& rec) {
+  char* A = static_cast<char*>(ctx->arena.p);
+  auto bpi = [&](const Act& d) { return act_bytes_per_image(CONV_HS, d.C, d.H, d.W); };
+  auto at = [&](const Act& d, int b0) { return A + d.off + (size_t)b0 * bpi(d); };
+  auto rat = [&](const Act& d, int b0) { return reinterpret_cast<HsRec*>(at(d, b0)); };
+  const bool no_pool_fuse = getenv("PNPX_NO_POOL_FUSE") != nullptr, no_outc_fuse = getenv("PNPX_NO_OUTC_FUSE") != nullptr;
+  int sub_default = 24;
+  if (const char* e = getenv("PNPX_SUBBATCH")) sub_default = atoi(e);
+  auto sub_of = [&](int level) {   // images per sub-batch at this level
+    if (sub_default <= 0 || level > 1) return B;
+    // level-1 tensors are 2x smaller per image: twice the images per sub-batch
+    const int sb = sub_default * (level == 1 ? 2 : 1) * (256 * 256) / ((H * W) > 0 ? (H * W) : 1);
+    return sb < 1 ? 1 : (sb > B ? B : sb);
+  };
+  auto pool_fused = [&](int l) { return !no_pool_fuse && l < 4 && conv_hs_can_pool(P.x[l].H, P.x[l].W); };
+
+  const size_t npix = (size_t)B * H * W;
+  hipLaunchKernelGGL(prep_input_hs_kernel, g1d(npix), dim3(256), 0, s, x, sigma, sigma_stride, rat(P.in0, 0), H, W, npix);
+  PNPX_LAUNCH_CHECK();
+  PNPX_TRY(rec.mark("prep_input", 0));
+
+  auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o, int b0, int nb, const ConvHsFuse& fuse) -> int {
+    const ConvLayer& L = ctx->conv[li];
+    const ConvLayerHsDev& D = ctx->conv_hs[li];
+    ConvLayerHs Lh;
+    Lh.cin = D.cin;
+    Lh.cout = D.cout;
+    Lh.cin_pad = D.cin_pad;
+    Lh.mt = D.mt;
+    Lh.w = D.w;
+    Lh.b = L.b;
+    Lh.inv_scale = D.inv_scale;
+    PNPX_TRY(launch_conv_hs(Lh, at(i0, b0), i0.C / 8, i1 ? at(*i1, b0) : nullptr, i1 ? i1->C / 8 : 0, at(o, b0), nb, o.H,
+                            o.W, fuse, s));
+    return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * nb);
+  };
+  auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o, int b0, int nb,
+                   const ConvHsFuse& fuse) -> int {
+    PNPX_TRY(conv(li, i0, i1, P.a[lvl], b0, nb, ConvHsFuse()));
+    PNPX_TRY(conv(li + 1, P.a[lvl], nullptr, P.b[lvl], b0, nb, ConvHsFuse()));
+    return conv(li + 2, P.b[lvl], nullptr, o, b0, nb, fuse);
+  };
+
+  // encoder: the last conv of a block also writes the 2x2 max-pooled tensor (fused epilogue) when the level is wide
+  // enough for 32-pixel tiles; otherwise a separate pool kernel runs.
+  for (int l = 0; l < 5; ++l) {
+    const Act& in = (l == 0) ? P.in0 : P.p[l];
+    const int sb = sub_of(l);
+    for (int b0 = 0; b0 < B; b0 += sb) {
+      const int nb = (B - b0 < sb) ? (B - b0) : sb;
+      if (l > 0 && !pool_fused(l - 1)) {
+        const Act& src = P.x[l - 1];
+        const size_t n_pool = (size_t)nb * (src.C / 8) * (src.H / 2) * (src.W / 2);
+        hipLaunchKernelGGL(maxpool2_hs_kernel, g1d(n_pool), dim3(256), 0, s, rat(src, b0), rat(P.p[l], b0), n_pool, src.H,
+                           src.W);
+        PNPX_LAUNCH_CHECK();
+        PNPX_TRY(rec.mark("maxpool2", 0));
+      }
+      ConvHsFuse f;
+      if (pool_fused(l)) f.pool_out = at(P.p[l + 1], b0);
+      PNPX_TRY(block(3 * l, in, nullptr, l, P.x[l], b0, nb, f));
+    }
+  }
+  // decoder
+  const Act* below = &P.x[4];
+  for (int l = 3; l >= 0; --l) {
+    const int h = below->H, w = below->W;
+    const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+    const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+    const int sb = sub_of(l);
+    for (int b0 = 0; b0 < B; b0 += sb) {
+      const int nb = (B - b0 < sb) ? (B - b0) : sb;
+      const size_t n_up = (size_t)nb * (below->C / 8) * (2 * h) * (2 * w);
+      hipLaunchKernelGGL(upsample2x_hs_kernel, g1d(n_up), dim3(256), 0, s, rat(*below, b0), rat(P.u[l], b0), n_up, h, w, sy,
+                         sx);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(rec.mark("upsample2x", 0));
+      ConvHsFuse f;
+      if (l == 0 && !no_outc_fuse) {   // the network tail (1x1 conv + residual + clamp) rides on the last conv's epilogue
+        f.outc_w = ctx->outc_w;
+        f.outc_b = ctx->outc_b;
+        f.x_in = x + (size_t)b0 * H * W;
+        f.out_img = out + (size_t)b0 * H * W;
+        f.out_pre = out_pre ? out_pre + (size_t)b0 * H * W : nullptr;
+      }
+      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l], b0, nb, f));
+    }
+    below = &P.y[l];
+  }
+  if (no_outc_fuse) {
+    hipLaunchKernelGGL(outc_residual_hs_kernel, g1d(npix), dim3(256), 0, s, rat(P.y[0], 0), x, ctx->outc_w, ctx->outc_b,
+                       out, out_pre, H, W, npix);
+    PNPX_LAUNCH_CHECK();
+    PNPX_TRY(rec.mark("outc_residual_clamp", 2.0 * 32 * (double)H * W * B));
+  }
+  return PNPX_OK;
+}
+
 int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
                  int B, int H, int W, hipStream_t s, ProfileSink* prof) {
   if (!ctx->has_weights) {
@@ -313,6 +417,7 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
   auto rptr = [&](const Act& d) { return reinterpret_cast<HsRec*>(A + d.off); };
   Recorder rec{prof, s};
   if (prof) PNPX_HIP(hipEventRecord((*prof->events)[0], s));
+  if (hs) return unet_forward_hs(ctx, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec);
 
   const size_t npix = (size_t)B * H * W;
   if (hs) {

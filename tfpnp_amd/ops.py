@@ -154,7 +154,7 @@ def unet_profile(ctx, x, sigma):
     sigma = _f32(sigma, "sigma").reshape(-1)
     B, _, H, W = x.shape
     out = torch.empty_like(x)
-    cap = 64
+    cap = 1000
     ms = (C.c_float * cap)()
     fl = (C.c_double * cap)()
     names = (C.c_char_p * cap)()
