@@ -170,12 +170,40 @@ def roofline(den, dev, B, H, W, reps=3):
         "frac": achieved / PEAK_HS_TFLOPS,
         "peak_note": "dense f16 MFMA peak 2500 TF/s / 3 MFMAs per product; the exact-fp32 MFMA peak is 157.3 TF/s",
         "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
-        "traffic": None,
+        "traffic": pmc_traffic(B, H, W),
         "flops_per_forward": conv_fl / reps,
         "conv_ms_per_forward": conv_ms / reps,
         "denoiser_ms_per_forward": tot_ms / reps,
         "ms_by_kernel": {k: v / reps for k, v in per.items()},
     }
+
+
+def pmc_traffic(B, H, W):
+    """HBM bytes of the conv launches of one denoiser forward, from the committed rocprofv3 PMC passes
+    (profiles/r1_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, per MI355X_MICROARCH.md).  Same aggregation as
+    `achieved` (all conv launches of one forward).  None when no PMC pass exists for this geometry."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+    except OSError:
+        return None
+    if (t.get("B"), t.get("H"), t.get("W")) != (B, H, W):
+        return None
+    return {"bytes_per_forward": t["hbm_bytes_per_forward"], "bytes_per_conv_launch": t["hbm_bytes_per_conv_launch"],
+            "algorithmic_bytes_per_forward": conv_algorithmic_bytes(B, H, W), "source": t["source"]}
+
+
+def conv_algorithmic_bytes(B, H, W):
+    """Input + output activation bytes of the 27 convolutions (4 B per value: f16 hi + f16 lo), weights excluded."""
+    blocks = [(2, 32, 0), (32, 64, 1), (64, 128, 2), (128, 256, 3), (256, 512, 4), (768, 256, 3), (384, 128, 2),
+              (192, 64, 1), (96, 32, 0)]
+    tot = 0
+    for cin, cout, lvl in blocks:
+        px = (H >> lvl) * (W >> lvl) * B
+        for j in range(3):
+            ci = cin if j == 0 else cout
+            tot += 4 * px * (max(ci, 16) + cout)
+    return tot
 
 
 def cpu_baseline(params, solver, dev, args, gpu_value):

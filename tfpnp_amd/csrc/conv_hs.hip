@@ -61,7 +61,7 @@ struct HsGeom {
   static constexpr int NS = NI + NWJ;
 };
 
-// Persistent kernel: a workgroup walks tiles blockIdx.x, +gridDim.x, ... and runs ONE software pipeline over the
+// Persistent kernel: a workgroup walks its tiles (XCD-aware order, below) and runs ONE software pipeline over the
 // flattened (tile, K-chunk) steps: the DMA of step s+1 (possibly the next tile's first chunk) is issued while
 // step s is multiplied, so the load latency is exposed once per workgroup, not once per tile, and the epilogue
 // stores of a tile overlap the next tile's first loads.
@@ -75,7 +75,14 @@ __global__ __launch_bounds__(256, (NBW == 4 ? 1 : 2)) void conv_hs_kernel(ConvHs
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int HpWp = a.Hp * a.Wp;
   const int nch = (a.G0 + a.G1) / 2;
-  const int ntiles = a.nct * a.tilesX * a.tilesY * a.B;
+  // XCD-aware tile walk.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own
+  // L2.  The nct cout-tiles of one pixel region read the same input halo, so they are given to workgroups of the
+  // SAME XCD that run at the same time (consecutive "slots"): step k of workgroup (xcd, slot) handles
+  //   j = slot + nslot*k,  pixel region p = 8*(j / nct) + xcd,  cout tile ct = j % nct.
+  // nct divides nslot, so a workgroup keeps one cout tile (its weight slice stays hot) for its whole life.
+  const int nregions = a.tilesX * a.tilesY * a.B;
+  const int nx = (gridDim.x % 8 == 0) ? 8 : 1;
+  const int xcd = blockIdx.x % nx, nslot = gridDim.x / nx;
 
   // per-thread byte offsets of the halo gather (identical for every chunk and tile)
   int ioff[G::NI];
@@ -92,10 +99,11 @@ __global__ __launch_bounds__(256, (NBW == 4 ? 1 : 2)) void conv_hs_kernel(ConvHs
   struct Tile {
     int ct, b, x0, y0;
   };
-  auto decode = [&](int t) {
+  auto valid = [&](int j) { return nx * (j / a.nct) + xcd < nregions; };
+  auto decode = [&](int j) {
     Tile T;
-    T.ct = t % a.nct;
-    t /= a.nct;
+    T.ct = j % a.nct;
+    int t = nx * (j / a.nct) + xcd;
     const int tx = t % a.tilesX;
     t /= a.tilesX;
     const int ty = t % a.tilesY;
@@ -325,8 +333,8 @@ __global__ __launch_bounds__(256, (NBW == 4 ? 1 : 2)) void conv_hs_kernel(ConvHs
     }
   };
 
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
+  int tile = blockIdx.x / nx;   // j of this workgroup's first step
+  if (!valid(tile)) return;
   Tile cur = decode(tile);
   int ch = 0, stage = 0;
   {
@@ -339,9 +347,9 @@ __global__ __launch_bounds__(256, (NBW == 4 ? 1 : 2)) void conv_hs_kernel(ConvHs
     int ntile = tile, nchk = ch + 1;
     if (nchk == nch) {
       nchk = 0;
-      ntile = tile + gridDim.x;
+      ntile = tile + nslot;
     }
-    const bool has_next = ntile < ntiles;
+    const bool has_next = valid(ntile);
     Tile nxt = cur;
     if (nchk == 0 && has_next) nxt = decode(ntile);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -397,6 +405,8 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, int per_cu, hipStream_t s)
   if (per_cu < 1) per_cu = 1;
   long long grid = 256LL * per_cu;
   if (grid > ntiles) grid = ntiles;
+  if (grid >= 8) grid -= grid % 8;          // whole XCD groups (the kernel falls back to a plain walk otherwise)
+  if (a.nct > 1 && (grid / 8) % a.nct != 0 && grid >= 8 * a.nct) grid -= grid % (8 * a.nct);
   hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NSTAGE>), dim3((unsigned)grid), dim3(256), G::LDS_BYTES, s, a);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
