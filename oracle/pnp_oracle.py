@@ -160,13 +160,16 @@ def unet_forward(x, params):
 def denoise(x, sigma, params):
     """UNetDenoiser2D.forward.  tfpnp/pnp/denoiser/base.py:23-32"""
     N, C, H, W = x.shape
-    noise_map = torch.ones(N, 1, H, W) * sigma.view(N, 1, 1, 1)
+    noise_map = torch.ones(N, 1, H, W, dtype=x.dtype) * sigma.view(N, 1, 1, 1)
     return torch.clamp(unet_forward(torch.cat([x, noise_map], dim=1), params), 0, 1)
 
 
 class Denoiser:
-    def __init__(self, params):
+    def __init__(self, params, dtype=None):
+        """dtype=torch.float64 gives the double-precision yardstick used by the drift tests."""
         self.params = _to_t(params)
+        if dtype is not None:
+            self.params = {k: v.to(dtype) for k, v in self.params.items()}
 
     def __call__(self, x, sigma):
         return denoise(x, sigma, self.params)
