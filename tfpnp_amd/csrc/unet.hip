@@ -305,6 +305,11 @@ static int unet_forward_hs(pnpx_ctx* ctx, const UNetPlan& P, const float* x, con
   auto at = [&](const Act& d, int b0) { return A + d.off + (size_t)b0 * bpi(d); };
   auto rat = [&](const Act& d, int b0) { return reinterpret_cast<HsRec*>(at(d, b0)); };
   const bool no_pool_fuse = getenv("PNPX_NO_POOL_FUSE") != nullptr, no_outc_fuse = getenv("PNPX_NO_OUTC_FUSE") != nullptr;
+  // Fused bilinear upsample inside the conv loader (ConvHsFuse::up_in1) is implemented and parity-tested but OFF by
+  // default: the interpolation costs ~190 VALU ops per 32-byte record in the MFMA waves and, measured at B=48/256^2,
+  // conv0 of the decoder blocks got 0.14/0.07/0.00 ms slower at levels 3/2/1 and only 0.06 ms faster at level 0 than
+  // "separate upsample kernel + DMA loader" (6.48 vs 6.31 ms per forward).  PNPX_UP_FUSE=1 enables it.
+  const bool no_up_fuse = getenv("PNPX_UP_FUSE") == nullptr;
   int sub_default = 24;
   if (const char* e = getenv("PNPX_SUBBATCH")) sub_default = atoi(e);
   auto sub_of = [&](int level) {   // images per sub-batch at this level
@@ -337,9 +342,13 @@ static int unet_forward_hs(pnpx_ctx* ctx, const UNetPlan& P, const float* x, con
   };
   auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o, int b0, int nb,
                    const ConvHsFuse& fuse) -> int {
-    PNPX_TRY(conv(li, i0, i1, P.a[lvl], b0, nb, ConvHsFuse()));
+    ConvHsFuse f0;
+    f0.up_in1 = fuse.up_in1;
+    PNPX_TRY(conv(li, i0, i1, P.a[lvl], b0, nb, f0));
     PNPX_TRY(conv(li + 1, P.a[lvl], nullptr, P.b[lvl], b0, nb, ConvHsFuse()));
-    return conv(li + 2, P.b[lvl], nullptr, o, b0, nb, fuse);
+    ConvHsFuse f2 = fuse;
+    f2.up_in1 = false;
+    return conv(li + 2, P.b[lvl], nullptr, o, b0, nb, f2);
   };
 
   // encoder: the last conv of a block also writes the 2x2 max-pooled tensor (fused epilogue) when the level is wide
@@ -371,12 +380,15 @@ static int unet_forward_hs(pnpx_ctx* ctx, const UNetPlan& P, const float* x, con
     const int sb = sub_of(l);
     for (int b0 = 0; b0 < B; b0 += sb) {
       const int nb = (B - b0 < sb) ? (B - b0) : sb;
-      const size_t n_up = (size_t)nb * (below->C / 8) * (2 * h) * (2 * w);
-      hipLaunchKernelGGL(upsample2x_hs_kernel, g1d(n_up), dim3(256), 0, s, rat(*below, b0), rat(P.u[l], b0), n_up, h, w, sy,
-                         sx);
-      PNPX_LAUNCH_CHECK();
-      PNPX_TRY(rec.mark("upsample2x", 0));
       ConvHsFuse f;
+      f.up_in1 = !no_up_fuse;
+      if (no_up_fuse) {
+        const size_t n_up = (size_t)nb * (below->C / 8) * (2 * h) * (2 * w);
+        hipLaunchKernelGGL(upsample2x_hs_kernel, g1d(n_up), dim3(256), 0, s, rat(*below, b0), rat(P.u[l], b0), n_up, h, w,
+                           sy, sx);
+        PNPX_LAUNCH_CHECK();
+        PNPX_TRY(rec.mark("upsample2x", 0));
+      }
       if (l == 0 && !no_outc_fuse) {   // the network tail (1x1 conv + residual + clamp) rides on the last conv's epilogue
         f.outc_w = ctx->outc_w;
         f.outc_b = ctx->outc_b;
@@ -384,7 +396,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, const UNetPlan& P, const float* x, con
         f.out_img = out + (size_t)b0 * H * W;
         f.out_pre = out_pre ? out_pre + (size_t)b0 * H * W : nullptr;
       }
-      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l], b0, nb, f));
+      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], no_up_fuse ? &P.u[l] : below, l, P.y[l], b0, nb, f));
     }
     below = &P.y[l];
   }
