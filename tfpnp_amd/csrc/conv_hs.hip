@@ -547,10 +547,21 @@ static int launch_hs_mt(const ConvHsArgs& a, int B, hipStream_t s) {
     const int th = 4 * nbw * (32 / mbw);
     return (long long)a.nct * ((a.W + mbw - 1) / mbw) * ((a.H + th - 1) / th) * B;
   };
-  // want >= ~3 tiles per resident workgroup, else shrink the tile
+  // Tile height by a small cost model: 256 persistent workgroups process ceil(tiles/256) rounds of tiles whose cost
+  // is ~ (NBW + 0.3) (0.3 = per-tile prologue/epilogue/barrier overhead in units of one 128-pixel block row,
+  // calibrated with tools/tune_hs.py).  Matters for batch sizes that do not fill the rounds (idx_left compaction).
   HsChoice c{4, 2, 1};
-  if (blocks(4) < 700) c.nbw = 2;
-  if (c.nbw == 2 && blocks(2) < 700) c.nbw = 1;
+  {
+    double best = 1e30;
+    for (int nbw : {4, 2, 1}) {
+      const long long nt = blocks(nbw);
+      const double cost = (double)((nt + 255) / 256) * (nbw + 0.3);
+      if (cost < best * 0.999) {
+        best = cost;
+        c.nbw = nbw;
+      }
+    }
+  }
   // Production configurations are double-buffered with >= 100 KB of LDS per workgroup, i.e. exactly one resident
   // workgroup per CU by construction.  Two co-resident workgroups per CU (single-stage or 80-KiB variants,
   // reachable through the PNPX_HS_* hook below) were 3-6 % faster on some layers, but the <MT=32, NBW=2> instance
