@@ -141,6 +141,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        D.barrier()          # rank 0 may still be in its (non-collective) roofline pass
         torch.distributed.destroy_process_group()
 
 

@@ -62,7 +62,7 @@ size_t pnpx_unet_num_params(void);
 int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params);
 /* out = clamp(UNet(cat[x, sigma*1]), 0, 1)   (denoiser/base.py:23-32).
  * x, out: [B,1,H,W]; sigma: [B]; out_preclamp (nullable): UNet output before the clamp.
- * H and W must be multiples of 16 (so that models/unet.py:109-113's F.pad is a no-op). */
+ * Any H, W >= 16; odd level sizes follow the reference's floor-pool / zero-pad rule (models/unet.py:82-85,109-113). */
 int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, float* out_preclamp,
                       int B, int H, int W, void* stream);
 /* Per-layer timing of one denoise call with HIP events on `stream` (synchronises).  ms_out[i] for the

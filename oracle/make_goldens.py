@@ -52,7 +52,7 @@ def main():
     with torch.no_grad():
         # (1) denoiser: UNet pre-clamp and UNetDenoiser2D post-clamp
         print("[1] denoiser")
-        for (B, H, W, seed) in [(2, 32, 32, 11), (2, 64, 64, 12), (1, 128, 128, 13), (2, 48, 80, 14)]:
+        for (B, H, W, seed) in [(2, 32, 32, 11), (2, 64, 64, 12), (1, 128, 128, 13), (2, 48, 80, 14), (2, 50, 39, 15)]:
             x, sigma = denoiser_inputs(B, H, W, seed)
             xin = torch.cat([t(x), torch.ones(B, 1, H, W) * t(sigma).view(B, 1, 1, 1)], 1)
             pre = den.net(xin)

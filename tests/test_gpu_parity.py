@@ -47,7 +47,8 @@ def oden(unet_params):
 
 
 # ------------------------------------------------------------------------------------------- denoiser
-@pytest.mark.parametrize("B,H,W,seed", [(2, 32, 32, 11), (2, 64, 64, 12), (1, 128, 128, 13), (2, 48, 80, 14)])
+@pytest.mark.parametrize("B,H,W,seed", [(2, 32, 32, 11), (2, 64, 64, 12), (1, 128, 128, 13), (2, 48, 80, 14),
+                                        (2, 50, 39, 15)])
 def test_denoiser_golden(den, B, H, W, seed):
     gd = golden(f"denoiser_B{B}_{H}x{W}")
     x, sigma = denoiser_inputs(B, H, W, seed)
@@ -75,7 +76,7 @@ def test_denoiser_rejects_bad_input(den):
     with pytest.raises(PnpxError):
         den(torch.zeros(1, 1, 32, 32), torch.zeros(1))               # CPU tensor: no CPU path
     with pytest.raises(PnpxError):
-        den(torch.zeros(1, 1, 24, 32, device=dev()), torch.zeros(1, device=dev()))   # not a multiple of 16
+        den(torch.zeros(1, 1, 12, 32, device=dev()), torch.zeros(1, device=dev()))   # too small for four poolings
 
 
 def test_denoiser_full_size_vs_oracle(den, oden):
@@ -84,7 +85,8 @@ def test_denoiser_full_size_vs_oracle(den, oden):
 
 
 # ------------------------------------------------------------------------------------------- FFT
-@pytest.mark.parametrize("shape,seed", [((2, 1, 16, 32), 21), ((1, 1, 128, 128), 22), ((1, 2, 64, 8), 24)])
+@pytest.mark.parametrize("shape,seed", [((2, 1, 16, 32), 21), ((1, 1, 128, 128), 22), ((2, 1, 6, 10), 23),
+                                        ((1, 2, 64, 8), 24)])
 def test_fft_golden(shape, seed):
     from tfpnp_amd.utils import transforms as T
     gd = golden("fft_" + "x".join(map(str, shape)))
@@ -106,13 +108,39 @@ def test_fft_properties_full_size():
     assert rel(T.fft2(y), ref) < 1e-5
 
 
-def test_fft_rejects_non_pow2():
+@pytest.mark.parametrize("H,W", [(5, 7), (9, 15), (1, 12), (12, 1), (96, 96), (30, 320), (63, 64)])
+def test_fft_general_sizes_vs_oracle(H, W):
+    """Any length up to 2048: mixed-radix Stockham stages; odd lengths use explicit (i)fftshift rolls."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd import ops
+    x = complex_inputs((3, 1, H, W), 100 + H + W)
+    assert rel(ops.fft2(g(x)), O.fft2c(t(x))) < 2e-6
+    assert rel(ops.fft2(g(x), inverse=True), O.ifft2c(t(x))) < 2e-6
+    ref = torch.view_as_real(torch.fft.fft2(torch.view_as_complex(t(x)), norm="ortho"))
+    assert rel(ops.fft2(g(x), centered=False), ref) < 2e-6
+    assert rel(ops.fft2(ops.fft2(g(x)), inverse=True), x) < 2e-6
+
+
+def test_fft_rejects_bad_input():
     from tfpnp_amd._lib import PnpxError
     from tfpnp_amd.utils import transforms as T
     with pytest.raises(PnpxError):
-        T.fft2(g(complex_inputs((2, 1, 6, 10), 23)))
+        T.fft2(torch.zeros(1, 1, 4, 4096, 2, device=dev()))          # longer than one LDS line
     with pytest.raises(AssertionError):
         T.fft2(torch.zeros(1, 1, 8, 8, 3, device=dev()))
+
+
+def test_csmri_non_power_of_two_vs_oracle(den, oden):
+    """96 x 96 (a multiple of 16 for the UNet, not a power of two for the FFT) and an odd-width k-space."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import csmri
+    B, H, W = 2, 96, 96
+    d = synth.make_csmri_batch(B, H, W, ratio=4, sigma_n=15.0, seed=55)
+    a = csmri_actions(B, 3, 56)
+    sol = csmri.ADMMSolver_CSMRI(den)
+    out = sol((sol.reset({"x0": g(d["x0"])}), (g(d["y0"]), g(d["mask"]))), (g(a["sigma_d"]), g(a["mu"])))
+    ref = O.csmri_admm(oden, O.admm_reset(t(d["x0"])), t(d["y0"]), t(d["mask"]), t(a["sigma_d"]), t(a["mu"]))
+    assert rel(out, ref) < TOL
 
 
 # ------------------------------------------------------------------------------------------- CS-MRI

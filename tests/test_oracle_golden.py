@@ -29,7 +29,8 @@ def den(unet_params):
     return O.Denoiser(unet_params)
 
 
-@pytest.mark.parametrize("B,H,W,seed", [(2, 32, 32, 11), (2, 64, 64, 12), (1, 128, 128, 13), (2, 48, 80, 14)])
+@pytest.mark.parametrize("B,H,W,seed", [(2, 32, 32, 11), (2, 64, 64, 12), (1, 128, 128, 13), (2, 48, 80, 14),
+                                        (2, 50, 39, 15)])
 def test_denoiser(unet_params, B, H, W, seed):
     g = golden(f"denoiser_B{B}_{H}x{W}")
     x, sigma = denoiser_inputs(B, H, W, seed)

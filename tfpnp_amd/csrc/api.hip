@@ -96,7 +96,7 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx) {
   if (ctx->arena.p) (void)hipFree(ctx->arena.p);
   if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
   for (auto& t : ctx->twiddle)
-    if (t) (void)hipFree(t);
+    if (t.second) (void)hipFree(t.second);
   for (auto e : ctx->events) (void)hipEventDestroy(e);
   delete ctx;
   return PNPX_OK;
@@ -104,8 +104,8 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx) {
 
 int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W) {
   LOCK_CTX(ctx);
-  if (B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) {
-    set_error("pnpx_ctx_reserve: need B>0 and H, W positive multiples of 16");
+  if (B <= 0 || H < 16 || W < 16) {
+    set_error("pnpx_ctx_reserve: need B > 0 and H, W >= 16");
     return PNPX_ERR_SHAPE;
   }
   return ctx_reserve_unet(ctx, B, H, W);

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -85,8 +86,8 @@ struct pnpx_ctx {
   int capB = 0, capH = 0, capW = 0;
   // --- solver scratch (complex fields etc.), grown on demand
   pnpx::DeviceBuf scratch;
-  // --- FFT twiddle tables, one per size log2(N) in [1,10]: device float2[N]
-  float2* twiddle[11] = {nullptr};
+  // --- FFT twiddle tables e^{-2 pi i m / N}, one per transform length: device float2[N]
+  std::map<int, float2*> twiddle;
   // --- events for pnpx_unet_profile
   std::vector<hipEvent_t> events;
 };

@@ -6,12 +6,12 @@
 namespace pnpx {
 
 int ctx_twiddle(pnpx_ctx* ctx, int N, const float2** out) {
-  const int lg = ilog2_exact(N);
-  if (lg < 0) {
-    set_error("FFT length %d unsupported (power of two in [2,1024] required)", N);
+  if (N < 1 || N > FFT_MAX_N) {
+    set_error("FFT length %d unsupported (1..%d)", N, FFT_MAX_N);
     return PNPX_ERR_SHAPE;
   }
-  if (!ctx->twiddle[lg]) {
+  auto it = ctx->twiddle.find(N);
+  if (it == ctx->twiddle.end()) {
     std::vector<float2> h(N);
     for (int m = 0; m < N; ++m) {
       const double a = -2.0 * M_PI * (double)m / (double)N;
@@ -20,21 +20,58 @@ int ctx_twiddle(pnpx_ctx* ctx, int N, const float2** out) {
     float2* d = nullptr;
     PNPX_HIP(hipMalloc(&d, sizeof(float2) * N));
     PNPX_HIP(hipMemcpy(d, h.data(), sizeof(float2) * N, hipMemcpyHostToDevice));
-    ctx->twiddle[lg] = d;
+    it = ctx->twiddle.emplace(N, d).first;
   }
-  *out = ctx->twiddle[lg];
+  *out = it->second;
+  return PNPX_OK;
+}
+
+// Stage radices for a length that is not a power of two: 4s and 2s first, then the odd prime factors.
+static int factorise(int N, PassGeom* g) {
+  g->nrad = 0;
+  int n = N;
+  auto push = [&](int r) {
+    if (g->nrad >= 12) return false;
+    g->rad[g->nrad++] = (unsigned short)r;
+    return true;
+  };
+  while (n % 4 == 0) {
+    if (!push(4)) return -1;
+    n /= 4;
+  }
+  for (int p = 2; p <= n; ++p)
+    while (n % p == 0) {
+      if (!push(p)) return -1;
+      n /= p;
+    }
+  return 0;
+}
+
+static int make_pass(pnpx_ctx* ctx, int n_img, int H, int W, int N, bool centered, int lines, PassGeom* g) {
+  const float2* tw;
+  PNPX_TRY(ctx_twiddle(ctx, N, &tw));
+  *g = PassGeom();
+  g->H = H;
+  g->W = W;
+  g->logN = ilog2_exact(N);
+  g->odd = (centered && (N & 1)) ? 1 : 0;
+  if (g->logN < 0 && factorise(N, g) != 0) {
+    set_error("FFT length %d has too many prime factors", N);
+    return PNPX_ERR_SHAPE;
+  }
+  g->lines = lines;
+  g->n_img = n_img;
+  g->scale = (float)(1.0 / std::sqrt((double)N));
+  g->centered = centered ? 1 : 0;
+  g->tw = tw;
   return PNPX_OK;
 }
 
 int make_fft_plan(pnpx_ctx* ctx, int n_img, int H, int W, bool centered, FftPlan2D* P) {
-  const int lw = ilog2_exact(W), lh = ilog2_exact(H);
-  if (lw < 0 || lh < 0 || n_img <= 0) {
-    set_error("fft2: H=%d W=%d unsupported (powers of two in [2,1024] required)", H, W);
+  if (H < 1 || W < 1 || H > FFT_MAX_N || W > FFT_MAX_N || n_img <= 0) {
+    set_error("fft2: H=%d W=%d unsupported (1..%d)", H, W, FFT_MAX_N);
     return PNPX_ERR_SHAPE;
   }
-  const float2 *tww, *twh;
-  PNPX_TRY(ctx_twiddle(ctx, W, &tww));
-  PNPX_TRY(ctx_twiddle(ctx, H, &twh));
   const int total_rows = n_img * H;
   int lr = FFT_TILE_POINTS / W;
   if (lr < 1) lr = 1;
@@ -43,10 +80,10 @@ int make_fft_plan(pnpx_ctx* ctx, int n_img, int H, int W, bool centered, FftPlan
   if (lc < 1) lc = 1;
   if (lc > W) lc = W;
   if (lc > 64) lc = 64;
-  P->rows = PassGeom{H, W, lw, lr, n_img, (float)(1.0 / std::sqrt((double)W)), centered ? 1 : 0, tww};
-  P->cols = PassGeom{H, W, lh, lc, n_img, (float)(1.0 / std::sqrt((double)H)), centered ? 1 : 0, twh};
+  PNPX_TRY(make_pass(ctx, n_img, H, W, W, centered, lr, &P->rows));
+  PNPX_TRY(make_pass(ctx, n_img, H, W, H, centered, lc, &P->cols));
   P->grid_rows = dim3((total_rows + lr - 1) / lr);
-  P->grid_cols = dim3(W / lc, n_img);
+  P->grid_cols = dim3((W + lc - 1) / lc, n_img);
   P->lds_rows = sizeof(float2) * 2 * (size_t)lr * (W + 1);
   P->lds_cols = sizeof(float2) * 2 * (size_t)lc * (H + 1);
   return PNPX_OK;

@@ -20,6 +20,7 @@ namespace pnpx {
 
 constexpr int FFT_THREADS = 256;
 constexpr int FFT_TILE_POINTS = 2048;
+constexpr int FFT_MAX_N = 2048;   // one line (+ ping-pong copy) must fit LDS
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -90,9 +91,53 @@ __device__ inline float2* lds_fft(float2* d0, float2* d1, int N, int logN, int l
   return d0;
 }
 
+// General-size stage: N = R * q, sub-transform length Ns so far.  O(R^2) butterflies straight from the definition
+// (R is a small prime factor in practice); twiddle and DFT_R phase are combined into one table index.
+template <bool INV>
+__device__ inline void lds_fft_stage_any(const float2* d0, float2* d1, int N, int R, int Ns, int lines,
+                                         const float2* __restrict__ tw) {
+  const int ls = N + 1, q = N / R, tstep = N / (R * Ns);
+  for (int item = threadIdx.x; item < lines * q; item += FFT_THREADS) {
+    const int l = item / q, j = item - l * q;
+    const int k = j % Ns;
+    const float2* s = d0 + l * ls + j;
+    float2* o = d1 + l * ls + (j - k) * R + k;
+    for (int rp = 0; rp < R; ++rp) {
+      float2 acc = make_float2(0.f, 0.f);
+      for (int r = 0; r < R; ++r) {
+        float2 t = tw[(int)(((long long)r * k * tstep + (long long)r * rp * q) % N)];
+        if (INV) t.y = -t.y;
+        const float2 v = s[r * q];
+        acc.x += v.x * t.x - v.y * t.y;
+        acc.y += v.x * t.y + v.y * t.x;
+      }
+      o[rp * Ns] = acc;
+    }
+  }
+}
+
+template <bool INV>
+__device__ inline float2* lds_fft_any(float2* d0, float2* d1, int N, int nrad, const unsigned short* rad, int lines,
+                                      const float2* __restrict__ tw) {
+  int Ns = 1;
+  __syncthreads();
+  for (int st = 0; st < nrad; ++st) {
+    lds_fft_stage_any<INV>(d0, d1, N, rad[st], Ns, lines, tw);
+    Ns *= rad[st];
+    __syncthreads();
+    float2* t = d0;
+    d0 = d1;
+    d1 = t;
+  }
+  return d0;
+}
+
 struct PassGeom {
   int H, W;          // image size
-  int logN;          // log2 of the transform length (W for rows, H for columns)
+  int logN;          // log2 of the transform length (W for rows, H for columns); -1 when it is not a power of two
+  int nrad;          // general sizes: Stockham stages of radix rad[0..nrad) (any factorisation of N)
+  unsigned short rad[12];
+  int odd;           // centered transform of odd length: explicit ifftshift/fftshift index rolls instead of sign flips
   int lines;         // lines per workgroup tile
   int n_img;
   float scale;       // 1/sqrt(N) (orthonormal)
@@ -110,26 +155,29 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_rows_kernel(PassGeom g, Load 
   const int line0 = blockIdx.x * g.lines;
   const int total = g.n_img * g.H;
   const int logW = g.logN;
+  const bool flip = g.centered && !g.odd;             // even length: shifts are sign flips
+  const int rin = g.odd ? (N + 1) / 2 : 0, rout = g.odd ? N / 2 : 0;   // odd length: explicit rolls
   for (int idx = threadIdx.x; idx < g.lines * N; idx += FFT_THREADS) {
-    const int l = idx >> logW, x = idx & (N - 1);
+    const int l = logW >= 0 ? idx >> logW : idx / N, x = idx - l * N;
     const int gl = line0 + l;
     float2 v = make_float2(0.f, 0.f);
     if (gl < total) {
       const int b = gl / g.H, y = gl - b * g.H;
-      v = ld(b, y, x);
-      if (g.centered && (x & 1)) { v.x = -v.x; v.y = -v.y; }
+      v = ld(b, y, g.odd ? (x + N - rin) % N : x);
+      if (flip && (x & 1)) { v.x = -v.x; v.y = -v.y; }
     }
     d0[l * ls + x] = v;
   }
-  float2* r = lds_fft<INV>(d0, d1, N, logW, g.lines, g.tw);
+  float2* r = logW >= 0 ? lds_fft<INV>(d0, d1, N, logW, g.lines, g.tw)
+                        : lds_fft_any<INV>(d0, d1, N, g.nrad, g.rad, g.lines, g.tw);
   for (int idx = threadIdx.x; idx < g.lines * N; idx += FFT_THREADS) {
-    const int l = idx >> logW, k = idx & (N - 1);
+    const int l = logW >= 0 ? idx >> logW : idx / N, k = idx - l * N;
     const int gl = line0 + l;
     if (gl < total) {
       const int b = gl / g.H, y = gl - b * g.H;
       float2 v = r[l * ls + k];
-      const float sc = (g.centered && ((k + (N >> 1)) & 1)) ? -g.scale : g.scale;
-      st(b, y, k, make_float2(v.x * sc, v.y * sc));
+      const float sc = (flip && ((k + (N >> 1)) & 1)) ? -g.scale : g.scale;
+      st(b, y, g.odd ? (k + rout) % N : k, make_float2(v.x * sc, v.y * sc));
     }
   }
 }
@@ -149,30 +197,34 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols_kernel(PassGeom g, Load 
   const int x0 = blockIdx.x * C;
   const int b = blockIdx.y;
   const int half = N >> 1;
+  const bool flip = g.centered && !g.odd;
+  const int rin = g.odd ? (N + 1) / 2 : 0, rout = g.odd ? N / 2 : 0;
   for (int idx = threadIdx.x; idx < C * N; idx += FFT_THREADS) {
     const int y = idx / C, c = idx - y * C;
-    float2 v = ld(b, y, x0 + c);
-    if (g.centered && (y & 1)) { v.x = -v.x; v.y = -v.y; }
+    float2 v = (x0 + c < g.W) ? ld(b, g.odd ? (y + N - rin) % N : y, x0 + c) : make_float2(0.f, 0.f);
+    if (flip && (y & 1)) { v.x = -v.x; v.y = -v.y; }
     d0[c * ls + y] = v;
   }
-  float2* r = lds_fft<INV>(d0, d1, N, g.logN, C, g.tw);
+  float2* r = g.logN >= 0 ? lds_fft<INV>(d0, d1, N, g.logN, C, g.tw) : lds_fft_any<INV>(d0, d1, N, g.nrad, g.rad, C, g.tw);
   if (FUSED) {
+    // For odd N the natural FFT index ky sits at centered position (ky + N/2) % N and, because
+    // N/2 + (N+1)/2 == N, is already in ifftshift order for the inverse transform: the value stays in place.
     for (int idx = threadIdx.x; idx < C * N; idx += FFT_THREADS) {
       const int ky = idx / C, c = idx - ky * C;
       float2 v = r[c * ls + ky];
-      const float sc = (g.centered && ((ky + half) & 1)) ? -g.scale : g.scale;
-      v = mid(b, ky, x0 + c, make_float2(v.x * sc, v.y * sc));
-      if (g.centered && (ky & 1)) { v.x = -v.x; v.y = -v.y; }
+      const float sc = (flip && ((ky + half) & 1)) ? -g.scale : g.scale;
+      if (x0 + c < g.W) v = mid(b, g.odd ? (ky + rout) % N : ky, x0 + c, make_float2(v.x * sc, v.y * sc));
+      if (flip && (ky & 1)) { v.x = -v.x; v.y = -v.y; }
       r[c * ls + ky] = v;
     }
     float2* other = (r == d0) ? d1 : d0;
-    r = lds_fft<!INV>(r, other, N, g.logN, C, g.tw);
+    r = g.logN >= 0 ? lds_fft<!INV>(r, other, N, g.logN, C, g.tw) : lds_fft_any<!INV>(r, other, N, g.nrad, g.rad, C, g.tw);
   }
   for (int idx = threadIdx.x; idx < C * N; idx += FFT_THREADS) {
     const int y = idx / C, c = idx - y * C;
     float2 v = r[c * ls + y];
-    const float sc = (g.centered && ((y + half) & 1)) ? -g.scale : g.scale;
-    st(b, y, x0 + c, make_float2(v.x * sc, v.y * sc));
+    const float sc = (flip && ((y + half) & 1)) ? -g.scale : g.scale;
+    if (x0 + c < g.W) st(b, g.odd ? (y + rout) % N : y, x0 + c, make_float2(v.x * sc, v.y * sc));
   }
 }
 
@@ -189,7 +241,7 @@ struct StoreC {
 };
 
 inline int ilog2_exact(int n) {
-  if (n < 2 || n > 1024 || (n & (n - 1))) return -1;
+  if (n < 2 || n > 2048 || (n & (n - 1))) return -1;
   int l = 0;
   while ((1 << l) < n) ++l;
   return l;

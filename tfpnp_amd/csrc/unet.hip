@@ -49,10 +49,13 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__
 
 // nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (models/unet.py:99): src = dst*(in-1)/(out-1),
 // i0 = floor(src), i1 = i0 + (i0 < in-1), weights (1-l, l); same association as ATen's CPU kernel.
+// The target tensor has the skip connection's size (Ht x Wt >= 2h x 2w): the reference zero-pads the upsampled map
+// on the bottom/right when a level's size is odd (F.pad, models/unet.py:109-113; the offset diff//2 is always 0
+// because diff is 0 or 1); those cells are part of the never-written zero margin here.
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                         size_t n_out, int h, int w, float sy, float sx) {
+                                                         size_t n_out, int h, int w, int Ht, int Wt, float sy, float sx) {
   const int H = 2 * h, W = 2 * w;
-  const int hp = padded_h(h), wp = padded_w(w), Hp = padded_h(H), Wp = padded_w(W);
+  const int hp = padded_h(h), wp = padded_w(w), Hp = padded_h(Ht), Wp = padded_w(Wt);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out) return;
   const int x = (int)(i % W);
@@ -144,7 +147,8 @@ __global__ __launch_bounds__(256) void maxpool2_hs_kernel(const HsRec* __restric
 }
 
 __global__ __launch_bounds__(256) void upsample2x_hs_kernel(const HsRec* __restrict__ src, HsRec* __restrict__ dst,
-                                                            size_t n_out, int h, int w, float sy, float sx) {
+                                                            size_t n_out, int h, int w, int Ht, int Wt, float sy,
+                                                            float sx) {
   const int H = 2 * h, W = 2 * w;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out) return;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void upsample2x_hs_kernel(const HsRec* __restr
   hs_unpack(s[(size_t)(y1 + 1) * (w + 2) + x1], v11);
 #pragma unroll
   for (int k = 0; k < 8; ++k) o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
-  dst[(bg * (H + 2) + (y + 1)) * (W + 2) + x + 1] = hs_pack(o);
+  dst[(bg * (Ht + 2) + (y + 1)) * (Wt + 2) + x + 1] = hs_pack(o);
 }
 
 __global__ __launch_bounds__(256) void outc_residual_hs_kernel(const HsRec* __restrict__ feat, const float* __restrict__ x,
@@ -381,11 +385,12 @@ static int unet_forward_hs(pnpx_ctx* ctx, const UNetPlan& P, const float* x, con
     for (int b0 = 0; b0 < B; b0 += sb) {
       const int nb = (B - b0 < sb) ? (B - b0) : sb;
       ConvHsFuse f;
-      f.up_in1 = !no_up_fuse;
-      if (no_up_fuse) {
+      const bool fuse_up = !no_up_fuse && P.u[l].H == 2 * h && P.u[l].W == 2 * w;
+      f.up_in1 = fuse_up;
+      if (!fuse_up) {
         const size_t n_up = (size_t)nb * (below->C / 8) * (2 * h) * (2 * w);
         hipLaunchKernelGGL(upsample2x_hs_kernel, g1d(n_up), dim3(256), 0, s, rat(*below, b0), rat(P.u[l], b0), n_up, h, w,
-                           sy, sx);
+                           P.u[l].H, P.u[l].W, sy, sx);
         PNPX_LAUNCH_CHECK();
         PNPX_TRY(rec.mark("upsample2x", 0));
       }
@@ -396,7 +401,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, const UNetPlan& P, const float* x, con
         f.out_img = out + (size_t)b0 * H * W;
         f.out_pre = out_pre ? out_pre + (size_t)b0 * H * W : nullptr;
       }
-      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], no_up_fuse ? &P.u[l] : below, l, P.y[l], b0, nb, f));
+      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], fuse_up ? below : &P.u[l], l, P.y[l], b0, nb, f));
     }
     below = &P.y[l];
   }
@@ -415,126 +420,59 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     set_error("denoiser called before pnpx_unet_load");
     return PNPX_ERR_NO_WEIGHTS;
   }
-  if (B <= 0 || H <= 0 || W <= 0 || (H % 16) != 0 || (W % 16) != 0) {
-    set_error("denoiser: H and W must be positive multiples of 16 (got B=%d H=%d W=%d)", B, H, W);
+  if (B <= 0 || H < 16 || W < 16) {
+    set_error("denoiser: need B > 0 and H, W >= 16 (four 2x2 poolings; got B=%d H=%d W=%d)", B, H, W);
     return PNPX_ERR_SHAPE;
   }
   PNPX_TRY(ctx_reserve_unet(ctx, B, H, W));
   const int mode = ctx->conv_mode;
   const bool hs = (mode == CONV_HS);
   const UNetPlan P = make_plan(mode, ctx->capB, H, W);
-  char* A = static_cast<char*>(ctx->arena.p);
-  auto cptr = [&](const Act& d) { return A + d.off; };
-  auto fptr = [&](const Act& d) { return reinterpret_cast<float*>(A + d.off); };
-  auto rptr = [&](const Act& d) { return reinterpret_cast<HsRec*>(A + d.off); };
   Recorder rec{prof, s};
   if (prof) PNPX_HIP(hipEventRecord((*prof->events)[0], s));
   if (hs) return unet_forward_hs(ctx, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec);
 
-  const size_t npix = (size_t)B * H * W;
-  if (hs) {
-    hipLaunchKernelGGL(prep_input_hs_kernel, g1d(npix), dim3(256), 0, s, x, sigma, sigma_stride, rptr(P.in0), H, W, npix);
-  } else {
-    hipLaunchKernelGGL(prep_input_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, x, sigma, sigma_stride,
-                       fptr(P.in0), H, W, padded_h(H), padded_w(W));
-  }
+  // ---- plain-fp32 path (conv_mode 0): padded planar fp32 activations, whole batch per launch
+  char* A = static_cast<char*>(ctx->arena.p);
+  auto fptr = [&](const Act& d) { return reinterpret_cast<float*>(A + d.off); };
+  hipLaunchKernelGGL(prep_input_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, x, sigma, sigma_stride, fptr(P.in0), H,
+                     W, padded_h(H), padded_w(W));
   PNPX_LAUNCH_CHECK();
   PNPX_TRY(rec.mark("prep_input", 0));
-
-  auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o, const ConvHsFuse& fuse = ConvHsFuse()) -> int {
+  auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o) -> int {
     const ConvLayer& L = ctx->conv[li];
-    if (hs) {
-      const ConvLayerHsDev& D = ctx->conv_hs[li];
-      ConvLayerHs Lh;
-      Lh.cin = D.cin;
-      Lh.cout = D.cout;
-      Lh.cin_pad = D.cin_pad;
-      Lh.mt = D.mt;
-      Lh.w = D.w;
-      Lh.b = L.b;
-      Lh.inv_scale = D.inv_scale;
-      PNPX_TRY(launch_conv_hs(Lh, cptr(i0), i0.C / 8, i1 ? cptr(*i1) : nullptr, i1 ? i1->C / 8 : 0, cptr(o), B, o.H,
-                              o.W, fuse, s));
-    } else {
-      PNPX_TRY(launch_conv3x3(L, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, i1 ? i1->C : 0, fptr(o), B, o.H, o.W, s));
-    }
+    PNPX_TRY(launch_conv3x3(L, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, i1 ? i1->C : 0, fptr(o), B, o.H, o.W, s));
     return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);
   };
-  auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o,
-                   const ConvHsFuse& fuse = ConvHsFuse()) -> int {
+  auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o) -> int {
     PNPX_TRY(conv(li, i0, i1, P.a[lvl]));
     PNPX_TRY(conv(li + 1, P.a[lvl], nullptr, P.b[lvl]));
-    return conv(li + 2, P.b[lvl], nullptr, o, fuse);
+    return conv(li + 2, P.b[lvl], nullptr, o);
   };
-
-  // encoder.  HS mode: the last conv of each encoder block also writes its 2x2 max-pooled output (fused epilogue)
-  // whenever the level is wide enough for the 32-pixel tiles; otherwise a separate pool kernel runs.
-  const bool no_pool_fuse = getenv("PNPX_NO_POOL_FUSE") != nullptr, no_outc_fuse = getenv("PNPX_NO_OUTC_FUSE") != nullptr;
-  auto pool_fused = [&](int l) { return hs && !no_pool_fuse && l < 4 && conv_hs_can_pool(P.x[l].H, P.x[l].W); };
-  {
-    ConvHsFuse f;
-    if (pool_fused(0)) f.pool_out = cptr(P.p[1]);
-    PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0], f));
-  }
+  PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0]));
   for (int l = 1; l < 5; ++l) {
     const Act& src = P.x[l - 1];
-    if (pool_fused(l - 1)) {
-      ConvHsFuse f;
-      if (pool_fused(l)) f.pool_out = cptr(P.p[l + 1]);
-      PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l], f));
-      continue;
-    }
-    if (hs) {
-      const size_t n_pool = (size_t)B * (src.C / 8) * (src.H / 2) * (src.W / 2);
-      hipLaunchKernelGGL(maxpool2_hs_kernel, g1d(n_pool), dim3(256), 0, s, rptr(src), rptr(P.p[l]), n_pool, src.H, src.W);
-    } else {
-      const size_t n_pool = (size_t)B * src.C * (src.H / 2) * (src.W / 2);
-      hipLaunchKernelGGL(maxpool2_kernel, g1d(n_pool), dim3(256), 0, s, fptr(src), fptr(P.p[l]), n_pool, src.H, src.W);
-    }
+    const size_t n_pool = (size_t)B * src.C * (src.H / 2) * (src.W / 2);
+    hipLaunchKernelGGL(maxpool2_kernel, g1d(n_pool), dim3(256), 0, s, fptr(src), fptr(P.p[l]), n_pool, src.H, src.W);
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(rec.mark("maxpool2", 0));
-    {
-      ConvHsFuse f;
-      if (pool_fused(l)) f.pool_out = cptr(P.p[l + 1]);
-      PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l], f));
-    }
+    PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l]));
   }
-  // decoder
   const Act* below = &P.x[4];
   for (int l = 3; l >= 0; --l) {
     const int h = below->H, w = below->W;
     const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
-    if (hs) {
-      const size_t n_up = (size_t)B * (below->C / 8) * (2 * h) * (2 * w);
-      hipLaunchKernelGGL(upsample2x_hs_kernel, g1d(n_up), dim3(256), 0, s, rptr(*below), rptr(P.u[l]), n_up, h, w, sy, sx);
-    } else {
-      const size_t n_up = (size_t)B * below->C * (2 * h) * (2 * w);
-      hipLaunchKernelGGL(upsample2x_kernel, g1d(n_up), dim3(256), 0, s, fptr(*below), fptr(P.u[l]), n_up, h, w, sy, sx);
-    }
+    const size_t n_up = (size_t)B * below->C * (2 * h) * (2 * w);
+    hipLaunchKernelGGL(upsample2x_kernel, g1d(n_up), dim3(256), 0, s, fptr(*below), fptr(P.u[l]), n_up, h, w, P.u[l].H,
+                       P.u[l].W, sy, sx);
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(rec.mark("upsample2x", 0));
-    {
-      ConvHsFuse f;
-      if (hs && l == 0 && !no_outc_fuse) {   // the network tail (1x1 conv + residual + clamp) rides on the last conv's epilogue
-        f.outc_w = ctx->outc_w;
-        f.outc_b = ctx->outc_b;
-        f.x_in = x;
-        f.out_img = out;
-        f.out_pre = out_pre;
-      }
-      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l], f));
-    }
+    PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l]));
     below = &P.y[l];
   }
-  if (hs && !no_outc_fuse) return PNPX_OK;
-  if (hs) {
-    hipLaunchKernelGGL(outc_residual_hs_kernel, g1d(npix), dim3(256), 0, s, rptr(P.y[0]), x, ctx->outc_w, ctx->outc_b,
-                       out, out_pre, H, W, npix);
-  } else {
-    hipLaunchKernelGGL(outc_residual_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, fptr(P.y[0]), x, ctx->outc_w,
-                       ctx->outc_b, out, out_pre, H, W);
-  }
+  hipLaunchKernelGGL(outc_residual_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, fptr(P.y[0]), x, ctx->outc_w,
+                     ctx->outc_b, out, out_pre, H, W);
   PNPX_LAUNCH_CHECK();
   PNPX_TRY(rec.mark("outc_residual_clamp", 2.0 * 32 * (double)H * W * B));
   return PNPX_OK;
