@@ -65,6 +65,12 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params);
  * Any H, W >= 16; odd level sizes follow the reference's floor-pool / zero-pad rule (models/unet.py:82-85,109-113). */
 int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, float* out_preclamp,
                       int B, int H, int W, void* stream);
+/* Vector-Jacobian product of pnpx_unet_denoise wrt x and sigma (weights are frozen): given grad_out [B,1,H,W] returns
+ * grad_x [B,1,H,W] and grad_sigma [B].  This is what autograd computes through UNetDenoiser2D.forward when the
+ * reference differentiates the solver for policy training (tfpnp/env/base.py:193-206, trainer/mddpg/trainer.py:171-192).
+ * The forward pass is re-computed internally in exact fp32 (gradient checkpointing); nothing is kept between calls. */
+int pnpx_unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, const float* grad_out,
+                               float* grad_x, float* grad_sigma, int B, int H, int W, void* stream);
 /* Per-layer timing of one denoise call with HIP events on `stream` (synchronises).  ms_out[i] for the
  * i-th kernel launch of the forward pass, flops_out[i] its algorithmic FLOPs (0 for non-conv launches),
  * names_out[i] a static string.  Returns the number of entries written (<= cap) in *n_out. */

@@ -1,0 +1,346 @@
+"""GPU tests of the training path: the native denoiser VJP (pnpx_unet_denoise_backward) and the differentiable
+solver iterations, against torch.autograd through the CPU oracle.
+
+Yardstick: LeakyReLU / max-pool / clamp have discontinuous derivatives, so two correct fp32 evaluations that round
+differently disagree at the few elements whose pre-activation sits within round-off of a kink.  The tolerance is
+therefore tied to what the CPU oracle itself shows between fp32 and fp64 (a structural error is O(1))."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_inputs import denoiser_inputs, csmri_actions
+from tfpnp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def g(a, grad=False):
+    x = t(a).to(dev())
+    return x.requires_grad_(True) if grad else x
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def den(unet_params):
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    return UNetDenoiser2D(state_dict=unet_params)
+
+
+@pytest.fixture(scope="module")
+def oden64(unet_params):
+    from oracle import pnp_oracle as O
+    return O.Denoiser(unet_params, dtype=torch.float64)
+
+
+@pytest.fixture(scope="module")
+def oden32(unet_params):
+    from oracle import pnp_oracle as O
+    return O.Denoiser(unet_params)
+
+
+def oracle_grads(fn, inputs, wts, dtype):
+    leaves = [t(a).to(dtype).requires_grad_(True) for a in inputs]
+    out = fn(*leaves)
+    (out * t(wts).to(dtype)).sum().backward()
+    return out.detach(), [l.grad for l in leaves]
+
+
+class _KinkProbe:
+    """Stands in for torch.nn.functional inside the oracle and records how close any LeakyReLU input or max-pool
+    decision comes to its kink, relative to the layer's mean magnitude."""
+
+    def __init__(self):
+        import torch.nn.functional as F
+        self.F, self.margin = F, float("inf")
+
+    def __getattr__(self, name):
+        return getattr(self.F, name)
+
+    def leaky_relu(self, x, slope):
+        self.margin = min(self.margin, float(x.abs().min() / x.abs().mean()))
+        return self.F.leaky_relu(x, slope)
+
+    def max_pool2d(self, x, k):
+        B, C, H, W = x.shape
+        win = x[:, :, :H // 2 * 2, :W // 2 * 2].reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5)
+        top = win.reshape(B, C, H // 2, W // 2, 4).topk(2, dim=-1).values
+        self.margin = min(self.margin, float((top[..., 0] - top[..., 1]).min() / x.abs().mean()))
+        return self.F.max_pool2d(x, k)
+
+
+def kink_margin(oden64, x, s):
+    from oracle import pnp_oracle as O
+    probe, keep = _KinkProbe(), O.F
+    O.F = probe
+    try:
+        with torch.no_grad():
+            xt, st = t(x).double(), t(s).double()
+            N, _, H, W = xt.shape
+            pre = O.unet_forward(torch.cat([xt, torch.ones(N, 1, H, W, dtype=xt.dtype) * st.view(N, 1, 1, 1)], 1),
+                                 oden64.params)
+    finally:
+        O.F = keep
+    return min(probe.margin, float(pre.abs().min()), float((pre - 1).abs().min()))
+
+
+def kink_free_inputs(oden64, B, H, W, seed, tau=1e-5, tries=200):
+    """Seeded inputs at which the denoiser is differentiable with a safety margin: no activation, pooling decision or
+    clamp within `tau` (relative) of its kink in the fp64 oracle.  The derivative there does not depend on fp32
+    round-off, so the VJP can be compared tightly."""
+    for k in range(tries):
+        x, s = denoiser_inputs(B, H, W, seed + 1000 * k)
+        if kink_margin(oden64, x, s) > tau:
+            return x, s, k
+    raise AssertionError("no kink-free input found")
+
+
+@pytest.mark.parametrize("B,H,W,seed", [(1, 16, 16, 61), (2, 16, 16, 62), (1, 17, 23, 63), (1, 24, 40, 64), (2, 19, 33, 65),
+                                         (1, 32, 32, 66)])
+def test_denoiser_vjp_tight_at_kink_free_inputs(den, oden64, B, H, W, seed):
+    x, s, k = kink_free_inputs(oden64, B, H, W, seed)
+    wts = np.random.RandomState(seed).standard_normal((B, 1, H, W)).astype(np.float32)
+    _, (gx64, gs64) = oracle_grads(lambda a, b: oden64(a, b), (x, s), wts, torch.float64)
+    xd, sd = g(x, True), g(s, True)
+    out = den(xd, sd)
+    assert out.requires_grad
+    (out * g(wts)).sum().backward()
+    ex, es = rel(xd.grad, gx64), rel(sd.grad, gs64)
+    print(f"vjp {B}x{H}x{W} (try {k}): grad_x {ex:.2e}  grad_sigma {es:.2e}")
+    assert ex < 2e-5 and es < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,seed", [(2, 48, 80, 62), (1, 50, 39, 63), (3, 64, 64, 64), (1, 128, 128, 65)])
+def test_denoiser_vjp_vs_oracle_autograd(den, oden32, oden64, B, H, W, seed):
+    """Arbitrary inputs: a handful of the ~1e6 activations sit within fp32 round-off of a LeakyReLU / pooling kink, and
+    each such element legitimately takes either one-sided derivative (observed effect 1e-3 .. 5e-3 relative)."""
+    x, s = denoiser_inputs(B, H, W, seed)
+    wts = np.random.RandomState(seed).standard_normal((B, 1, H, W)).astype(np.float32)
+    _, (gx64, gs64) = oracle_grads(lambda a, b: oden64(a, b), (x, s), wts, torch.float64)
+    xd, sd = g(x, True), g(s, True)
+    (den(xd, sd) * g(wts)).sum().backward()
+    ex, es = rel(xd.grad, gx64), rel(sd.grad, gs64)
+    print(f"vjp {B}x{H}x{W}: grad_x {ex:.2e}  grad_sigma {es:.2e}  kink margin {kink_margin(oden64, x, s):.1e}")
+    assert ex < 2e-2 and es < 2e-2
+
+
+def test_denoiser_vjp_is_linear_and_batch_independent(den):
+    from tfpnp_amd import ops
+    x, s = denoiser_inputs(3, 48, 48, 66)
+    rs = np.random.RandomState(66)
+    g1, g2 = (rs.standard_normal((3, 1, 48, 48)).astype(np.float32) for _ in range(2))
+    ctx = den.context(dev())
+    a, sa = ops.unet_denoise_backward(ctx, g(x), g(s), g(g1))
+    b, sb = ops.unet_denoise_backward(ctx, g(x), g(s), g(g2))
+    c, sc = ops.unet_denoise_backward(ctx, g(x), g(s), g(2 * g1 - 3 * g2))
+    assert rel(c, 2 * a - 3 * b) < 1e-5 and rel(sc, 2 * sa - 3 * sb) < 1e-5
+    one, sone = ops.unet_denoise_backward(ctx, g(x[1:2]), g(s[1:2]), g(g1[1:2]))
+    assert rel(one, a[1:2]) < 1e-6 and rel(sone, sa[1:2]) < 1e-6
+    # the forward pass in between still works and is unchanged by the backward workspaces
+    ref = den(g(x), g(s)).clone()
+    ops.unet_denoise_backward(ctx, g(x), g(s), g(g1))
+    assert torch.equal(den(g(x), g(s)), ref)
+
+
+def _check(names, got, want64, want32, floor=2e-2):   # floor: see test_denoiser_vjp_vs_oracle_autograd
+    for n, a, b64, b32 in zip(names, got, want64, want32):
+        e, y = rel(a, b64), rel(b32, b64)
+        print(f"  d/d{n}: {e:.2e} (cpu fp32 {y:.2e})")
+        assert e < max(3 * y, floor), n
+
+
+@pytest.mark.parametrize("name,keys", [("admm", ("sigma_d", "mu")), ("hqs", ("sigma_d", "mu")),
+                                       ("pg", ("sigma_d", "tau")), ("apg", ("sigma_d", "tau", "beta")),
+                                       ("redadmm", ("sigma_d", "mu", "lamda"))])
+def test_csmri_solver_gradients(den, oden32, oden64, name, keys):
+    """PnPEnv.forward under autograd (tfpnp/env/base.py:193-206): d loss / d (state, policy actions)."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import csmri
+    B, H, W, T = 2, 32, 32, 3
+    d = synth.make_csmri_batch(B, H, W, seed=71)
+    a = csmri_actions(B, T, 72, keys)
+    if "beta" in a:
+        a["beta"] = (0.3 * a["beta"]).astype(np.float32)
+    sol = {"admm": csmri.ADMMSolver_CSMRI, "hqs": csmri.HQSSolver_CSMRI, "pg": csmri.PGSolver_CSMRI,
+           "apg": csmri.APGSolver_CSMRI, "redadmm": csmri.REDADMMSolver_CSMRI}[name](den)
+    v0 = sol.reset({"x0": g(d["x0"])}).cpu().numpy()
+    wts = np.random.RandomState(73).standard_normal(v0.shape).astype(np.float32)
+    ofn = getattr(O, "csmri_" + name)
+    acts = [a[k] for k in keys]
+
+    def run_oracle(oden, dtype):
+        y0, m = t(d["y0"]).to(dtype), t(d["mask"])
+        return oracle_grads(lambda v, *p: ofn(oden, v, y0, m, *p), [v0] + acts, wts, dtype)
+
+    out64, g64 = run_oracle(oden64, torch.float64)
+    _, g32 = run_oracle(oden32, torch.float32)
+    leaves = [g(v0, True)] + [g(p, True) for p in acts]
+    out = sol((leaves[0], (g(d["y0"]), g(d["mask"]))), tuple(leaves[1:]))
+    assert rel(out, out64) < 1e-4
+    # same values as the fused inference loop
+    with torch.no_grad():
+        fused = sol((g(v0), (g(d["y0"]), g(d["mask"]))), tuple(g(p) for p in acts))
+    assert rel(out, fused) < 1e-5
+    (out * g(wts)).sum().backward()
+    _check(["variables"] + list(keys), [l.grad for l in leaves], g64, g32)
+
+
+def test_pr_solver_gradients(den, oden32, oden64):
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import pr
+    B, H, W, S, T = 2, 32, 32, 4, 3
+    d = synth.make_pr_batch(B, H, W, S=S, alpha=9.0, seed=75)
+    a = csmri_actions(B, T, 76, ("sigma_d", "mu", "tau"))
+    a["tau"] = (a["tau"] * 0.5).astype(np.float32)
+    sol = pr.IADMMSolver_PR(den)
+    v0 = sol.reset({"x0": g(d["x0"])}).cpu().numpy()
+    wts = np.random.RandomState(77).standard_normal(v0.shape).astype(np.float32)
+    acts = [a["sigma_d"], a["mu"], a["tau"]]
+
+    def run_oracle(oden, dtype):
+        y0, m = t(d["y0"]).to(dtype), t(d["mask"]).to(dtype)
+        return oracle_grads(lambda v, *p: O.pr_iadmm(oden, v, y0, m, *p), [v0] + acts, wts, dtype)
+
+    out64, g64 = run_oracle(oden64, torch.float64)
+    _, g32 = run_oracle(oden32, torch.float32)
+    leaves = [g(v0, True)] + [g(p, True) for p in acts]
+    out = sol((leaves[0], (g(d["y0"]), g(d["mask"]))), tuple(leaves[1:]))
+    assert rel(out, out64) < 1e-4
+    (out * g(wts)).sum().backward()
+    _check(["variables", "sigma_d", "mu", "tau"], [l.grad for l in leaves], g64, g32)
+
+
+def test_spi_solver_gradients(den, oden32):
+    """One iteration from the same state (the bisection prox is discontinuous, see test_spi_golden)."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import spi
+    B, H, W = 2, 32, 32
+    d = synth.make_spi_batch(B, H, W, K=6, seed=78)
+    rs = np.random.RandomState(79)
+    sg = rs.uniform(15 / 255.0, 70 / 255.0, (B, 1)).astype(np.float32)
+    m = rs.uniform(50, 120, (B, 1)).astype(np.float32)
+    sol = spi.ADMMSolver_SPI(den)
+    v0 = sol.reset({"x0": g(d["x0"])}).cpu().numpy()
+    v0[:, 2] = 0.02 * rs.standard_normal(v0[:, 2].shape).astype(np.float32)
+    wts = rs.standard_normal(v0.shape).astype(np.float32)
+    out32, g32 = oracle_grads(lambda v, s_, m_: O.spi_admm(oden32, v, t(d["x0"]), t(d["K"]), s_, m_), [v0, sg, m], wts,
+                              torch.float32)
+    leaves = [g(v0, True), g(sg, True), g(m, True)]
+    out = sol((leaves[0], (g(d["x0"]), g(d["K"]))), tuple(leaves[1:]))
+    assert rel(out, out32) < 5e-3
+    (out * g(wts)).sum().backward()
+    for n, a_, b_ in zip(["variables", "sigma_d", "mu"], [l.grad for l in leaves], g32):
+        print(f"  spi d/d{n}: {rel(a_, b_):.2e}")
+        assert rel(a_, b_) < 2e-2, n
+
+
+def test_ct_solver_gradients(den, oden32, oden64, monkeypatch):
+    """The Radon pair is unmatched and each operator is used as the other's VJP (torch_radon's convention); the
+    oracle is given the same convention through autograd.Function wrappers for this test."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import ct
+    from tfpnp_amd.utils import transforms as Tr
+    B, R, V, T = 2, 32, 20, 3
+    fwd, bwd = O.radon_forward, O.radon_backprojection
+
+    class F_(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, img, angles, det):
+            ctx.a, ctx.R = angles, img.shape[-1]
+            return fwd(img, angles, det)
+
+        @staticmethod
+        def backward(ctx, gr):
+            return bwd(gr, ctx.a, ctx.R), None, None
+
+    class B_(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, sino, angles, res):
+            ctx.a, ctx.det = angles, sino.shape[-1]
+            return bwd(sino, angles, res)
+
+        @staticmethod
+        def backward(ctx, gr):
+            return fwd(gr, ctx.a, ctx.det), None, None
+
+    monkeypatch.setattr(O, "radon_forward", lambda img, a, det: F_.apply(img, a, det))
+    monkeypatch.setattr(O, "radon_backprojection", lambda s, a, res: B_.apply(s, a, res))
+    angles, det = O.radon_geometry(R, V)
+    gt = synth.phantom_batch(B, R, R, 91)
+    rs = np.random.RandomState(92)
+    sino = fwd(t(gt), angles, det).numpy()
+    y0 = (sino * (1 + 0.05 * rs.standard_normal(sino.shape))).astype(np.float32)
+    radon = Tr.Radon_norm(R, V, device=dev())
+    x0 = radon.backprojection_norm(g(y0)).cpu().numpy()
+    view = np.full((B, 1, R, R), V / 120.0, np.float32)
+    a = csmri_actions(B, T, 93, ("sigma_d", "mu", "tau"))
+    sol = ct.IADMMSolver_CT(den)
+    v0 = sol.reset({"x0": g(x0)}).cpu().numpy()
+    wts = rs.standard_normal(v0.shape).astype(np.float32)
+    acts = [a["sigma_d"], a["mu"], a["tau"]]
+
+    def run_oracle(oden, dtype):
+        return oracle_grads(lambda v, *p: O.ct_iadmm(oden, v, t(y0).to(dtype), V, radon.opnorm, *p), [v0] + acts, wts,
+                            dtype)
+
+    out64, g64 = run_oracle(oden64, torch.float64)
+    _, g32 = run_oracle(oden32, torch.float32)
+    leaves = [g(v0, True)] + [g(p, True) for p in acts]
+    out = sol((leaves[0], (g(y0), g(view))), tuple(leaves[1:]))
+    assert rel(out, out64) < 1e-4
+    (out * g(wts)).sum().backward()
+    _check(["variables", "sigma_d", "mu", "tau"], [l.grad for l in leaves], g64, g32)
+    # PG variant: values + gradients flow
+    pg = ct.PGSolver_CT(den)
+    pg.radon_generator.opnorms = dict(sol.radon_generator.opnorms)
+    leaves = [g(x0, True), g(a["sigma_d"], True), g(a["tau"], True)]
+    out = pg((leaves[0], (g(y0), g(view))), (leaves[1], leaves[2]))
+    _, gp64 = oracle_grads(lambda v, s_, t_: O.ct_pg(oden64, v, t(y0).double(), V, radon.opnorm, s_, t_),
+                           [x0, a["sigma_d"], a["tau"]], wts[:, :1], torch.float64)
+    _, gp32 = oracle_grads(lambda v, s_, t_: O.ct_pg(oden32, v, t(y0), V, radon.opnorm, s_, t_),
+                           [x0, a["sigma_d"], a["tau"]], wts[:, :1], torch.float32)
+    (out * g(wts[:, :1])).sum().backward()
+    _check(["variables", "sigma_d", "tau"], [l.grad for l in leaves], gp64, gp32)
+
+
+def test_env_forward_trains_through_the_solver(den, oden64):
+    """PnPEnv.forward (tfpnp/env/base.py:193-206): delta-PSNR reward differentiated wrt policy-like actions."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.env import PnPEnv
+    from tfpnp_amd.tasks import csmri
+    B, H, W = 2, 32, 32
+    d = synth.make_csmri_batch(B, H, W, seed=95)
+    sol = csmri.ADMMSolver_CSMRI(den)
+    env = PnPEnv(sol, max_episode_step=6)
+    state = env.reset({k: g(v) for k, v in d.items() if isinstance(v, np.ndarray)})
+    raw0 = np.random.RandomState(96).standard_normal((B, 10)).astype(np.float32)
+
+    def act(raw):
+        return {"sigma_d": torch.sigmoid(raw[:, :5]) * 70 / 255, "mu": torch.sigmoid(raw[:, 5:])}
+
+    raw = g(raw0, True)
+    _, reward = env.forward(state, act(raw))
+    assert reward.shape == (B, 1)
+    reward.sum().backward()
+    # oracle: same computation in fp64 on the CPU
+    r64 = t(raw0).double().requires_grad_(True)
+    a64 = act(r64)
+    v0 = O.admm_reset(t(d["x0"]).double())
+    st = O.csmri_admm(oden64, v0, t(d["y0"]).double(), t(d["mask"]), a64["sigma_d"], a64["mu"])
+    out2 = O.complex2real(st[:, 0:1]) if st.dim() == 5 else st[:, 0:1]
+    rew64 = O.torch_psnr(out2, t(d["gt"]).double()) - O.torch_psnr(t(d["output"]).double(), t(d["gt"]).double())
+    rew64.sum().backward()
+    assert rel(reward, rew64) < 1e-4
+    print(f"  env.forward d reward / d policy logits: {rel(raw.grad, r64.grad):.2e}")
+    assert rel(raw.grad, r64.grad) < 2e-3

@@ -93,7 +93,8 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   if (ctx->weights.p) (void)hipFree(ctx->weights.p);
-  if (ctx->arena.p) (void)hipFree(ctx->arena.p);
+  for (pnpx::UNetArena* a : {&ctx->arena, &ctx->arena_f32, &ctx->arena_grad})
+    if (a->buf.p) (void)hipFree(a->buf.p);
   if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
   for (auto& t : ctx->twiddle)
     if (t.second) (void)hipFree(t.second);
@@ -122,7 +123,9 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
 }
 
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
-  return ctx ? ctx->weights.bytes + ctx->arena.bytes + ctx->scratch.bytes : 0;
+  return ctx ? ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_f32.buf.bytes + ctx->arena_grad.buf.bytes +
+                   ctx->scratch.bytes
+             : 0;
 }
 
 size_t pnpx_unet_num_params(void) {
@@ -181,6 +184,22 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
     ctx->conv_hs[i].mt = mt;
     ctx->conv_hs[i].inv_scale = 1.0f / (hscale[i] * HS_ASCALE);
   }
+  // adjoint (input-gradient) convolutions for the backward pass: transposed, tap-flipped, fp32 kernel family
+  size_t toff[27];
+  for (int i = 0; i < 27; ++i) {
+    const int cout_pad = (L[i].cin + 31) / 32 * 32;            // adjoint output channels = forward input channels
+    const int mt = (cout_pad % 64 == 0) ? 64 : 32;
+    align();
+    toff[i] = host.size();
+    host.resize(host.size() + (size_t)cout_pad * L[i].cout * 9);
+    const float* wsrc = params_host;
+    for (int k = 0; k < i; ++k) wsrc += (size_t)L[k].cin * L[k].cout * 9 + L[k].cout;
+    pack_conv_weights_transposed(wsrc, L[i].cout, L[i].cin, cout_pad, mt, 8, host.data() + toff[i]);
+    ctx->conv_bwd[i].cin = L[i].cout;
+    ctx->conv_bwd[i].cout = cout_pad;
+    ctx->conv_bwd[i].mt = mt;
+    ctx->conv_bwd[i].cc = 8;
+  }
   align();
   const size_t ow = host.size();
   host.insert(host.end(), src, src + 32);
@@ -205,6 +224,8 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
     ctx->conv[i].w = d + woff[i];
     ctx->conv[i].b = d + boff[i];
     ctx->conv_hs[i].w = reinterpret_cast<char*>(d + hoff[i]);
+    ctx->conv_bwd[i].w = d + toff[i];
+    ctx->conv_bwd[i].b = nullptr;
   }
   ctx->outc_w = d + ow;
   ctx->outc_b = d + ob;
@@ -222,6 +243,16 @@ int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* 
     return PNPX_ERR_ARG;
   }
   return unet_denoise(ctx, x, sigma, 1, out, out_preclamp, B, H, W, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int pnpx_unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, const float* grad_out, float* grad_x,
+                               float* grad_sigma, int B, int H, int W, void* stream) {
+  LOCK_CTX(ctx);
+  if (!x || !sigma || !grad_out || !grad_x || !grad_sigma) {
+    set_error("pnpx_unet_denoise_backward: null pointer");
+    return PNPX_ERR_ARG;
+  }
+  return unet_denoise_backward(ctx, x, sigma, 1, grad_out, grad_x, grad_sigma, B, H, W, static_cast<hipStream_t>(stream));
 }
 
 int pnpx_unet_profile(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, int B, int H, int W,

@@ -59,6 +59,11 @@ struct DeviceBuf {
   size_t bytes = 0;
 };
 
+struct UNetArena {
+  DeviceBuf buf;
+  int capB = 0, capH = 0, capW = 0, mode = -1;
+};
+
 struct ConvLayerHsDev {     // the same conv packed for the half-split f16 kernel (conv_hs.hip)
   int cin = 0, cout = 0, cin_pad = 0, mt = 0;
   char* w = nullptr;        // device: [cout/mt][cin_pad/16][9][hi,lo][2][mt][8] f16
@@ -77,13 +82,14 @@ struct pnpx_ctx {
   pnpx::ConvLayer conv[27];
   pnpx::ConvLayerHsDev conv_hs[27];
   int conv_mode = pnpx::CONV_HS;   // which conv kernel family the denoiser runs (pnpx_ctx_set_option)
-  int arena_mode = -1;             // layout the arena was zero-initialised for
+  pnpx::ConvLayer conv_bwd[27];    // adjoint (input-gradient) convolutions, fp32 kernel family
   float* outc_w = nullptr;   // [32]
   float* outc_b = nullptr;   // [1]
   pnpx::DeviceBuf weights;   // single allocation holding all of the above
-  // --- UNet activation arena (capacity capB images of capH x capW)
-  pnpx::DeviceBuf arena;
-  int capB = 0, capH = 0, capW = 0;
+  // --- UNet activation arenas (capacity capB images of capH x capW, zero borders valid for one layout `mode`):
+  //     arena = forward pass in the ctx's conv_mode; arena_f32 = fp32 re-computation inside the backward pass;
+  //     arena_grad = gradients of every activation (fp32 planar)
+  pnpx::UNetArena arena, arena_f32, arena_grad;
   // --- solver scratch (complex fields etc.), grown on demand
   pnpx::DeviceBuf scratch;
   // --- FFT twiddle tables e^{-2 pi i m / N}, one per transform length: device float2[N]
@@ -94,7 +100,8 @@ struct pnpx_ctx {
 
 namespace pnpx {
 
-int ctx_reserve_unet(pnpx_ctx* ctx, int B, int H, int W);
+int ctx_reserve_unet(pnpx_ctx* ctx, int B, int H, int W);   // main arena, ctx->conv_mode
+int reserve_arena(pnpx_ctx* ctx, UNetArena& ar, int mode, int B, int H, int W, size_t extra_bytes);
 int ctx_scratch(pnpx_ctx* ctx, size_t bytes, void** out);
 int ctx_twiddle(pnpx_ctx* ctx, int N, const float2** out);
 
@@ -108,7 +115,10 @@ struct ProfileSink {      // optional per-launch event recording for pnpx_unet_p
 // Denoiser forward on padded input already resident in the arena is internal; these are the pieces the
 // solver loops call.  x/sigma/out are unpadded [B,1,H,W] / [B] tensors (C-ABI layout).
 int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
-                 int B, int H, int W, hipStream_t s, ProfileSink* prof);
+                 int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena = nullptr, int mode = -1);
+// VJP of the denoiser wrt x and sigma (unet_bwd.hip): recomputes the forward pass in fp32 and back-propagates.
+int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out,
+                          float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s);
 
 // FFT building blocks (fft.hip)
 int fft2(pnpx_ctx* ctx, const float* in, float* out, int n_img, int H, int W, bool inverse, bool centered,

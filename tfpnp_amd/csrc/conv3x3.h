@@ -14,6 +14,11 @@ struct ConvArgs {
   int H, W, Hp, Wp;
   int tilesX, tilesY, nct;
   float slope;       // LeakyReLU negative slope
+  // epilogue mode: 0 = bias + LeakyReLU (forward); 1 = raw accumulator (no bias, no activation);
+  // 2 = raw accumulator x LeakyReLU'(dmask) -- the input-gradient convolution of the backward pass, where dmask is
+  // the saved forward activation that this gradient flows into (same [B][Cout][Hp][Wp] geometry as `out`)
+  int mode;
+  const float* dmask;
 };
 
 int conv_pack_mt(int cout);
@@ -21,5 +26,11 @@ int conv_pack_cc(int cin);
 void pack_conv_weights(const float* w, int cout, int cin, int mt, int cc, float* dst);
 int launch_conv3x3(const ConvLayer& L, const float* in0, int C0, const float* in1, int C1, float* out, int B,
                    int H, int W, hipStream_t s);
+// Input-gradient convolution: L holds the transposed, tap-flipped weights (pack_conv_weights_transposed).
+int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const float* dmask, int B, int H, int W,
+                        hipStream_t s);
+// w[cout][cin][3][3] -> packed weights of the adjoint convolution: wt[ci][co][tap] = w[co][ci][8 - tap], with the
+// adjoint's output channels (= cin) zero-padded to cout_pad.
+void pack_conv_weights_transposed(const float* w, int cout, int cin, int cout_pad, int mt, int cc, float* dst);
 
 }  // namespace pnpx

@@ -172,18 +172,22 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   for (int m = 0; m < G::MTB; ++m) {
     float bias[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bias[r] = a.bias[ct * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf];
+    for (int r = 0; r < 16; ++r)
+      bias[r] = a.mode == 0 ? a.bias[ct * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf] : 0.f;
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
       const int y = y0 + (wave * NBW + n) * G::MBH + py;
       const int x = x0 + px;
       if (y < a.H && x < a.W) {
-        float* o = a.out + (((size_t)b * Cout + ct * MT + m * 32 + 4 * khalf) * a.Hp + (y + 1)) * a.Wp + x + PADL;
+        const size_t off = (((size_t)b * Cout + ct * MT + m * 32 + 4 * khalf) * a.Hp + (y + 1)) * a.Wp + x + PADL;
+        float* o = a.out + off;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          const size_t ro = (size_t)((r & 3) + 8 * (r >> 2)) * HpWp;
           float v = acc[m][n][r] + bias[r];
-          v = v > 0.f ? v : v * a.slope;
-          o[(size_t)((r & 3) + 8 * (r >> 2)) * HpWp] = v;
+          if (a.mode == 0) v = v > 0.f ? v : v * a.slope;
+          else if (a.mode == 2) v = a.dmask[off + ro] > 0.f ? v : v * a.slope;
+          o[ro] = v;
         }
       }
     }
@@ -240,11 +244,54 @@ int launch_conv3x3(const ConvLayer& L, const float* in0, int C0, const float* in
   a.Wp = padded_w(W);
   a.nct = L.cout / L.mt;
   a.slope = 0.2f;
+  a.mode = 0;
+  a.dmask = nullptr;
   if (L.mt == 64 && L.cc == 8) return launch_mt_cc<64, 8>(a, B, s);
   if (L.mt == 32 && L.cc == 8) return launch_mt_cc<32, 8>(a, B, s);
   if (L.mt == 32 && L.cc == 2) return launch_mt_cc<32, 2>(a, B, s);
   set_error("conv3x3: no kernel for mt=%d cc=%d", L.mt, L.cc);
   return PNPX_ERR_SHAPE;
+}
+
+int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const float* dmask, int B, int H, int W,
+                        hipStream_t s) {
+  ConvArgs a;
+  a.in0 = gin;
+  a.C0 = L.cin;
+  a.in1 = gin;
+  a.C1 = 0;
+  a.wpk = L.w;
+  a.bias = nullptr;
+  a.out = gout;
+  a.H = H;
+  a.W = W;
+  a.Hp = padded_h(H);
+  a.Wp = padded_w(W);
+  a.nct = L.cout / L.mt;
+  a.slope = 0.2f;
+  a.mode = dmask ? 2 : 1;
+  a.dmask = dmask;
+  if (L.cc != 8 || L.cin % 8 != 0 || L.cout % L.mt != 0) {
+    set_error("conv3x3_grad: unsupported packing (cin %d cout %d mt %d cc %d)", L.cin, L.cout, L.mt, L.cc);
+    return PNPX_ERR_SHAPE;
+  }
+  if (L.mt == 64) return launch_mt_cc<64, 8>(a, B, s);
+  return launch_mt_cc<32, 8>(a, B, s);
+}
+
+void pack_conv_weights_transposed(const float* w, int cout, int cin, int cout_pad, int mt, int cc, float* dst) {
+  // adjoint conv: input channels = cout (forward outputs), output channels = cin (padded to cout_pad)
+  const int nct = cout_pad / mt, nch = cout / cc;
+  for (int ct = 0; ct < nct; ++ct)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int c = 0; c < cc; ++c)
+          for (int m = 0; m < mt; ++m) {
+            const int ci = ct * mt + m;      // forward input channel = adjoint output channel
+            const int co = ch * cc + c;      // forward output channel = adjoint input channel
+            const float v = (ci < cin) ? w[((size_t)co * cin + ci) * 9 + (8 - tap)] : 0.f;
+            dst[((((size_t)ct * nch + ch) * 9 + tap) * cc + c) * mt + m] = v;
+          }
 }
 
 // Host-side repack: w[cout][cin][3][3] -> [cout/mt][cin/cc][tap][cc][mt]

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "conv3x3.h"
 #include "conv_hs.h"
+#include "unet_plan.h"
 
 namespace pnpx {
 
@@ -197,83 +198,37 @@ __global__ __launch_bounds__(256) void outc_residual_hs_kernel(const HsRec* __re
   out[i] = fminf(fmaxf(r, 0.f), 1.f);
 }
 
-// ----------------------------------------------------------------------------------------- arena plan
-struct Act {              // one activation tensor in the arena
-  size_t off = 0;         // byte offset
-  int C = 0, H = 0, W = 0;
-};
-struct UNetPlan {
-  // per level l (resolution H>>l, W>>l, channels 32<<l)
-  Act in0;                // network input (2 channels; 16 in HS mode, the upper 14 zero) @ level 0
-  Act a[5], b[5];         // ConvBlock temporaries
-  Act x[5];               // encoder outputs x1..x5 (skips)
-  Act p[5];               // pooled inputs of level l (l >= 1): channels 16<<l
-  Act u[4];               // upsampled decoder inputs at level l (l <= 3): channels 64<<l
-  Act y[4];               // decoder outputs at level l (l <= 3)
-  size_t total = 0;       // bytes, for capB images
-};
-
-static size_t act_bytes_per_image(int mode, int C, int h, int w) {
-  if (mode == CONV_HS) return (size_t)((C + 7) / 8) * (h + 2) * (w + 2) * 32;
-  return (size_t)C * padded_h(h) * padded_w(w) * sizeof(float);
-}
-
-static UNetPlan make_plan(int mode, int capB, int H, int W) {
-  UNetPlan P;
-  size_t off = 0;
-  auto add = [&](Act& d, int C, int h, int w) {
-    d.off = off;
-    d.C = C;
-    d.H = h;
-    d.W = w;
-    off += act_bytes_per_image(mode, C, h, w) * (size_t)capB;
-    off = (off + 255) & ~(size_t)255;
-  };
-  add(P.in0, mode == CONV_HS ? 16 : 2, H, W);
-  for (int l = 0; l < 5; ++l) {
-    const int h = H >> l, w = W >> l, c = 32 << l;
-    add(P.a[l], c, h, w);
-    add(P.b[l], c, h, w);
-    add(P.x[l], c, h, w);
-    if (l >= 1) add(P.p[l], c / 2, h, w);
-    if (l <= 3) {
-      add(P.u[l], 2 * c, h, w);
-      add(P.y[l], c, h, w);
+int reserve_arena(pnpx_ctx* ctx, UNetArena& ar, int mode, int B, int H, int W, size_t extra_bytes) {
+  if (B <= ar.capB && H == ar.capH && W == ar.capW && mode == ar.mode) return PNPX_OK;
+  const bool same_geom = (H == ar.capH && W == ar.capW);
+  const int nb = same_geom ? (B > ar.capB ? B : ar.capB) : B;
+  UNetPlan P = make_plan(mode, nb, H, W);
+  const size_t total = P.total + extra_bytes * (size_t)nb;
+  PNPX_HIP(hipSetDevice(ctx->device));
+  PNPX_HIP(hipDeviceSynchronize());
+  if (ar.buf.bytes < total) {
+    if (ar.buf.p) PNPX_HIP(hipFree(ar.buf.p));
+    ar = UNetArena();
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, total);
+    if (e != hipSuccess) {
+      set_error("arena allocation of %zu bytes failed: %s", total, hipGetErrorString(e));
+      return PNPX_ERR_ALLOC;
     }
+    ar.buf.p = p;
+    ar.buf.bytes = total;
   }
-  P.total = off + (1u << 20);  // 1 MiB slack: overhanging tiles read (never write) past their tensor
-  return P;
+  PNPX_HIP(hipMemset(ar.buf.p, 0, total));  // borders stay zero until the layout changes
+  PNPX_HIP(hipDeviceSynchronize());
+  ar.capB = nb;
+  ar.capH = H;
+  ar.capW = W;
+  ar.mode = mode;
+  return PNPX_OK;
 }
 
 int ctx_reserve_unet(pnpx_ctx* ctx, int B, int H, int W) {
-  const int mode = ctx->conv_mode;
-  if (B <= ctx->capB && H == ctx->capH && W == ctx->capW && mode == ctx->arena_mode) return PNPX_OK;
-  const bool same_geom = (H == ctx->capH && W == ctx->capW);
-  const int nb = same_geom ? (B > ctx->capB ? B : ctx->capB) : B;
-  UNetPlan P = make_plan(mode, nb, H, W);
-  PNPX_HIP(hipSetDevice(ctx->device));
-  PNPX_HIP(hipDeviceSynchronize());
-  if (ctx->arena.bytes < P.total) {
-    if (ctx->arena.p) PNPX_HIP(hipFree(ctx->arena.p));
-    ctx->arena = DeviceBuf();
-    ctx->capB = ctx->capH = ctx->capW = 0;
-    ctx->arena_mode = -1;
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, P.total);
-    if (e != hipSuccess) {
-      set_error("arena allocation of %zu bytes failed: %s", P.total, hipGetErrorString(e));
-      return PNPX_ERR_ALLOC;
-    }
-    ctx->arena.p = p;
-    ctx->arena.bytes = P.total;
-  }
-  PNPX_HIP(hipMemset(ctx->arena.p, 0, P.total));  // borders stay zero until the layout changes
-  PNPX_HIP(hipDeviceSynchronize());
-  ctx->capB = nb;
-  ctx->capH = H;
-  ctx->capW = W;
-  ctx->arena_mode = mode;
-  return PNPX_OK;
+  return reserve_arena(ctx, ctx->arena, ctx->conv_mode, B, H, W, 0);
 }
 
 // ----------------------------------------------------------------------------------------- forward
@@ -302,9 +257,10 @@ inline dim3 g1d(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 // that at level 1; 0 = whole batch).  Measured (tools/time_denoiser.py, B=48, 256^2): 6.58 ms whole batch, 6.38 ms
 // at 24, worse below 12 (launch count, thinner grids) -- the Infinity Cache does not turn these layers around, the
 // gain is small; 24 is the default.  Deeper levels always run the whole batch.
-static int unet_forward_hs(pnpx_ctx* ctx, const UNetPlan& P, const float* x, const float* sigma, int sigma_stride,
-                           float* out, float* out_pre, int B, int H, int W, hipStream_t s, Recorder& rec) {
-  char* A = static_cast<char*>(ctx->arena.p);
+static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, const float* x, const float* sigma,
+                           int sigma_stride, float* out, float* out_pre, int B, int H, int W, hipStream_t s,
+                           Recorder& rec) {
+  char* A = static_cast<char*>(ar.buf.p);
   auto bpi = [&](const Act& d) { return act_bytes_per_image(CONV_HS, d.C, d.H, d.W); };
   auto at = [&](const Act& d, int b0) { return A + d.off + (size_t)b0 * bpi(d); };
   auto rat = [&](const Act& d, int b0) { return reinterpret_cast<HsRec*>(at(d, b0)); };
@@ -346,13 +302,15 @@ static int unet_forward_hs(pnpx_ctx* ctx, const UNetPlan& P, const float* x, con
   };
   auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o, int b0, int nb,
                    const ConvHsFuse& fuse) -> int {
+    const Act& ta = i1 ? P.da[lvl] : P.a[lvl];   // decoder blocks (two sources) have their own temporaries
+    const Act& tb = i1 ? P.db[lvl] : P.b[lvl];
     ConvHsFuse f0;
     f0.up_in1 = fuse.up_in1;
-    PNPX_TRY(conv(li, i0, i1, P.a[lvl], b0, nb, f0));
-    PNPX_TRY(conv(li + 1, P.a[lvl], nullptr, P.b[lvl], b0, nb, ConvHsFuse()));
+    PNPX_TRY(conv(li, i0, i1, ta, b0, nb, f0));
+    PNPX_TRY(conv(li + 1, ta, nullptr, tb, b0, nb, ConvHsFuse()));
     ConvHsFuse f2 = fuse;
     f2.up_in1 = false;
-    return conv(li + 2, P.b[lvl], nullptr, o, b0, nb, f2);
+    return conv(li + 2, tb, nullptr, o, b0, nb, f2);
   };
 
   // encoder: the last conv of a block also writes the 2x2 max-pooled tensor (fused epilogue) when the level is wide
@@ -415,7 +373,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, const UNetPlan& P, const float* x, con
 }
 
 int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
-                 int B, int H, int W, hipStream_t s, ProfileSink* prof) {
+                 int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena, int mode) {
   if (!ctx->has_weights) {
     set_error("denoiser called before pnpx_unet_load");
     return PNPX_ERR_NO_WEIGHTS;
@@ -424,16 +382,17 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     set_error("denoiser: need B > 0 and H, W >= 16 (four 2x2 poolings; got B=%d H=%d W=%d)", B, H, W);
     return PNPX_ERR_SHAPE;
   }
-  PNPX_TRY(ctx_reserve_unet(ctx, B, H, W));
-  const int mode = ctx->conv_mode;
+  UNetArena& ar = arena ? *arena : ctx->arena;
+  if (mode < 0) mode = ctx->conv_mode;
+  PNPX_TRY(reserve_arena(ctx, ar, mode, B, H, W, 0));
   const bool hs = (mode == CONV_HS);
-  const UNetPlan P = make_plan(mode, ctx->capB, H, W);
+  const UNetPlan P = make_plan(mode, ar.capB, H, W);
   Recorder rec{prof, s};
   if (prof) PNPX_HIP(hipEventRecord((*prof->events)[0], s));
-  if (hs) return unet_forward_hs(ctx, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec);
+  if (hs) return unet_forward_hs(ctx, ar, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec);
 
   // ---- plain-fp32 path (conv_mode 0): padded planar fp32 activations, whole batch per launch
-  char* A = static_cast<char*>(ctx->arena.p);
+  char* A = static_cast<char*>(ar.buf.p);
   auto fptr = [&](const Act& d) { return reinterpret_cast<float*>(A + d.off); };
   hipLaunchKernelGGL(prep_input_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, x, sigma, sigma_stride, fptr(P.in0), H,
                      W, padded_h(H), padded_w(W));
@@ -445,9 +404,11 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);
   };
   auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o) -> int {
-    PNPX_TRY(conv(li, i0, i1, P.a[lvl]));
-    PNPX_TRY(conv(li + 1, P.a[lvl], nullptr, P.b[lvl]));
-    return conv(li + 2, P.b[lvl], nullptr, o);
+    const Act& ta = i1 ? P.da[lvl] : P.a[lvl];
+    const Act& tb = i1 ? P.db[lvl] : P.b[lvl];
+    PNPX_TRY(conv(li, i0, i1, ta));
+    PNPX_TRY(conv(li + 1, ta, nullptr, tb));
+    return conv(li + 2, tb, nullptr, o);
   };
   PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0]));
   for (int l = 1; l < 5; ++l) {

@@ -1,0 +1,304 @@
+// Vector-Jacobian product of the UNet denoiser wrt its input image and its noise level.
+//
+// the reference trains its policy THROUGH the solver (PnPEnv.forward under autograd,
+// tfpnp/env/base.py:193-206, called from tfpnp/trainer/mddpg/trainer.py:171-192): gradients of the reward flow
+// through UNetDenoiser2D.forward (tfpnp/pnp/denoiser/base.py:23-32; weights frozen) into sigma_d and into the
+// image argument.  This file is that backward pass:
+//     (gx, gsigma) = J^T g,   out = clamp(in[:, :1] + UNet(cat[x, sigma*1]), 0, 1)
+// Strategy: gradient checkpointing per call -- the forward pass is RE-COMPUTED here in exact fp32 (conv3x3.hip, its
+// own arena) and then back-propagated layer by layer, so nothing has to be kept alive between the forward and the
+// backward of the autograd graph.  Gradients are fp32 planar tensors in a third arena with the same zero-border
+// layout, so every input-gradient convolution is the SAME MFMA kernel run on transposed, tap-flipped weights
+// (pack_conv_weights_transposed) with the LeakyReLU derivative of the saved activation fused in its epilogue.
+#include "common.h"
+#include "conv3x3.h"
+#include "unet_plan.h"
+
+namespace pnpx {
+namespace {
+
+inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+__device__ __forceinline__ float dlrelu(float a) { return a > 0.f ? 1.f : 0.2f; }
+
+// d/d(feat) of  out = clamp(x + sum_c w[c] feat[c] + b):  g_feat[c] = w[c] * g_out * 1[0 <= pre <= 1] * lrelu'(feat[c])
+// (feat = y[0], the last conv's activation; the result is the gradient wrt that conv's PRE-activation).
+// Also emits g_res = g_out * 1[0 <= pre <= 1], the gradient reaching the residual path in[:, :1].
+__global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ pre,
+                                                       const float* __restrict__ w, const float* __restrict__ feat,
+                                                       float* __restrict__ g_feat, float* __restrict__ g_res, int H,
+                                                       int W, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W);
+  const size_t t = i / W;
+  const int y = (int)(t % H);
+  const size_t b = t / H;
+  const float p = pre[i];
+  const float g = (p >= 0.f && p <= 1.f) ? g_out[i] : 0.f;   // torch.clamp's backward mask is inclusive (min <= x <= max)
+  g_res[i] = g;
+  const int Hp = padded_h(H), Wp = padded_w(W);
+  const size_t o = b * 32 * (size_t)Hp * Wp + (size_t)(y + 1) * Wp + x + PADL;
+#pragma unroll 4
+  for (int c = 0; c < 32; ++c) {
+    const size_t oc = o + (size_t)c * Hp * Wp;
+    g_feat[oc] = w[c] * g * dlrelu(feat[oc]);
+  }
+}
+
+// Adjoint of bilinear x2 (align_corners) restricted to the channel range [c_off, c_off + C) of the concat gradient,
+// as a gather: every source pixel sums the destination pixels that interpolate from it; then x lrelu'(saved source).
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ gcat, int Ccat, int c_off,
+                                                           const float* __restrict__ src_act, float* __restrict__ g_src,
+                                                           int C, int h, int w, int Ht, int Wt, float sy, float sx,
+                                                           size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int xs = (int)(i % w);
+  size_t t = i / w;
+  const int ys = (int)(t % h);
+  t /= h;
+  const int c = (int)(t % C);
+  const size_t b = t / C;
+  const int H = 2 * h, W = 2 * w;
+  const int Hp = padded_h(Ht), Wp = padded_w(Wt), hp = padded_h(h), wp = padded_w(w);
+  const float* g = gcat + (b * Ccat + c_off + c) * (size_t)Hp * Wp;
+  // candidate destination rows/cols: those whose floor(s*dst) is ys-1 or ys  (s ~ 0.5 => at most 5 candidates)
+  const int ylo = max(0, 2 * ys - 3), yhi = min(H - 1, 2 * ys + 3);
+  const int xlo = max(0, 2 * xs - 3), xhi = min(W - 1, 2 * xs + 3);
+  float acc = 0.f;
+  for (int yd = ylo; yd <= yhi; ++yd) {
+    const float fy = sy * yd;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = fy - y0;
+    float wy = 0.f;
+    if (y0 == ys) wy += 1.f - ly;
+    if (y1 == ys) wy += ly;
+    if (wy == 0.f) continue;
+    for (int xd = xlo; xd <= xhi; ++xd) {
+      const float fx = sx * xd;
+      const int x0 = (int)fx;
+      const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float lx = fx - x0;
+      float wx = 0.f;
+      if (x0 == xs) wx += 1.f - lx;
+      if (x1 == xs) wx += lx;
+      if (wx != 0.f) acc += wy * wx * g[(size_t)(yd + 1) * Wp + xd + PADL];
+    }
+  }
+  const size_t o = (b * C + c) * (size_t)hp * wp + (size_t)(ys + 1) * wp + xs + PADL;
+  g_src[o] = acc * dlrelu(src_act[o]);
+}
+
+// Gradient reaching an encoder output x[l] (H x W, C channels): the skip part of the decoder's concat gradient
+// (channels [0, C) of gcat) plus, for l < 4, the max-pool routing of g_pool (first maximum in scan order, like ATen),
+// all times lrelu'(x[l]).
+__global__ __launch_bounds__(256) void skip_pool_merge_kernel(const float* __restrict__ gcat, int Ccat,
+                                                              const float* __restrict__ g_pool,
+                                                              const float* __restrict__ xact, float* __restrict__ g_x,
+                                                              int C, int H, int W, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W);
+  size_t t = i / W;
+  const int y = (int)(t % H);
+  t /= H;
+  const int c = (int)(t % C);
+  const size_t b = t / C;
+  const int Hp = padded_h(H), Wp = padded_w(W);
+  const size_t plane = (size_t)Hp * Wp;
+  const size_t o = (b * C + c) * plane + (size_t)(y + 1) * Wp + x + PADL;
+  float g = gcat ? gcat[(b * Ccat + c) * plane + (size_t)(y + 1) * Wp + x + PADL] : 0.f;
+  if (g_pool) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int yo = y >> 1, xo = x >> 1;
+    if (yo < Ho && xo < Wo) {
+      const float* a = xact + (b * C + c) * plane + (size_t)(2 * yo + 1) * Wp + 2 * xo + PADL;
+      const float v00 = a[0], v01 = a[1], v10 = a[Wp], v11 = a[Wp + 1];
+      int arg = 0;
+      float m = v00;
+      if (v01 > m) { m = v01; arg = 1; }
+      if (v10 > m) { m = v10; arg = 2; }
+      if (v11 > m) { m = v11; arg = 3; }
+      if (arg == ((y & 1) * 2 + (x & 1))) {
+        const int Hpo = padded_h(Ho), Wpo = padded_w(Wo);
+        g += g_pool[(b * C + c) * (size_t)Hpo * Wpo + (size_t)(yo + 1) * Wpo + xo + PADL];
+      }
+    }
+  }
+  g_x[o] = g * dlrelu(xact[o]);
+}
+
+// gx = g_in0[:, 0] + g_res;  gsigma[b] = sum over pixels of g_in0[:, 1]   (two-stage, deterministic)
+constexpr int SIG_CHUNKS = 64;
+__global__ __launch_bounds__(256) void input_grad_kernel(const float* __restrict__ g_in0, int Cg,
+                                                         const float* __restrict__ g_res, float* __restrict__ gx,
+                                                         float* __restrict__ part, int H, int W) {
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int n = H * W, per = (n + SIG_CHUNKS - 1) / SIG_CHUNKS;
+  const int lo = chunk * per, hi = min(n, lo + per);
+  const int Hp = padded_h(H), Wp = padded_w(W);
+  const float* g0 = g_in0 + (size_t)b * Cg * Hp * Wp;
+  const float* g1c = g0 + (size_t)Hp * Wp;
+  float acc = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const int y = i / W, x = i - y * W;
+    const size_t o = (size_t)(y + 1) * Wp + x + PADL;
+    gx[(size_t)b * n + i] = g0[o] + g_res[(size_t)b * n + i];
+    acc += g1c[o];
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ float w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[b * SIG_CHUNKS + chunk] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+__global__ void sigma_grad_final_kernel(const float* __restrict__ part, float* __restrict__ gsigma, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int c = 0; c < SIG_CHUNKS; ++c) s += part[b * SIG_CHUNKS + c];
+  gsigma[b] = s;
+}
+
+// gradient arena: one tensor per forward activation + the concat gradients of the four decoder blocks
+struct GradPlan {
+  Act in0;        // 32 channels (the adjoint of the first conv is padded from 2 to 32 output channels)
+  Act a[5], b[5], x[5], p[5], y[4], cat[4];
+  size_t total = 0;
+};
+GradPlan make_grad_plan(int capB, int H, int W) {
+  GradPlan P;
+  size_t off = 0;
+  auto add = [&](Act& d, int C, int h, int w) {
+    d.off = off;
+    d.C = C;
+    d.H = h;
+    d.W = w;
+    off += act_bytes_per_image(CONV_F32, C, h, w) * (size_t)capB;
+    off = (off + 255) & ~(size_t)255;
+  };
+  add(P.in0, 32, H, W);
+  for (int l = 0; l < 5; ++l) {
+    const int h = H >> l, w = W >> l, c = 32 << l;
+    add(P.a[l], c, h, w);
+    add(P.b[l], c, h, w);
+    add(P.x[l], c, h, w);
+    if (l >= 1) add(P.p[l], c / 2, h, w);
+    if (l <= 3) {
+      add(P.y[l], c, h, w);
+      add(P.cat[l], 3 * c, h, w);
+    }
+  }
+  P.total = off + (1u << 20);
+  return P;
+}
+
+}  // namespace
+
+int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out,
+                          float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s) {
+  if (!ctx->has_weights) {
+    set_error("denoiser backward called before pnpx_unet_load");
+    return PNPX_ERR_NO_WEIGHTS;
+  }
+  if (B <= 0 || H < 16 || W < 16) {
+    set_error("denoiser backward: need B > 0 and H, W >= 16");
+    return PNPX_ERR_SHAPE;
+  }
+  const size_t npix = (size_t)B * H * W;
+  // scratch: recomputed clamped output (unused), pre-clamp output, residual gradient, sigma partials
+  void* sp;
+  PNPX_TRY(ctx_scratch(ctx, (3 * npix + (size_t)B * SIG_CHUNKS) * sizeof(float) + 4096, &sp));
+  float* out_tmp = static_cast<float*>(sp);
+  float* pre = out_tmp + npix;
+  float* g_res = pre + npix;
+  float* part = g_res + npix;
+
+  // 1. recompute the forward pass in exact fp32 into its own arena (activations stay there for the masks)
+  PNPX_TRY(unet_denoise(ctx, x, sigma, sigma_stride, out_tmp, pre, B, H, W, s, nullptr, &ctx->arena_f32, CONV_F32));
+  const UNetPlan F = make_plan(CONV_F32, ctx->arena_f32.capB, H, W);
+  char* FA = static_cast<char*>(ctx->arena_f32.buf.p);
+  auto fact = [&](const Act& d) { return reinterpret_cast<const float*>(FA + d.off); };
+
+  // 2. gradient arena (zero borders: gradients are convolution INPUTS of the adjoint convs)
+  {
+    UNetArena& ga = ctx->arena_grad;
+    if (!(B <= ga.capB && H == ga.capH && W == ga.capW)) {
+      const bool same = (H == ga.capH && W == ga.capW);
+      const int nb = same ? (B > ga.capB ? B : ga.capB) : B;
+      const GradPlan GP = make_grad_plan(nb, H, W);
+      PNPX_HIP(hipDeviceSynchronize());
+      if (ga.buf.bytes < GP.total) {
+        if (ga.buf.p) PNPX_HIP(hipFree(ga.buf.p));
+        ga = UNetArena();
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, GP.total);
+        if (e != hipSuccess) {
+          set_error("gradient arena allocation of %zu bytes failed: %s", GP.total, hipGetErrorString(e));
+          return PNPX_ERR_ALLOC;
+        }
+        ga.buf.p = p;
+        ga.buf.bytes = GP.total;
+      }
+      PNPX_HIP(hipMemset(ga.buf.p, 0, GP.total));
+      PNPX_HIP(hipDeviceSynchronize());
+      ga.capB = nb;
+      ga.capH = H;
+      ga.capW = W;
+      ga.mode = CONV_F32;
+    }
+  }
+  const GradPlan G = make_grad_plan(ctx->arena_grad.capB, H, W);
+  char* GA = static_cast<char*>(ctx->arena_grad.buf.p);
+  auto gptr = [&](const Act& d) { return reinterpret_cast<float*>(GA + d.off); };
+
+  // 3. tail: clamp + residual + 1x1 out-conv -> gradient wrt the pre-activation of the last conv (y[0])
+  hipLaunchKernelGGL(outc_bwd_kernel, g1(npix), dim3(256), 0, s, grad_out, pre, ctx->outc_w, fact(F.y[0]), gptr(G.y[0]),
+                     g_res, H, W, npix);
+  PNPX_LAUNCH_CHECK();
+
+  auto convT = [&](int li, const Act& gin, const Act& gout, const float* dmask) -> int {
+    return launch_conv3x3_grad(ctx->conv_bwd[li], gptr(gin), gptr(gout), dmask, B, gout.H, gout.W, s);
+  };
+
+  // 4. decoder blocks, top (level 0) to bottom (level 3)
+  for (int l = 0; l <= 3; ++l) {
+    const int li = 15 + 3 * (3 - l);
+    PNPX_TRY(convT(li + 2, G.y[l], G.b[l], fact(F.db[l])));  // through conv2, x lrelu'(decoder b)
+    PNPX_TRY(convT(li + 1, G.b[l], G.a[l], fact(F.da[l])));  // through conv1, x lrelu'(decoder a)
+    PNPX_TRY(convT(li, G.a[l], G.cat[l], nullptr));          // through conv0 -> gradient of cat[skip, up]
+    // up part -> through the bilinear upsample -> pre-activation gradient of the tensor below
+    const Act& below_f = (l == 3) ? F.x[4] : F.y[l + 1];
+    const Act& below_g = (l == 3) ? G.x[4] : G.y[l + 1];
+    const int h = below_f.H, w = below_f.W, Cb = below_f.C;
+    const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+    const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+    const size_t n = (size_t)B * Cb * h * w;
+    hipLaunchKernelGGL(upsample_bwd_kernel, g1(n), dim3(256), 0, s, gptr(G.cat[l]), G.cat[l].C, F.x[l].C, fact(below_f),
+                       gptr(below_g), Cb, h, w, G.cat[l].H, G.cat[l].W, sy, sx, n);
+    PNPX_LAUNCH_CHECK();
+  }
+  // 5. encoder blocks, bottom (level 4) to top
+  for (int l = 4; l >= 0; --l) {
+    if (l < 4) {   // gradient reaching x[l]: skip part of the decoder concat + max-pool routing from level l+1
+      const size_t n = (size_t)B * F.x[l].C * F.x[l].H * F.x[l].W;
+      hipLaunchKernelGGL(skip_pool_merge_kernel, g1(n), dim3(256), 0, s, gptr(G.cat[l]), G.cat[l].C, gptr(G.p[l + 1]),
+                         fact(F.x[l]), gptr(G.x[l]), F.x[l].C, F.x[l].H, F.x[l].W, n);
+      PNPX_LAUNCH_CHECK();
+    }
+    PNPX_TRY(convT(3 * l + 2, G.x[l], G.b[l], fact(F.b[l])));
+    PNPX_TRY(convT(3 * l + 1, G.b[l], G.a[l], fact(F.a[l])));
+    PNPX_TRY(convT(3 * l, G.a[l], l == 0 ? G.in0 : G.p[l], nullptr));
+  }
+  // 6. input gradients
+  hipLaunchKernelGGL(input_grad_kernel, dim3(SIG_CHUNKS, B), dim3(256), 0, s, gptr(G.in0), G.in0.C, g_res, grad_x, part, H,
+                     W);
+  PNPX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sigma_grad_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, part, grad_sigma, B);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+
+}  // namespace pnpx

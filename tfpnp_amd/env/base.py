@@ -9,8 +9,30 @@ import torch
 from .. import ops
 
 
+class _Psnr(torch.autograd.Function):
+    """Native PSNR forward; analytic VJP: d psnr_b / d out = -(20 / ln 10) * (clamp(out) - gt) / (N * mse_b) inside (0,1)."""
+
+    @staticmethod
+    def forward(ctx, output, gt):
+        ctx.save_for_backward(output, gt)
+        return ops.psnr(output, gt)
+
+    @staticmethod
+    def backward(ctx, g):
+        output, gt = ctx.saved_tensors
+        B = output.shape[0]
+        o = output.reshape(B, -1)
+        diff = o.clamp(0, 1) - gt.reshape(B, -1)
+        sse = (diff * diff).sum(dim=1, keepdim=True)
+        inside = (o > 0) & (o < 1)
+        go = (-20.0 / 2.302585092994046) * g.reshape(B, 1) * diff / sse * inside
+        return go.view_as(output), None
+
+
 def torch_psnr(output, gt):
     """tfpnp/env/base.py:237-242 -> [B,1]"""
+    if torch.is_grad_enabled() and output.requires_grad:
+        return _Psnr.apply(output, gt)
     return ops.psnr(output, gt)
 
 
@@ -58,8 +80,21 @@ class PnPEnv:
             done = torch.ones_like(idx_stop)
         return reward, all_done, {'done': done}
 
+    def forward(self, state, action):
+        """Differentiable one-step model of the environment used by the actor/critic update
+        (tfpnp/env/base.py:193-206; called from tfpnp/trainer/mddpg/trainer.py:171-192).  `state` is the dict form of
+        the observation (keys 'solver', 'output', 'gt' + the solver's aux inputs; the reference packs the same
+        tensors channel-wise, base.py:208-231); returns (next solver state, delta-PSNR reward [B,1]).  Gradients
+        flow into whatever `action` / `state` tensors require them."""
+        inputs = (state['solver'], tuple(self.solver.filter_aux_inputs(state)))
+        parameters = self.solver.filter_hyperparameter(action)
+        solver_state = self.solver(inputs, parameters)
+        output2 = self.solver.get_output(solver_state)
+        reward = self.metric_fn(output2, state['gt']) - self.metric_fn(state['output'], state['gt'])
+        return solver_state, reward
+
     def _compute_metric(self):
-        return self.metric_fn(self.state['output'], self.state['gt'])
+        return self.metric_fn(self.state['output'].detach(), self.state['gt'])
 
     def _compute_reward(self):
         metric = self._compute_metric()

@@ -148,6 +148,22 @@ def unet_denoise(ctx, x, sigma, return_preclamp=False):
     return (out, pre) if return_preclamp else out
 
 
+def unet_denoise_backward(ctx, x, sigma, grad_out):
+    """(grad_x [B,1,H,W], grad_sigma [B]) = J^T grad_out of unet_denoise (forward re-computed natively in fp32)."""
+    x = _f32(x, "x")
+    sigma = _f32(sigma, "sigma").reshape(-1)
+    grad_out = _f32(grad_out, "grad_out")
+    B, _, H, W = x.shape
+    if grad_out.shape != x.shape or sigma.numel() != B:
+        raise PnpxError("unet_denoise_backward: shape mismatch")
+    gx = torch.empty_like(x)
+    gs = torch.empty((B,), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().pnpx_unet_denoise_backward(ctx.handle, _p(x), _p(sigma), _p(grad_out), _p(gx), _p(gs), B, H, W,
+                                                    _stream(x)))
+    return gx, gs
+
+
 def unet_profile(ctx, x, sigma):
     """[(name, ms, flops)] per kernel launch of one denoiser forward (HIP events on the current stream)."""
     x = _f32(x, "x")

@@ -49,6 +49,9 @@ class UNetDenoiser2D(torch.nn.Module):
 
     def forward(self, x, sigma):
         # x: [B,1,H,W]; sigma: [B]      (denoiser/base.py:23-32)
+        from ... import autograd as A
+        if A.needs_grad(x, sigma):      # training path: native forward + native VJP wrt x and sigma
+            return A.denoise(self.context(x.device), x, sigma)
         return ops.unet_denoise(self.context(x.device), x, sigma)
 
     def forward_preclamp(self, x, sigma):

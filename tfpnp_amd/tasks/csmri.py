@@ -4,9 +4,21 @@ solver(inputs, parameters, iter_num=None) with inputs = (variables, (y0, mask)),
 filter_hyperparameter(action); returns the next state tensor.  Each forward is ONE native call that runs all
 iter_num inner iterations (denoiser prox + masked-FFT data prox + dual update) on the caller's stream.
 """
+import torch
+
+from .. import autograd as A
 from .. import ops
 from ..pnp.solver.base import ADMMSolver, HQSSolver, PGSolver, APGSolver, REDADMMSolver, AMPSolver
 from ..utils import transforms
+
+
+def _v5(t, B):
+    return t.reshape(B, 1, 1, 1, 1)
+
+
+def _blend(k, y0, m, mu):
+    """k[mask] = ((mu*k) + y0)[mask] / (1 + mu)   (tasks/csmri/solver.py:49-51) without in-place writes."""
+    return torch.where(m, (mu * k + y0) / (1 + mu), k)
 
 
 class CSMRIMixin:
@@ -25,7 +37,20 @@ class ADMMSolver_CSMRI(CSMRIMixin, ADMMSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, mask) = inputs
         sigma_d, mu = parameters
+        if A.needs_grad(variables, sigma_d, mu):
+            return self._forward_autograd(variables, y0, mask, sigma_d, mu, iter_num)
         return ops.csmri_admm(self._ctx(variables), variables, y0, mask, sigma_d, mu, iter_num)
+
+    def _forward_autograd(self, variables, y0, mask, sigma_d, mu, iter_num):
+        """Training path (PnPEnv.forward under autograd): the reference's loop, tasks/csmri/solver.py:43-55."""
+        x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
+        B = x.shape[0]
+        m = (mask != 0).unsqueeze(-1)
+        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
+            x = A.r2c(self.prox_mapping(A.c2r(z - u), sigma_d[:, i]))
+            z = A.fft2(_blend(A.fft2(x + u), y0, m, _v5(mu[:, i], B)), inverse=True)
+            u = u + x - z
+        return torch.cat((x, z, u), dim=1)
 
 
 class HQSSolver_CSMRI(CSMRIMixin, HQSSolver):
@@ -34,6 +59,13 @@ class HQSSolver_CSMRI(CSMRIMixin, HQSSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, mask) = inputs
         sigma_d, mu = parameters
+        if A.needs_grad(variables, sigma_d, mu):
+            x, z = torch.split(variables, variables.shape[1] // 2, dim=1)
+            B, m = x.shape[0], (mask != 0).unsqueeze(-1)
+            for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):      # tasks/csmri/solver.py:76-85
+                x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
+                z = A.fft2(_blend(A.fft2(x), y0, m, _v5(mu[:, i], B)), inverse=True)
+            return torch.cat([x, z], dim=1)
         return ops.csmri_hqs(self._ctx(variables), variables, y0, mask, sigma_d, mu, iter_num)
 
 
@@ -43,6 +75,13 @@ class PGSolver_CSMRI(CSMRIMixin, PGSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, mask) = inputs
         sigma_d, tau = parameters
+        if A.needs_grad(variables, sigma_d, tau):
+            x, B, m = variables, variables.shape[0], (mask != 0).unsqueeze(-1)
+            for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):      # tasks/csmri/solver.py:107-116
+                temp = torch.where(m, A.fft2(x) - y0, torch.zeros_like(y0))
+                z = x - _v5(tau[:, i], B) * A.fft2(temp, inverse=True)
+                x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
+            return x
         return ops.csmri_pg(self._ctx(variables), variables, y0, mask, sigma_d, tau, iter_num)
 
 
@@ -52,6 +91,16 @@ class APGSolver_CSMRI(CSMRIMixin, APGSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, mask) = inputs
         sigma_d, tau, beta = parameters
+        if A.needs_grad(variables, sigma_d, tau, beta):
+            x, s = torch.split(variables, variables.shape[1] // 2, dim=1)
+            B, m = x.shape[0], (mask != 0).unsqueeze(-1)
+            for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):      # tasks/csmri/solver.py:141-159
+                temp = torch.where(m, A.fft2(s) - y0, torch.zeros_like(y0))
+                z = s - _v5(tau[:, i], B) * A.fft2(temp, inverse=True)
+                x_prev = x
+                x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
+                s = x + _v5(beta[:, i], B) * (x - x_prev)
+            return torch.cat([x, s], dim=1)
         return ops.csmri_apg(self._ctx(variables), variables, y0, mask, sigma_d, tau, beta, iter_num)
 
 
@@ -61,6 +110,16 @@ class REDADMMSolver_CSMRI(CSMRIMixin, REDADMMSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, mask) = inputs
         sigma_d, mu, lamda = parameters
+        if A.needs_grad(variables, sigma_d, mu, lamda):
+            x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
+            B, m = x.shape[0], (mask != 0).unsqueeze(-1)
+            for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):      # tasks/csmri/solver.py:183-200
+                _mu, _la = _v5(mu[:, i], B), _v5(lamda[:, i], B)
+                x_half = A.r2c(self.prox_mapping(A.c2r(x), sigma_d[:, i]))
+                x = (_la * x_half + _mu * (z - u)) / (_mu + _la)
+                z = A.fft2(_blend(A.fft2(x + u), y0, m, _mu), inverse=True)
+                u = u + x - z
+            return torch.cat([x, z, u], dim=1)
         return ops.csmri_redadmm(self._ctx(variables), variables, y0, mask, sigma_d, mu, lamda, iter_num)
 
 

@@ -1,4 +1,7 @@
 """Sparse-view CT solvers -- drop-in for tasks/ct/solver.py (own Radon pair instead of torch_radon)."""
+import torch
+
+from .. import autograd as A
 from .. import ops
 from ..pnp.solver.base import IADMMSolver, PGSolver
 from ..utils.transforms import RadonGenerator
@@ -23,6 +26,16 @@ class IADMMSolver_CT(CTMixin, IADMMSolver):
         sigma_d, mu, tau = parameters
         n_view = int(view[0, 0, 0, 0].item() * 120)     # host sync, as in the reference (:26)
         radon = self.radon_generator(variables.shape[-1], n_view, device=variables.device)
+        if A.needs_grad(variables, sigma_d, mu, tau):
+            x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
+            B, R = x.shape[0], x.shape[-1]
+            for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):      # tasks/ct/solver.py:32-49
+                x = self.prox_mapping(z - u, sigma_d[:, i])
+                _tau, _mu = tau[:, i].reshape(B, 1, 1, 1), mu[:, i].reshape(B, 1, 1, 1)
+                g = A.radon_backprojection(A.radon_forward(z, n_view) - y0, R) / radon.opnorm ** 2
+                z = z - _tau * (g + _mu * (z - (x + u)))
+                u = u + x - z
+            return torch.cat([x, z, u], dim=1)
         return ops.ct_iadmm(self._ctx(variables), variables, y0, n_view, radon.opnorm, sigma_d, mu, tau, iter_num)
 
 
@@ -38,6 +51,12 @@ class PGSolver_CT(CTMixin, PGSolver):
         sigma_d, tau = parameters
         n_view = int(view[0, 0, 0, 0].item() * 120)
         radon = self.radon_generator(variables.shape[-1], n_view, device=variables.device)
+        if A.needs_grad(variables, sigma_d, tau):
+            x, B, R = variables, variables.shape[0], variables.shape[-1]
+            for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):      # tasks/ct/solver.py:73-83
+                g = A.radon_backprojection(A.radon_forward(x, n_view) - y0, R) / radon.opnorm ** 2
+                x = self.prox_mapping(x - tau[:, i].reshape(B, 1, 1, 1) * g, sigma_d[:, i])
+            return x
         return ops.ct_pg(self._ctx(variables), variables, y0, n_view, radon.opnorm, sigma_d, tau, iter_num)
 
 
