@@ -1,8 +1,9 @@
 """The caller contract of the hot path: a minimal PnPEnv (tfpnp/env/base.py:121-191, 237-242).
 
 Only what SURVEY.md section 8(b) lists is reproduced: live-row gather (`idx_left`), the solver call, state /
-output write-back, delta-PSNR reward and the idx_left shrink.  Observation packing for the RL policy, the
-policy itself and training are out of scope.  `metric_fn` runs natively (pnpx_psnr).
+output write-back, delta-PSNR reward and the idx_left shrink, plus the differentiable `forward` used by the
+actor/critic update (base.py:193-206).  Observation packing for the RL policy, the policy itself and the trainer are
+out of scope.  `metric_fn` runs natively (pnpx_psnr; analytic VJP under autograd).
 """
 import torch
 
