@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 from tfpnp_amd import dist as D  # noqa: E402
 from tfpnp_amd import ops, synth  # noqa: E402
-from tfpnp_amd.env import PnPEnv  # noqa: E402
+from tfpnp_amd.tasks.csmri import CSMRIEnv  # noqa: E402
 from tfpnp_amd.pnp import UNetDenoiser2D  # noqa: E402
 from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI  # noqa: E402
 
@@ -80,14 +80,14 @@ def main():
     for a in actions:
         a["idx_stop"] = torch.zeros(B, dtype=torch.int64, device=dev)
     den.context(dev).reserve(B, H, W)
-    env = PnPEnv(solver, max_episode_step=N_POLICY_STEPS)
+    env = CSMRIEnv(None, solver, max_episode_step=N_POLICY_STEPS)
     n_global = B * world
 
     def episode():
         env.reset(data)
         rewards = []
         for a in actions:
-            reward, _, _ = env.step(a)
+            _, _, reward, _, _ = env.step(a)
             rewards.append(D.all_gather_rows(reward, n_global))       # [B*world, 1] on every rank
         return rewards
 

@@ -78,10 +78,30 @@ int pnpx_unet_profile(pnpx_ctx* ctx, const float* x, const float* sigma, float* 
                       void* stream, int cap, float* ms_out, double* flops_out, const char** names_out,
                       int* n_out);
 
+/* ---- policy actor (tfpnp/policy/network.py) ------------------------------------------------------- */
+/* ResNetActorBase (network.py:129-147) in eval mode: ResNet-18 encoder (network.py:87-125; BasicBlock :33-58;
+ * SynchronizedBatchNorm2d on running statistics, sync_batchnorm/batchnorm.py:63-68) -> adaptive_avg_pool2d(1) ->
+ * fc_softmax (Linear(512,2)+Softmax) and fc_deterministic (Linear(512,n_det)+Sigmoid; spi_head=1: the
+ * Linear(512,64)-ReLU-Linear(64,n_det)-Sigmoid head of ResNetActor_SPI, network.py:262-268).
+ * `params_host`: fp32 values of the module's state_dict in this order (integer num_batches_tracked entries skipped):
+ *   actor_encoder.conv1.weight, actor_encoder.bn1.{weight,bias,running_mean,running_var},
+ *   for L in layer1..layer4:  L.0.{conv1.weight, bn1.*, conv2.weight, bn2.*, shortcut.0.weight, shortcut.1.*},
+ *                             L.1.{conv1.weight, bn1.*, conv2.weight, bn2.*},
+ *   fc_softmax.0.{weight,bias}, fc_deterministic.0.{weight,bias} [, fc_deterministic.2.{weight,bias}]
+ * where bn.* = weight, bias, running_mean, running_var.  num_inputs = channels of the policy observation
+ * (env.get_policy_ob, e.g. tasks/csmri/env.py:14-23 -> 9), n_det = action_bundle * num_actions. */
+size_t pnpx_policy_num_params(int num_inputs, int n_det, int spi_head);
+int pnpx_policy_load(pnpx_ctx* ctx, const float* params_host, size_t n_params, int num_inputs, int n_det,
+                     int spi_head);
+/* ob [B,num_inputs,H,W] (device, contiguous; H, W multiples of 32) -> probs [B,2] (softmax over {continue, stop}),
+ * det [B,n_det] (sigmoid outputs, before the action-range mapping of network.py:163-175). */
+int pnpx_policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int B, int H, int W,
+                        void* stream);
+
 /* ---- transforms (tfpnp/utils/transforms.py) ------------------------------------------------------ */
 /* fft2 / ifft2 (transforms.py:68-103): centered (ifftshift -> FFT -> fftshift), orthonormal, over the
  * last two image dims of [n_img, H, W, 2].  centered=0 gives the plain torch.fft(x, 2, normalized=True)
- * used by cdp_forward/backward (transforms.py:300,318).  H, W powers of two in [2, 1024]. */
+ * used by cdp_forward/backward (transforms.py:300,318).  H, W in [1, 2048], any factorisation. */
 int pnpx_fft2(pnpx_ctx* ctx, const float* in, float* out, int n_img, int H, int W, int inverse,
               int centered, void* stream);
 /* cdp_forward (transforms.py:282-301): x [B,1,H,W,2], mask [B,S,H,W,2] -> out [B,S,H,W,2]. */

@@ -148,14 +148,16 @@ def main():
         d = synth.make_csmri_batch(B, H, W, ratio=4, sigma_n=15.0, seed=seed)
         data = {k: t(v) for k, v in d.items()}
         env = env_mod.CSMRIEnv(None, cs.ADMMSolver_CSMRI(den), max_episode_step=3)
-        env.reset(data={k: v.clone() for k, v in data.items()})
-        out = {}
+        ob0 = env.reset(data={k: v.clone() for k, v in data.items()})
+        out = {"policy_ob_reset": env.get_policy_ob(ob0)}
         stops = [np.array([0, 1, 0]), np.array([1, 0]), np.array([0])]
         for s, stop in enumerate(stops):
             nb = len(stop)
             a = csmri_actions(nb, 2, seed + 10 + s)
             action = {"sigma_d": t(a["sigma_d"]), "mu": t(a["mu"]), "idx_stop": torch.from_numpy(stop)}
             ob, ob_masked, reward, all_done, info = env.step(action)
+            out[f"policy_ob{s}"] = env.get_policy_ob(ob)
+            out[f"policy_ob_masked_shape{s}"] = np.array(env.get_policy_ob(ob_masked).shape)
             out[f"reward{s}"] = reward
             out[f"done{s}"] = info["done"]
             out[f"all_done{s}"] = np.array(all_done)
@@ -163,6 +165,60 @@ def main():
             out[f"output{s}"] = env.state["output"].clone()
             out[f"idx_left{s}"] = env.idx_left.clone()
         save("env_step_csmri", in_sha=sha(d["y0"], d["mask"], d["x0"]), **out)
+
+        # (8) policy actor (eval mode) + a policy-driven rollout (evaluator.py:85-100)
+        print("[8] policy")
+        from tfpnp.policy import network as pol
+        from tests.golden_inputs import POLICY_SEED, ROLLOUT_CONTINUE_BIAS, policy_obs
+
+        def load_actor(cls, num_aux, bundle, nin, n_det, spi, continue_bias=0.0):
+            net = cls(num_aux, bundle).eval()
+            P = synth.make_policy_params(nin, n_det, spi, seed=POLICY_SEED)
+            P["fc_softmax.0.bias"] = P["fc_softmax.0.bias"] + np.array([continue_bias, 0], np.float32)
+            sd = net.state_dict()
+            sd.update({k: t(v) for k, v in P.items()})
+            net.load_state_dict(sd)
+            return net
+
+        pol_out = {}
+        cases = [("admm", pol.ResNetActor_ADMM, 6, 5, 9, 10, False, (2, 64, 64)),
+                 ("admm_rect", pol.ResNetActor_ADMM, 6, 5, 9, 10, False, (1, 96, 128)),
+                 ("iadmm_pr", pol.ResNetActor_IADMM, 14, 5, 17, 15, False, (2, 32, 32)),
+                 ("spi", pol.ResNetActor_SPI, 3, 5, 6, 10, True, (2, 64, 64))]
+        for name, cls, num_aux, bundle, nin, n_det, spi, (B, H, W) in cases:
+            net = load_actor(cls, num_aux, bundle, nin, n_det, spi)
+            ob = policy_obs(B, nin, H, W, 81)
+            with torch.no_grad():
+                action, logp, ent, _ = net(t(ob), None, False, None)
+                feat = torch.nn.functional.adaptive_avg_pool2d(net.actor_encoder(t(ob)), 1).flatten(1)
+                pol_out[f"{name}_probs"] = net.fc_softmax(feat)
+                pol_out[f"{name}_det"] = net.fc_deterministic(feat)
+            for k, v in action.items():
+                pol_out[f"{name}_action_{k}"] = v
+            pol_out[f"{name}_logp"] = logp
+            pol_out[f"{name}_entropy"] = ent
+        save("policy_actor", **pol_out)
+
+        # rollout: CSMRIEnv + ResNetActor_ADMM, 3 items, 3 policy steps of 5 iterations, arg-max stop decisions
+        B, H, W, seed = 3, 64, 64, 91
+        d = synth.make_csmri_batch(B, H, W, ratio=4, sigma_n=15.0, seed=seed)
+        env = env_mod.CSMRIEnv(None, cs.ADMMSolver_CSMRI(den), max_episode_step=3)
+        actor = load_actor(pol.ResNetActor_ADMM, 6, 5, 9, 10, False, continue_bias=ROLLOUT_CONTINUE_BIAS)
+        ob = env.reset(data={k: t(v).clone() for k, v in d.items()})
+        ro = {}
+        for s in range(3):
+            with torch.no_grad():
+                action, _, _, _ = actor(env.get_policy_ob(ob), None, False, None)
+            ro[f"sigma_d{s}"], ro[f"mu{s}"], ro[f"idx_stop{s}"] = action["sigma_d"], action["mu"], action["idx_stop"]
+            feat = torch.nn.functional.adaptive_avg_pool2d(actor.actor_encoder(env.get_policy_ob(ob)), 1).flatten(1)
+            ro[f"probs{s}"] = actor.fc_softmax(feat).detach()
+            _, ob, reward, all_done, _ = env.step(action)
+            ro[f"reward{s}"] = reward
+            ro[f"output{s}"] = env.state["output"].clone()
+            if all_done:
+                break
+        ro["n_steps"] = np.array(s + 1)
+        save("policy_rollout_csmri", **ro)
     print("done")
 
 

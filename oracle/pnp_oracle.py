@@ -416,6 +416,35 @@ def ct_pg(den, variables, y0, n_view, opnorm, sigma_d, tau, iter_num=None):
     return x
 
 
+# ----------------------------------------------------------------------------- policy actor (eval mode)
+def policy_forward(params, state, spi_head=False):
+    """ResNetActorBase.forward up to the head activations, eval-mode BatchNorm.  tfpnp/policy/network.py:87-147
+    (ResNetEncoder :87-125, BasicBlock :33-58, heads :137-147, SPI head :262-268).  Returns (probs [B,2], det [B,n])."""
+    p = {k: v.to(state.dtype) for k, v in _to_t(params).items()}
+
+    def bn(x, pre):
+        return F.batch_norm(x, p[pre + ".running_mean"], p[pre + ".running_var"], p[pre + ".weight"], p[pre + ".bias"],
+                            False, 0.1, 1e-5)
+
+    x = F.relu(bn(F.conv2d(state, p["actor_encoder.conv1.weight"], stride=2, padding=1), "actor_encoder.bn1"))
+    for li in range(1, 5):
+        for blk in range(2):
+            pre = f"actor_encoder.layer{li}.{blk}"
+            stride = 2 if blk == 0 else 1
+            out = F.relu(bn(F.conv2d(x, p[pre + ".conv1.weight"], stride=stride, padding=1), pre + ".bn1"))
+            out = bn(F.conv2d(out, p[pre + ".conv2.weight"], padding=1), pre + ".bn2")
+            sc = x
+            if blk == 0:
+                sc = bn(F.conv2d(x, p[pre + ".shortcut.0.weight"], stride=stride), pre + ".shortcut.1")
+            x = F.relu(out + sc)
+    x = F.adaptive_avg_pool2d(x, 1).view(x.shape[0], -1)
+    probs = torch.softmax(F.linear(x, p["fc_softmax.0.weight"], p["fc_softmax.0.bias"]), dim=1)
+    h = F.linear(x, p["fc_deterministic.0.weight"], p["fc_deterministic.0.bias"])
+    if spi_head:
+        h = F.linear(F.relu(h), p["fc_deterministic.2.weight"], p["fc_deterministic.2.bias"])
+    return probs, torch.sigmoid(h)
+
+
 # ----------------------------------------------------------------------------- metric + env step contract
 def torch_psnr(output, gt):
     """tfpnp/env/base.py:237-242"""

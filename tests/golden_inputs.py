@@ -46,3 +46,12 @@ def spi_grid(seed=3):
     zt = rs.uniform(-0.5, 1.5, size=(B, 1, H, W)).astype(np.float32)
     mu = np.array([50.0, 85.0, 120.0], np.float32).reshape(B, 1, 1, 1)
     return zt, K1, K, mu
+
+
+POLICY_SEED = 4242
+ROLLOUT_CONTINUE_BIAS = 3.0   # added to the "continue" logit of the rollout actor so that the episode runs > 1 step
+
+
+def policy_obs(B, C, H, W, seed):
+    """Synthetic policy observation in [0,1] (float32 [B,C,H,W])."""
+    return np.random.RandomState(seed).uniform(0, 1, (B, C, H, W)).astype(np.float32)

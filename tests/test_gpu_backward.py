@@ -317,20 +317,20 @@ def test_ct_solver_gradients(den, oden32, oden64, monkeypatch):
 def test_env_forward_trains_through_the_solver(den, oden64):
     """PnPEnv.forward (tfpnp/env/base.py:193-206): delta-PSNR reward differentiated wrt policy-like actions."""
     from oracle import pnp_oracle as O
-    from tfpnp_amd.env import PnPEnv
     from tfpnp_amd.tasks import csmri
     B, H, W = 2, 32, 32
     d = synth.make_csmri_batch(B, H, W, seed=95)
     sol = csmri.ADMMSolver_CSMRI(den)
-    env = PnPEnv(sol, max_episode_step=6)
-    state = env.reset({k: g(v) for k, v in d.items() if isinstance(v, np.ndarray)})
+    env = csmri.CSMRIEnv(None, sol, max_episode_step=6)
+    ob = env.reset({k: g(v) for k, v in d.items() if isinstance(v, np.ndarray)})
     raw0 = np.random.RandomState(96).standard_normal((B, 10)).astype(np.float32)
 
     def act(raw):
         return {"sigma_d": torch.sigmoid(raw[:, :5]) * 70 / 255, "mu": torch.sigmoid(raw[:, 5:])}
 
     raw = g(raw0, True)
-    _, reward = env.forward(state, act(raw))
+    next_ob, reward = env.forward(ob, act(raw))
+    assert abs(float(next_ob.T.mean()) - 1 / 6) < 1e-6
     assert reward.shape == (B, 1)
     reward.sum().backward()
     # oracle: same computation in fp64 on the CPU

@@ -140,6 +140,23 @@ def test_env_step(den):
         assert rel(env.state["output"], g[f"output{s}"]) < 1e-5
 
 
+POLICY_CASES = [("admm", 9, 10, False, (2, 64, 64)), ("admm_rect", 9, 10, False, (1, 96, 128)),
+                ("iadmm_pr", 17, 15, False, (2, 32, 32)), ("spi", 6, 10, True, (2, 64, 64))]
+
+
+@pytest.mark.parametrize("name,nin,n_det,spi,shape", POLICY_CASES)
+def test_policy_actor(name, nin, n_det, spi, shape):
+    """Oracle restatement of the eval-mode actor vs the real ResNetActor_* (golden 8)."""
+    from tests.golden_inputs import POLICY_SEED, policy_obs
+    g = golden("policy_actor")
+    P = synth.make_policy_params(nin, n_det, spi, seed=POLICY_SEED)
+    ob = policy_obs(shape[0], nin, shape[1], shape[2], 81)
+    probs, det = O.policy_forward(P, t(ob), spi)
+    assert np.allclose(probs.numpy(), g[f"{name}_probs"], atol=1e-6)
+    assert np.allclose(det.numpy(), g[f"{name}_det"], atol=1e-6)
+    assert np.array_equal(probs.argmax(1).numpy(), g[f"{name}_action_idx_stop"])
+
+
 def test_radon_adjoint_and_disc():
     """CT is parity-unpinned (no torch_radon here): check the oracle's own pair by mathematical properties."""
     R, V = 32, 12

@@ -95,12 +95,33 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx) {
   if (ctx->weights.p) (void)hipFree(ctx->weights.p);
   for (pnpx::UNetArena* a : {&ctx->arena, &ctx->arena_f32, &ctx->arena_grad})
     if (a->buf.p) (void)hipFree(a->buf.p);
+  policy_free(ctx);
   if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
   for (auto& t : ctx->twiddle)
     if (t.second) (void)hipFree(t.second);
   for (auto e : ctx->events) (void)hipEventDestroy(e);
   delete ctx;
   return PNPX_OK;
+}
+
+size_t pnpx_policy_num_params(int num_inputs, int n_det, int spi_head) {
+  return policy_num_params(num_inputs, n_det, spi_head);
+}
+
+int pnpx_policy_load(pnpx_ctx* ctx, const float* params_host, size_t n_params, int num_inputs, int n_det,
+                     int spi_head) {
+  LOCK_CTX(ctx);
+  return policy_load(ctx, params_host, n_params, num_inputs, n_det, spi_head);
+}
+
+int pnpx_policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int B, int H, int W,
+                        void* stream) {
+  LOCK_CTX(ctx);
+  if (!ob || !probs || !det) {
+    set_error("pnpx_policy_forward: null pointer");
+    return PNPX_ERR_ARG;
+  }
+  return policy_forward(ctx, ob, probs, det, B, H, W, static_cast<hipStream_t>(stream));
 }
 
 int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W) {

@@ -72,6 +72,33 @@ struct ConvLayerHsDev {     // the same conv packed for the half-split f16 kerne
 
 enum ConvMode { CONV_F32 = 0, CONV_HS = 1 };
 
+// ---------------------------------------------------------------------------------------------------
+// Policy actor (ResNet-18 encoder + heads, eval mode) -- policy.hip.  One PolicyConv per launch: BatchNorm is folded
+// into weights/bias at load time; stride-2 convolutions run as stride-1 convolutions over a space-to-depth input
+// with per-(cout tile, K-chunk) tap masks; the 1x1 stride-2 shortcut rides in the same launch as extra cout tiles.
+struct PolicyConv {
+  const float* w = nullptr;              // device: [cout/64][cin/8][9][8][64]
+  const float* bias = nullptr;           // device: [cout]
+  const unsigned short* tapmask = nullptr;  // device: [cout/64][cin/8]
+  int cin = 0;      // K channels of the (possibly space-to-depth) input, multiple of 8
+  int cout = 0;     // output channels over both outputs, multiple of 64
+  int split_c = 0;  // channels written to the first output (ReLU); the rest go to the second output (linear)
+};
+struct PolicyNet {
+  bool loaded = false;
+  int num_inputs = 0, cin_pad = 0, n_det = 0, spi_head = 0;
+  PolicyConv conv[17];       // stem, then per stage: conv1+shortcut, conv2, block-2 conv1, block-2 conv2
+  const float* fc_sm_w = nullptr;   // [2][512], [2]
+  const float* fc_sm_b = nullptr;
+  const float* fc_det_w = nullptr;  // [n_det][512] ([64][512] with the SPI head)
+  const float* fc_det_b = nullptr;
+  const float* fc_det2_w = nullptr; // SPI head only: [n_det][64]
+  const float* fc_det2_b = nullptr;
+  DeviceBuf weights;
+  DeviceBuf arena;           // activations for capB observations of capH x capW, zero borders
+  int capB = 0, capH = 0, capW = 0;
+};
+
 }  // namespace pnpx
 
 struct pnpx_ctx {
@@ -90,6 +117,8 @@ struct pnpx_ctx {
   //     arena = forward pass in the ctx's conv_mode; arena_f32 = fp32 re-computation inside the backward pass;
   //     arena_grad = gradients of every activation (fp32 planar)
   pnpx::UNetArena arena, arena_f32, arena_grad;
+  // --- policy actor
+  pnpx::PolicyNet policy;
   // --- solver scratch (complex fields etc.), grown on demand
   pnpx::DeviceBuf scratch;
   // --- FFT twiddle tables e^{-2 pi i m / N}, one per transform length: device float2[N]
@@ -119,6 +148,12 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
 // VJP of the denoiser wrt x and sigma (unet_bwd.hip): recomputes the forward pass in fp32 and back-propagates.
 int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out,
                           float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s);
+
+// Policy actor (policy.hip)
+size_t policy_num_params(int num_inputs, int n_det, int spi_head);
+int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, int n_det, int spi_head);
+int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int B, int H, int W, hipStream_t s);
+void policy_free(pnpx_ctx* ctx);
 
 // FFT building blocks (fft.hip)
 int fft2(pnpx_ctx* ctx, const float* in, float* out, int n_img, int H, int W, bool inverse, bool centered,

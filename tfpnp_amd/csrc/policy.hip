@@ -1,0 +1,429 @@
+// Policy actor forward (eval mode) -- SURVEY section 8(f) rank 2.
+//
+// Replaces ResNetActorBase.forward up to the head activations (tfpnp/policy/network.py:129-147):
+//     x = ResNetEncoder(18)(state)            network.py:87-125  (3x3 stride-2 stem, 4 stages of 2 BasicBlocks, each
+//                                             stage entered with stride 2; BasicBlock network.py:33-58)
+//     x = adaptive_avg_pool2d(x, 1).view(B, 512)
+//     probs = softmax(fc_softmax(x));  det = sigmoid(fc_deterministic(x))      (SPI head: 512-64-ReLU-n, :262-268)
+// with SynchronizedBatchNorm2d in eval mode (= F.batch_norm on running statistics, sync_batchnorm/batchnorm.py:63-68;
+// both the rollout, trainer.py:216-221, and the evaluator, evaluator.py:23, run the actor that way).  Sampling /
+// arg-max of idx_stop, log-probabilities and the action range mapping stay in the host mirror (O(B) scalars).
+//
+// MI355X design: every convolution is one launch of the fp32 MFMA kernel (conv3x3.hip, POL variant):
+//   * BatchNorm folded into weights and bias on the host; ReLU / residual add in the epilogue.
+//   * stride-2 3x3 convolutions read a SPACE-TO-DEPTH copy of their input ([4*C][H/2][W/2], written directly by the
+//     producer's epilogue): on that grid the convolution is stride 1, and of the 36 (phase, tap) pairs only 9 are
+//     non-zero -- a per-(cout tile, K-chunk) tap mask skips the other MFMAs, so no arithmetic is wasted on stride.
+//   * the 1x1 stride-2 shortcut is the centre tap of phase (0,0): it rides in the same launch as extra cout tiles
+//     (all other chunks masked out) and is written, without ReLU, to a second output.
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+#include "conv3x3.h"
+
+namespace pnpx {
+namespace {
+
+constexpr float BN_EPS = 1e-5f;
+inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// observation [B][C][H][W] -> space-to-depth padded planar [B][4*Cp][H/2+2][W/2+8] (channels >= C stay zero)
+__global__ __launch_bounds__(256) void pack_ob_s2d_kernel(const float* __restrict__ ob, float* __restrict__ out, int C,
+                                                          int Cp, int H, int W, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W);
+  size_t t = i / W;
+  const int y = (int)(t % H);
+  t /= H;
+  const int c = (int)(t % C);
+  const size_t b = t / C;
+  const int Hp2 = padded_h(H >> 1), Wp2 = padded_w(W >> 1);
+  const int ph = (y & 1) * 2 + (x & 1);
+  out[((b * 4 * Cp + (size_t)ph * Cp + c) * Hp2 + (y >> 1) + 1) * Wp2 + (x >> 1) + PADL] = ob[i];
+}
+
+// global average pool over [B][512][h][w] (padded planar) + the two heads.  One workgroup per observation.
+__global__ __launch_bounds__(256) void pool_heads_kernel(const float* __restrict__ feat, int h, int w,
+                                                         const float* __restrict__ sm_w, const float* __restrict__ sm_b,
+                                                         const float* __restrict__ d_w, const float* __restrict__ d_b,
+                                                         const float* __restrict__ d2_w, const float* __restrict__ d2_b,
+                                                         int n_det, int spi, float* __restrict__ probs,
+                                                         float* __restrict__ det) {
+  __shared__ float f[512];
+  __shared__ float hid[64];
+  __shared__ float logit[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Hp = padded_h(h), Wp = padded_w(w);
+  const float inv = 1.f / (float)(h * w);
+  for (int c = tid; c < 512; c += 256) {
+    const float* p = feat + ((size_t)b * 512 + c) * Hp * Wp;
+    float s = 0.f;
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) s += p[(y + 1) * Wp + x + PADL];
+    f[c] = s * inv;
+  }
+  __syncthreads();
+  auto dot512 = [&](const float* wrow) {
+    float s = 0.f;
+    for (int k = 0; k < 512; ++k) s = fmaf(wrow[k], f[k], s);
+    return s;
+  };
+  if (tid < 2) logit[tid] = dot512(sm_w + tid * 512) + sm_b[tid];
+  if (spi) {
+    if (tid >= 64 && tid < 128) hid[tid - 64] = fmaxf(dot512(d_w + (tid - 64) * 512) + d_b[tid - 64], 0.f);
+  } else if (tid >= 64 && tid < 64 + n_det) {
+    const int j = tid - 64;
+    det[(size_t)b * n_det + j] = 1.f / (1.f + expf(-(dot512(d_w + j * 512) + d_b[j])));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float m = fmaxf(logit[0], logit[1]);
+    const float e0 = expf(logit[0] - m), e1 = expf(logit[1] - m);
+    probs[b * 2 + 0] = e0 / (e0 + e1);
+    probs[b * 2 + 1] = e1 / (e0 + e1);
+  }
+  if (spi && tid < n_det) {
+    float s = d2_b[tid];
+    for (int k = 0; k < 64; ++k) s = fmaf(d2_w[tid * 64 + k], hid[k], s);
+    det[(size_t)b * n_det + tid] = 1.f / (1.f + expf(-s));
+  }
+}
+
+// ------------------------------------------------------------------------------------------- parameter layout
+struct BnView {
+  const float *g, *b, *m, *v;
+};
+struct Reader {
+  const float* p;
+  const float* take(size_t n) {
+    const float* r = p;
+    p += n;
+    return r;
+  }
+  BnView bn(int c) {
+    BnView r;
+    r.g = take(c);
+    r.b = take(c);
+    r.m = take(c);
+    r.v = take(c);
+    return r;
+  }
+};
+inline int stage_planes(int n) { return 64 << n; }   // n = 0..3
+
+// Dense "effective" weights of one launch: E[cout][K][9] (+ bias[cout]), then packed + masked.
+struct Eff {
+  int cout, K;
+  std::vector<float> w, bias;
+  Eff(int cout_, int K_) : cout(cout_), K(K_), w((size_t)cout_ * K_ * 9, 0.f), bias(cout_, 0.f) {}
+  float& at(int co, int k, int tap) { return w[((size_t)co * K + k) * 9 + tap]; }
+};
+inline void bn_fold(const BnView& bn, int c, float* scale, float* shift) {
+  for (int i = 0; i < c; ++i) {
+    scale[i] = bn.g[i] / std::sqrt(bn.v[i] + BN_EPS);
+    shift[i] = bn.b[i] - bn.m[i] * scale[i];
+  }
+}
+// 3x3 stride-1 conv + BN -> rows [row0, row0 + cout) of E
+void put_conv_s1(Eff& E, int row0, const float* w, const BnView& bn, int cout, int cin) {
+  std::vector<float> sc(cout), sh(cout);
+  bn_fold(bn, cout, sc.data(), sh.data());
+  for (int co = 0; co < cout; ++co) {
+    E.bias[row0 + co] = sh[co];
+    for (int ci = 0; ci < cin; ++ci)
+      for (int t = 0; t < 9; ++t) E.at(row0 + co, ci, t) = w[((size_t)co * cin + ci) * 9 + t] * sc[co];
+  }
+}
+// 3x3 stride-2 conv + BN over a space-to-depth input with Cp channels per phase
+void put_conv_s2(Eff& E, int row0, const float* w, const BnView& bn, int cout, int cin, int Cp) {
+  std::vector<float> sc(cout), sh(cout);
+  bn_fold(bn, cout, sc.data(), sh.data());
+  for (int co = 0; co < cout; ++co) {
+    E.bias[row0 + co] = sh[co];
+    for (int ci = 0; ci < cin; ++ci)
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx) {
+          // input row 2*yo + (dy - 1): offset 0 -> phase 0 / same half-res row (tap row 1); offset -1 -> phase 1 /
+          // previous row (tap row 0); offset +1 -> phase 1 / same row (tap row 1).  Likewise in x.
+          const int py = (dy == 1) ? 0 : 1, ty = (dy == 0) ? 0 : 1;
+          const int px = (dx == 1) ? 0 : 1, tx = (dx == 0) ? 0 : 1;
+          E.at(row0 + co, (py * 2 + px) * Cp + ci, ty * 3 + tx) = w[((size_t)co * cin + ci) * 9 + dy * 3 + dx] * sc[co];
+        }
+  }
+}
+// 1x1 stride-2 conv + BN = centre tap of phase (0,0)
+void put_shortcut(Eff& E, int row0, const float* w, const BnView& bn, int cout, int cin) {
+  std::vector<float> sc(cout), sh(cout);
+  bn_fold(bn, cout, sc.data(), sh.data());
+  for (int co = 0; co < cout; ++co) {
+    E.bias[row0 + co] = sh[co];
+    for (int ci = 0; ci < cin; ++ci) E.at(row0 + co, ci, 4) = w[(size_t)co * cin + ci] * sc[co];
+  }
+}
+
+struct HostBlob {
+  std::vector<float> f;
+  void align() { f.resize((f.size() + 255) & ~(size_t)255, 0.f); }
+  size_t add(const float* p, size_t n) {
+    align();
+    const size_t off = f.size();
+    f.insert(f.end(), p, p + n);
+    return off;
+  }
+};
+struct ConvOff {
+  size_t w, bias, mask;
+};
+ConvOff pack_eff(HostBlob& H, Eff& E) {
+  const int nct = E.cout / 64, nch = E.K / 8;
+  ConvOff o;
+  H.align();
+  o.w = H.f.size();
+  H.f.resize(H.f.size() + (size_t)E.cout * E.K * 9);
+  std::vector<unsigned short> mask((size_t)nct * nch, 0);
+  float* dst = H.f.data() + o.w;
+  for (int ct = 0; ct < nct; ++ct)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int tap = 0; tap < 9; ++tap) {
+        bool any = false;
+        for (int c = 0; c < 8; ++c)
+          for (int m = 0; m < 64; ++m) {
+            const float v = E.at(ct * 64 + m, ch * 8 + c, tap);
+            any |= (v != 0.f);
+            dst[((((size_t)ct * nch + ch) * 9 + tap) * 8 + c) * 64 + m] = v;
+          }
+        if (any) mask[(size_t)ct * nch + ch] |= (unsigned short)(1u << tap);
+      }
+  o.bias = H.add(E.bias.data(), E.bias.size());
+  H.align();
+  o.mask = H.f.size();
+  H.f.resize(H.f.size() + (mask.size() + 1) / 2, 0.f);
+  std::memcpy(H.f.data() + o.mask, mask.data(), mask.size() * sizeof(unsigned short));
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------- activation plan
+struct PolAct {
+  size_t off = 0;   // floats
+  int C = 0, H = 0, W = 0;
+};
+struct PolicyPlan {
+  PolAct ob, stem;               // both space-to-depth
+  PolAct t1[4], sc[4], o0[4], t2[4], o1[4];
+  size_t total = 0;              // floats for capB observations
+};
+PolicyPlan make_policy_plan(int capB, int cin_pad, int H, int W) {
+  PolicyPlan P;
+  size_t off = 0;
+  auto add = [&](PolAct& d, int C, int h, int w) {
+    d.off = off;
+    d.C = C;
+    d.H = h;
+    d.W = w;
+    off += (size_t)C * padded_h(h) * padded_w(w) * capB;
+    off = (off + 63) & ~(size_t)63;
+  };
+  add(P.ob, 4 * cin_pad, H / 2, W / 2);
+  add(P.stem, 4 * 64, H / 4, W / 4);
+  for (int n = 0; n < 4; ++n) {
+    const int p = stage_planes(n), h = H >> (n + 2), w = W >> (n + 2);
+    add(P.t1[n], p, h, w);
+    add(P.sc[n], p, h, w);
+    add(P.o0[n], p, h, w);
+    add(P.t2[n], p, h, w);
+    if (n < 3) add(P.o1[n], 4 * p, h / 2, w / 2);
+    else add(P.o1[n], p, h, w);
+  }
+  P.total = off + (1u << 18);   // slack: overhanging tiles read past their tensor
+  return P;
+}
+
+}  // namespace
+
+size_t policy_num_params(int num_inputs, int n_det, int spi_head) {
+  size_t n = (size_t)64 * num_inputs * 9 + 4 * 64;
+  int in_planes = 64;
+  for (int s = 0; s < 4; ++s) {
+    const int p = stage_planes(s);
+    n += (size_t)p * in_planes * 9 + 4 * p + (size_t)p * p * 9 + 4 * p + (size_t)p * in_planes + 4 * p;  // block 0
+    n += 2 * ((size_t)p * p * 9 + 4 * p);                                                                 // block 1
+    in_planes = p;
+  }
+  n += 2 * 512 + 2;
+  n += spi_head ? (size_t)64 * 512 + 64 + (size_t)n_det * 64 + n_det : (size_t)n_det * 512 + n_det;
+  return n;
+}
+
+void policy_free(pnpx_ctx* ctx) {
+  PolicyNet& N = ctx->policy;
+  if (N.weights.p) (void)hipFree(N.weights.p);
+  if (N.arena.p) (void)hipFree(N.arena.p);
+  N = PolicyNet();
+}
+
+int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, int n_det, int spi_head) {
+  if (!params || num_inputs < 1 || num_inputs > 64 || n_det < 1 || n_det > 64 ||
+      n != policy_num_params(num_inputs, n_det, spi_head)) {
+    set_error("pnpx_policy_load: expected %zu parameters for (%d inputs, %d outputs, spi %d), got %zu",
+              policy_num_params(num_inputs, n_det, spi_head), num_inputs, n_det, spi_head, n);
+    return PNPX_ERR_ARG;
+  }
+  PNPX_HIP(hipDeviceSynchronize());
+  policy_free(ctx);
+  PolicyNet& N = ctx->policy;
+  N.num_inputs = num_inputs;
+  N.cin_pad = (num_inputs + 7) / 8 * 8;
+  N.n_det = n_det;
+  N.spi_head = spi_head;
+  Reader R{params};
+  HostBlob H;
+  ConvOff off[17];
+  int cins[17], couts[17], splits[17];
+  int li = 0;
+  auto finish = [&](Eff& E, int split) {
+    off[li] = pack_eff(H, E);
+    cins[li] = E.K;
+    couts[li] = E.cout;
+    splits[li] = split;
+    ++li;
+  };
+  {  // stem: conv3x3(num_inputs, 64, stride 2) + bn1
+    const float* w = R.take((size_t)64 * num_inputs * 9);
+    const BnView bn = R.bn(64);
+    Eff E(64, 4 * N.cin_pad);
+    put_conv_s2(E, 0, w, bn, 64, num_inputs, N.cin_pad);
+    finish(E, 64);
+  }
+  int in_planes = 64;
+  for (int s = 0; s < 4; ++s) {
+    const int p = stage_planes(s);
+    // block 0 (stride 2): conv1, bn1, conv2, bn2, shortcut.0 (1x1), shortcut.1 (bn)   -- state_dict order
+    const float* w1 = R.take((size_t)p * in_planes * 9);
+    const BnView b1 = R.bn(p);
+    const float* w2 = R.take((size_t)p * p * 9);
+    const BnView b2 = R.bn(p);
+    const float* ws = R.take((size_t)p * in_planes);
+    const BnView bs = R.bn(p);
+    {
+      Eff E(2 * p, 4 * in_planes);
+      put_conv_s2(E, 0, w1, b1, p, in_planes, in_planes);
+      put_shortcut(E, p, ws, bs, p, in_planes);
+      finish(E, p);
+    }
+    {
+      Eff E(p, p);
+      put_conv_s1(E, 0, w2, b2, p, p);
+      finish(E, p);
+    }
+    // block 1 (stride 1, identity shortcut)
+    for (int j = 0; j < 2; ++j) {
+      const float* w = R.take((size_t)p * p * 9);
+      const BnView b = R.bn(p);
+      Eff E(p, p);
+      put_conv_s1(E, 0, w, b, p, p);
+      finish(E, p);
+    }
+    in_planes = p;
+  }
+  const size_t o_smw = H.add(R.take(2 * 512), 2 * 512);
+  const size_t o_smb = H.add(R.take(2), 2);
+  size_t o_dw, o_db, o_d2w = 0, o_d2b = 0;
+  if (spi_head) {
+    o_dw = H.add(R.take((size_t)64 * 512), (size_t)64 * 512);
+    o_db = H.add(R.take(64), 64);
+    o_d2w = H.add(R.take((size_t)n_det * 64), (size_t)n_det * 64);
+    o_d2b = H.add(R.take(n_det), n_det);
+  } else {
+    o_dw = H.add(R.take((size_t)n_det * 512), (size_t)n_det * 512);
+    o_db = H.add(R.take(n_det), n_det);
+  }
+  H.f.resize(H.f.size() + 8192, 0.f);   // DMA over-read slack
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, H.f.size() * sizeof(float));
+  if (e != hipSuccess) {
+    set_error("policy weight allocation of %zu bytes failed: %s", H.f.size() * sizeof(float), hipGetErrorString(e));
+    return PNPX_ERR_ALLOC;
+  }
+  N.weights.p = d;
+  N.weights.bytes = H.f.size() * sizeof(float);
+  PNPX_HIP(hipMemcpy(d, H.f.data(), N.weights.bytes, hipMemcpyHostToDevice));
+  const float* base = static_cast<const float*>(d);
+  for (int i = 0; i < 17; ++i) {
+    N.conv[i].w = base + off[i].w;
+    N.conv[i].bias = base + off[i].bias;
+    N.conv[i].tapmask = reinterpret_cast<const unsigned short*>(base + off[i].mask);
+    N.conv[i].cin = cins[i];
+    N.conv[i].cout = couts[i];
+    N.conv[i].split_c = splits[i];
+  }
+  N.fc_sm_w = base + o_smw;
+  N.fc_sm_b = base + o_smb;
+  N.fc_det_w = base + o_dw;
+  N.fc_det_b = base + o_db;
+  N.fc_det2_w = spi_head ? base + o_d2w : nullptr;
+  N.fc_det2_b = spi_head ? base + o_d2b : nullptr;
+  N.loaded = true;
+  return PNPX_OK;
+}
+
+int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int B, int H, int W, hipStream_t s) {
+  PolicyNet& N = ctx->policy;
+  if (!N.loaded) {
+    set_error("policy forward called before pnpx_policy_load");
+    return PNPX_ERR_NO_WEIGHTS;
+  }
+  if (B <= 0 || H < 32 || W < 32 || (H % 32) || (W % 32)) {
+    set_error("policy forward: need B > 0 and H, W positive multiples of 32 (got %d x %d x %d)", B, H, W);
+    return PNPX_ERR_SHAPE;
+  }
+  if (!(B <= N.capB && H == N.capH && W == N.capW)) {
+    const bool same = (H == N.capH && W == N.capW);
+    const int nb = same ? (B > N.capB ? B : N.capB) : B;
+    const PolicyPlan P = make_policy_plan(nb, N.cin_pad, H, W);
+    PNPX_HIP(hipDeviceSynchronize());
+    if (N.arena.bytes < P.total * sizeof(float)) {
+      if (N.arena.p) PNPX_HIP(hipFree(N.arena.p));
+      N.arena = DeviceBuf();
+      void* p = nullptr;
+      hipError_t e = hipMalloc(&p, P.total * sizeof(float));
+      if (e != hipSuccess) {
+        set_error("policy arena allocation of %zu bytes failed: %s", P.total * sizeof(float), hipGetErrorString(e));
+        return PNPX_ERR_ALLOC;
+      }
+      N.arena.p = p;
+      N.arena.bytes = P.total * sizeof(float);
+    }
+    PNPX_HIP(hipMemset(N.arena.p, 0, P.total * sizeof(float)));
+    PNPX_HIP(hipDeviceSynchronize());
+    N.capB = nb;
+    N.capH = H;
+    N.capW = W;
+  }
+  const PolicyPlan P = make_policy_plan(N.capB, N.cin_pad, H, W);
+  float* A = static_cast<float*>(N.arena.p);
+  auto ptr = [&](const PolAct& d) { return A + d.off; };
+
+  const size_t n = (size_t)B * N.num_inputs * H * W;
+  hipLaunchKernelGGL(pack_ob_s2d_kernel, g1(n), dim3(256), 0, s, ob, ptr(P.ob), N.num_inputs, N.cin_pad, H, W, n);
+  PNPX_LAUNCH_CHECK();
+  // stem (on the H/2 grid) -> space-to-depth for stage 1
+  PNPX_TRY(launch_conv3x3_policy(N.conv[0], ptr(P.ob), ptr(P.stem), nullptr, nullptr, true, B, H / 2, W / 2, s));
+  const float* xin = ptr(P.stem);
+  for (int st = 0; st < 4; ++st) {
+    const int h = H >> (st + 2), w = W >> (st + 2);
+    const PolicyConv* L = &N.conv[1 + 4 * st];
+    PNPX_TRY(launch_conv3x3_policy(L[0], xin, ptr(P.t1[st]), ptr(P.sc[st]), nullptr, false, B, h, w, s));
+    PNPX_TRY(launch_conv3x3_policy(L[1], ptr(P.t1[st]), ptr(P.o0[st]), nullptr, ptr(P.sc[st]), false, B, h, w, s));
+    PNPX_TRY(launch_conv3x3_policy(L[2], ptr(P.o0[st]), ptr(P.t2[st]), nullptr, nullptr, false, B, h, w, s));
+    PNPX_TRY(launch_conv3x3_policy(L[3], ptr(P.t2[st]), ptr(P.o1[st]), nullptr, ptr(P.o0[st]), st < 3, B, h, w, s));
+    xin = ptr(P.o1[st]);
+  }
+  hipLaunchKernelGGL(pool_heads_kernel, dim3(B), dim3(256), 0, s, ptr(P.o1[3]), H / 32, W / 32, N.fc_sm_w, N.fc_sm_b,
+                     N.fc_det_w, N.fc_det_b, N.fc_det2_w, N.fc_det2_b, N.n_det, N.spi_head, probs, det);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+
+}  // namespace pnpx

@@ -1,13 +1,20 @@
-"""The caller contract of the hot path: a minimal PnPEnv (tfpnp/env/base.py:121-191, 237-242).
+"""PnPEnv -- the caller of the hot path, mirror of tfpnp/env/base.py:43-242 (same constructor, `reset` / `step` /
+`forward` / `get_images` signatures and return values) so the reference's trainer / evaluator loops drive it unchanged.
 
-Only what SURVEY.md section 8(b) lists is reproduced: live-row gather (`idx_left`), the solver call, state /
-output write-back, delta-PSNR reward and the idx_left shrink, plus the differentiable `forward` used by the
-actor/critic update (base.py:193-206).  Observation packing for the RL policy, the policy itself and the trainer are
-out of scope.  `metric_fn` runs natively (pnpx_psnr; analytic VJP under autograd).
+What happens per `step` (base.py:157-191): gather the live rows `idx_left`, run the native solver under no_grad, write
+state / output back, delta-PSNR reward over the whole batch (native pnpx_psnr), build the observation of the rows that
+were live, shrink `idx_left` by `idx_stop`, build the observation of the rows still live.  `forward` (base.py:193-206) is
+the differentiable one-step model used by the actor / critic update (native VJPs, see tfpnp_amd/autograd.py).
+
+The four task environments of the reference (tasks/*/env.py) differ only in which state entries make up the
+observation and how they are packed for the policy; here that is data (class attributes), not four copies of the code.
 """
+import numpy as np
 import torch
 
 from .. import ops
+from ..data.batch import Batch
+from ..utils import transforms
 
 
 class _Psnr(torch.autograd.Function):
@@ -37,8 +44,26 @@ def torch_psnr(output, gt):
     return ops.psnr(output, gt)
 
 
+def torch2img255(img):
+    """tfpnp/utils/misc.py:9-12"""
+    return np.clip(img.detach().cpu().numpy(), 0, 1) * 255
+
+
 class PnPEnv:
-    def __init__(self, solver, max_episode_step, aux_keys=None):
+    # ---- task description (overridden by tasks/*: CSMRIEnv, PREnv, CTEnv, SPIEnv)
+    ob_base_dim = 0          # channels of the policy observation besides the solver variables
+    ob_keys = ()             # state entries copied into the observation (besides gt / variables / T)
+    float_keys = ()          # ... of which these are cast to float (bool masks)
+    policy_layout = ()       # (key, 'real' | 'channel' | 'raw') in channel order of get_policy_ob
+    input_key = None         # observation entry shown as the "input" image
+    aux_keys = ()            # solver aux inputs, in order
+    aux_bool = ()            # ... of which these are handed over as bool
+
+    def __init__(self, data_loader, solver, max_episode_step, data_transform=None):
+        self.data_loader = data_loader
+        self.data_iterator = iter(data_loader) if data_loader is not None else None
+        self.device = torch.device('cpu')
+        self.data_transform = data_transform
         self.solver = solver
         self.max_episode_step = max_episode_step
         self.cur_step = 0
@@ -46,22 +71,71 @@ class PnPEnv:
         self.idx_left = None
         self.last_metric = 0
         self.metric_fn = torch_psnr
-        self.aux_keys = aux_keys
 
-    def reset(self, data):
-        """data: dict of device tensors with at least x0, gt, output + the solver's aux inputs.  base.py:121-155"""
+    # ------------------------------------------------------------------ observation plumbing (tasks/*/env.py)
+    def get_policy_ob(self, ob):
+        parts = []
+        for key, kind in self.policy_layout:
+            v = ob[key]
+            if kind == 'real':
+                v = transforms.complex2real(v)
+            elif kind == 'channel':
+                v = transforms.complex2channel(v)
+            parts.append(v)
+        return torch.cat(parts, 1)
+
+    def get_eval_ob(self, ob):
+        return self.get_policy_ob(ob)
+
+    def _get_attribute(self, ob, key):
+        if key == 'gt':
+            return ob.gt
+        if key == 'output':
+            return self.solver.get_output(ob.variables)
+        if key == 'input':
+            return ob[self.input_key]
+        if key == 'solver_input':
+            return ob.variables, tuple(ob[k].bool() if k in self.aux_bool else ob[k] for k in self.aux_keys)
+        raise NotImplementedError('key is not supported, ' + str(key))
+
+    def _build_next_ob(self, ob, solver_state):
+        nxt = Batch({k: ob[k] for k in ('gt',) + tuple(self.ob_keys)})
+        nxt.update(variables=solver_state, T=ob.T + 1 / self.max_episode_step)
+        return nxt
+
+    def _observation(self):
+        il = self.idx_left
+        ob = Batch(gt=self.state['gt'][il, ...], variables=self.state['solver'][il, ...], T=self.state['T'][il, ...])
+        for k in self.ob_keys:
+            v = self.state[k][il, ...]
+            ob[k] = v.float() if k in self.float_keys else v
+        return ob
+
+    # ------------------------------------------------------------------ basic API (tfpnp/env/base.py:121-206)
+    def reset(self, data=None):
         self.cur_step = 0
-        data = dict(data)
+        if data is None:
+            try:
+                data = next(self.data_iterator)
+            except StopIteration:
+                self.data_iterator = iter(self.data_loader)
+                data = next(self.data_iterator)
+        if self.data_transform is not None:
+            data = self.data_transform(data)
+        data = {k: (v.to(self.device) if isinstance(v, torch.Tensor) and self.device.type != 'cpu' else v)
+                for k, v in dict(data).items()}
         data['solver'] = self.solver.reset(data)
-        data['output'] = data['output'].clone()
+        if 'output' in data:
+            data['output'] = data['output'].clone()
+        B, _, H, W = data['gt'].shape
+        dev = data['gt'].device
+        data['T'] = torch.full((B, 1, H, W), self.cur_step / self.max_episode_step, dtype=torch.float32, device=dev)
         self.state = data
-        B = data['gt'].shape[0]
-        self.idx_left = torch.arange(0, B, device=data['gt'].device)
+        self.idx_left = torch.arange(0, B, device=dev)
         self.last_metric = self._compute_metric()
-        return self.state
+        return self._observation()
 
     def step(self, action):
-        """base.py:157-191.  action: dict of [n_live, action_pack] tensors + 'idx_stop' [n_live]."""
         self.cur_step += 1
         il = self.idx_left
         with torch.no_grad():
@@ -69,9 +143,11 @@ class PnPEnv:
             inputs = (self.state['solver'][il, ...], aux)
             parameters = self.solver.filter_hyperparameter(action)
             solver_state = self.solver(inputs, parameters)
+        self.state['T'] = torch.full_like(self.state['T'], self.cur_step / self.max_episode_step)
         self.state['output'][il, ...] = self.solver.get_output(solver_state)
         self.state['solver'][il, ...] = solver_state
         reward = self._compute_reward()
+        ob = self._observation()
         idx_stop = action['idx_stop']
         self.idx_left = il[idx_stop == 0]
         all_done = len(self.idx_left) == 0
@@ -79,20 +155,29 @@ class PnPEnv:
         if self.cur_step == self.max_episode_step:
             all_done = True
             done = torch.ones_like(idx_stop)
-        return reward, all_done, {'done': done}
+        ob_masked = self._observation()
+        return ob, ob_masked, reward, all_done, {'done': done}
 
-    def forward(self, state, action):
-        """Differentiable one-step model of the environment used by the actor/critic update
-        (tfpnp/env/base.py:193-206; called from tfpnp/trainer/mddpg/trainer.py:171-192).  `state` is the dict form of
-        the observation (keys 'solver', 'output', 'gt' + the solver's aux inputs; the reference packs the same
-        tensors channel-wise, base.py:208-231); returns (next solver state, delta-PSNR reward [B,1]).  Gradients
-        flow into whatever `action` / `state` tensors require them."""
-        inputs = (state['solver'], tuple(self.solver.filter_aux_inputs(state)))
+    def forward(self, ob, action):
+        """Differentiable one-step model (base.py:193-206): gradients flow into `action` / `ob` tensors that require
+        them.  -> (next observation, delta-PSNR reward [B,1])"""
+        output = self._get_attribute(ob, 'output')
+        gt = self._get_attribute(ob, 'gt')
+        inputs = self._get_attribute(ob, 'solver_input')
         parameters = self.solver.filter_hyperparameter(action)
         solver_state = self.solver(inputs, parameters)
         output2 = self.solver.get_output(solver_state)
-        reward = self.metric_fn(output2, state['gt']) - self.metric_fn(state['output'], state['gt'])
-        return solver_state, reward
+        reward = self.metric_fn(output2, gt) - self.metric_fn(output, gt)
+        return self._build_next_ob(ob, solver_state), reward
+
+    def get_images(self, ob, pre_process=torch2img255):
+        return tuple(pre_process(self._get_attribute(ob, k)) for k in ('input', 'output', 'gt'))
+
+    def to(self, device):
+        if not isinstance(device, torch.device):
+            raise TypeError('device must be torch.device, but got {}'.format(type(device)))
+        self.device = device
+        return self
 
     def _compute_metric(self):
         return self.metric_fn(self.state['output'].detach(), self.state['gt'])

@@ -25,6 +25,7 @@ class Context:
         check(_lib.lib().pnpx_ctx_create(self.device.index, C.byref(h)))
         self._h = h
         self._has_weights = False
+        self._policy = None
 
     @property
     def handle(self):
@@ -47,6 +48,23 @@ class Context:
         flat = np.concatenate(chunks)
         check(_lib.lib().pnpx_unet_load(self.handle, flat.ctypes.data_as(C.c_void_p), flat.size))
         self._has_weights = True
+
+    def load_policy(self, state_dict, num_inputs, n_det, spi_head=False):
+        """state_dict with the reference's ResNetActor_* key names (tfpnp/policy/network.py) -> native actor."""
+        from .synth import policy_param_specs
+        chunks = []
+        for key, shape in policy_param_specs(num_inputs, n_det, spi_head):
+            if key not in state_dict:
+                raise PnpxError(f"policy state_dict is missing '{key}'")
+            v = state_dict[key]
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if tuple(v.shape) != tuple(shape):
+                raise PnpxError(f"'{key}' has shape {tuple(v.shape)}, expected {tuple(shape)}")
+            chunks.append(np.ascontiguousarray(v, dtype=np.float32).reshape(-1))
+        flat = np.concatenate(chunks)
+        check(_lib.lib().pnpx_policy_load(self.handle, flat.ctypes.data_as(C.c_void_p), flat.size, int(num_inputs),
+                                          int(n_det), int(bool(spi_head))))
+        self._policy = (int(num_inputs), int(n_det))
 
     def set_option(self, key, value):
         """e.g. set_option('conv_mode', 0) selects the plain-fp32 MFMA convolutions (default 1 = half-split f16)."""
@@ -162,6 +180,19 @@ def unet_denoise_backward(ctx, x, sigma, grad_out):
         check(_lib.lib().pnpx_unet_denoise_backward(ctx.handle, _p(x), _p(sigma), _p(grad_out), _p(gx), _p(gs), B, H, W,
                                                     _stream(x)))
     return gx, gs
+
+
+def policy_forward(ctx, ob):
+    """ob [B,C,H,W] -> (probs [B,2], det [B,n_det]) of the loaded actor (eval mode)."""
+    ob = _f32(ob, "ob")
+    if ob.dim() != 4 or getattr(ctx, "_policy", None) is None or ob.shape[1] != ctx._policy[0]:
+        raise PnpxError("policy_forward: no policy loaded or observation has the wrong channel count")
+    B, _, H, W = ob.shape
+    probs = torch.empty((B, 2), device=ob.device, dtype=torch.float32)
+    det = torch.empty((B, ctx._policy[1]), device=ob.device, dtype=torch.float32)
+    with torch.cuda.device(ob.device):
+        check(_lib.lib().pnpx_policy_forward(ctx.handle, _p(ob), _p(probs), _p(det), B, H, W, _stream(ob)))
+    return probs, det
 
 
 def unet_profile(ctx, x, sigma):

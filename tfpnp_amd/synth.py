@@ -68,6 +68,59 @@ def flatten_params(params):
     return np.concatenate([params[k].reshape(-1) for k, _ in unet_param_specs()]).astype(np.float32)
 
 
+# --------------------------------------------------------------------------- policy actor parameters
+def policy_param_specs(num_inputs, n_det, spi_head=False):
+    """(key, shape) of the fp32 entries of ResNetActorBase.state_dict() in registration order
+    (tfpnp/policy/network.py:87-147; integer num_batches_tracked entries are not listed)."""
+    specs = []
+
+    def bn(prefix, c):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            specs.append((f"{prefix}.{k}", (c,)))
+
+    specs.append(("actor_encoder.conv1.weight", (64, num_inputs, 3, 3)))
+    bn("actor_encoder.bn1", 64)
+    in_planes = 64
+    for li, planes in enumerate((64, 128, 256, 512), start=1):
+        for blk in range(2):
+            pre = f"actor_encoder.layer{li}.{blk}"
+            cin = in_planes if blk == 0 else planes
+            specs.append((f"{pre}.conv1.weight", (planes, cin, 3, 3)))
+            bn(f"{pre}.bn1", planes)
+            specs.append((f"{pre}.conv2.weight", (planes, planes, 3, 3)))
+            bn(f"{pre}.bn2", planes)
+            if blk == 0:
+                specs.append((f"{pre}.shortcut.0.weight", (planes, in_planes, 1, 1)))
+                bn(f"{pre}.shortcut.1", planes)
+        in_planes = planes
+    specs += [("fc_softmax.0.weight", (2, 512)), ("fc_softmax.0.bias", (2,))]
+    if spi_head:
+        specs += [("fc_deterministic.0.weight", (64, 512)), ("fc_deterministic.0.bias", (64,)),
+                  ("fc_deterministic.2.weight", (n_det, 64)), ("fc_deterministic.2.bias", (n_det,))]
+    else:
+        specs += [("fc_deterministic.0.weight", (n_det, 512)), ("fc_deterministic.0.bias", (n_det,))]
+    return specs
+
+
+def make_policy_params(num_inputs, n_det, spi_head=False, seed=0):
+    """Synthetic actor weights with non-trivial BatchNorm statistics (no trained actor checkpoint ships with the
+    reference): He-normal convolutions, gamma ~ U(0.5,1.5), beta, running_mean ~ N(0,0.1^2), running_var ~ U(0.5,1.5),
+    heads ~ N(0, 0.01/fan_in) (keeps softmax / sigmoid away from saturation)."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for key, shape in policy_param_specs(num_inputs, n_det, spi_head):
+        if len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            out[key] = (rs.standard_normal(shape) * math.sqrt(2.0 / fan_in)).astype(np.float32)
+        elif len(shape) == 2:
+            out[key] = (rs.standard_normal(shape) * 0.1 * math.sqrt(1.0 / shape[1])).astype(np.float32)
+        elif key.endswith("running_var") or (key.endswith(".weight") and ".bn" in key or ".shortcut.1.weight" in key):
+            out[key] = rs.uniform(0.5, 1.5, shape).astype(np.float32)
+        else:
+            out[key] = (rs.standard_normal(shape) * 0.1).astype(np.float32)
+    return out
+
+
 # --------------------------------------------------------------------------- images
 def phantom(H, W, seed):
     """Smooth ellipse phantom in [0,1], float32 [H,W]."""

@@ -8,6 +8,7 @@ import torch
 
 from .. import autograd as A
 from .. import ops
+from ..env.base import PnPEnv
 from ..pnp.solver.base import ADMMSolver, HQSSolver, PGSolver, APGSolver, REDADMMSolver, AMPSolver
 from ..utils import transforms
 
@@ -145,3 +146,16 @@ def create_solver_csmri(opt, denoiser):
     if opt.solver in _solver_map:
         return _solver_map[opt.solver](denoiser)
     raise NotImplementedError
+
+
+class CSMRIEnv(PnPEnv):
+    """tasks/csmri/env.py:7-56.  Policy observation (9 channels for 3-variable solvers): Re(variables), y0 as 2
+    channels, Re(ATy0), mask, T, Re(sigma_n)."""
+    ob_base_dim = 6
+    ob_keys = ('y0', 'ATy0', 'mask', 'sigma_n')
+    float_keys = ('mask',)
+    policy_layout = (('variables', 'real'), ('y0', 'channel'), ('ATy0', 'real'), ('mask', 'raw'), ('T', 'raw'),
+                     ('sigma_n', 'real'))
+    input_key = 'ATy0'
+    aux_keys = ('y0', 'mask')
+    aux_bool = ('mask',)

@@ -3,6 +3,7 @@ import torch
 
 from .. import autograd as A
 from .. import ops
+from ..env.base import PnPEnv
 from ..pnp.solver.base import IADMMSolver, PGSolver
 from ..utils.transforms import RadonGenerator
 
@@ -68,3 +69,12 @@ def create_solver_ct(opt, denoiser):
     if opt.solver in _solver_map:
         return _solver_map[opt.solver](denoiser)
     raise NotImplementedError
+
+
+class CTEnv(PnPEnv):
+    """tasks/ct/env.py:6-55.  Observation: variables, ATy0, view, T, sigma_n."""
+    ob_base_dim = 4
+    ob_keys = ('y0', 'ATy0', 'view', 'sigma_n')
+    policy_layout = (('variables', 'raw'), ('ATy0', 'raw'), ('view', 'raw'), ('T', 'raw'), ('sigma_n', 'raw'))
+    input_key = 'ATy0'
+    aux_keys = ('y0', 'view')

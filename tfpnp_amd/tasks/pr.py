@@ -3,6 +3,7 @@ import torch
 
 from .. import autograd as A
 from .. import ops
+from ..env.base import PnPEnv
 from ..pnp.solver.base import IADMMSolver, PGSolver
 from ..utils.transforms import complex2real, real2complex
 
@@ -64,3 +65,13 @@ def create_solver_pr(opt, denoiser):
     if opt.solver in _solver_map:
         return _solver_map[opt.solver](denoiser)
     raise NotImplementedError
+
+
+class PREnv(PnPEnv):
+    """tasks/pr/env.py:7-56.  Observation: Re(variables), y0 [S], mask as 2S channels, T, sigma_n  (S = 4 -> 14 + 3)."""
+    ob_base_dim = 14
+    ob_keys = ('y0', 'x0', 'mask', 'sigma_n')
+    float_keys = ('mask',)
+    policy_layout = (('variables', 'real'), ('y0', 'raw'), ('mask', 'channel'), ('T', 'raw'), ('sigma_n', 'raw'))
+    input_key = 'x0'
+    aux_keys = ('y0', 'mask')

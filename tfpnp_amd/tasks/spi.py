@@ -3,6 +3,7 @@ import torch
 
 from .. import autograd as A
 from .. import ops
+from ..env.base import PnPEnv
 from ..pnp.solver.base import ADMMSolver
 
 
@@ -45,3 +46,12 @@ def create_solver_spi(opt, denoiser):
     if opt.solver in _solver_map:
         return _solver_map[opt.solver](denoiser)
     raise NotImplementedError
+
+
+class SPIEnv(PnPEnv):
+    """tasks/spi/env.py:7-52.  Observation: variables, x0, K, T."""
+    ob_base_dim = 3
+    ob_keys = ('x0', 'K')
+    policy_layout = (('variables', 'raw'), ('x0', 'raw'), ('K', 'raw'), ('T', 'raw'))
+    input_key = 'x0'
+    aux_keys = ('x0', 'K')
