@@ -76,10 +76,12 @@ enum ConvMode { CONV_F32 = 0, CONV_HS = 1 };
 // Policy actor (ResNet-18 encoder + heads, eval mode) -- policy.hip.  One PolicyConv per launch: BatchNorm is folded
 // into weights/bias at load time; stride-2 convolutions run as stride-1 convolutions over a space-to-depth input
 // with per-(cout tile, K-chunk) tap masks; the 1x1 stride-2 shortcut rides in the same launch as extra cout tiles.
+struct PolStep;
 struct PolicyConv {
-  const float* w = nullptr;              // device: [cout/64][cin/8][9][8][64]
+  const float* w = nullptr;              // device: present tap slices [8][64], in PolStep order
   const float* bias = nullptr;           // device: [cout]
-  const unsigned short* tapmask = nullptr;  // device: [cout/64][cin/8]
+  const PolStep* steps = nullptr;        // device: [cout/64][cin/8] (first nsteps[ct] entries of each row valid)
+  const int* nsteps = nullptr;           // device: [cout/64]
   int cin = 0;      // K channels of the (possibly space-to-depth) input, multiple of 8
   int cout = 0;     // output channels over both outputs, multiple of 64
   int split_c = 0;  // channels written to the first output (ReLU); the rest go to the second output (linear)

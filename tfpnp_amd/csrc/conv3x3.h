@@ -19,14 +19,6 @@ struct ConvArgs {
   // the saved forward activation that this gradient flows into (same [B][Cout][Hp][Wp] geometry as `out`)
   int mode;
   const float* dmask;
-  // ---- policy-network variant only (template POL, launch_conv3x3_policy; mode 3):
-  //   v = acc + bias[c] (+ res[same position]);  ReLU unless the cout tile is >= split (linear shortcut branch);
-  //   cout tiles >= split are written to out2 (channel index restarts at 0);  s2d: the output is stored
-  //   space-to-depth ([4*C][H/2][W/2], channel = (y&1)*2+(x&1) major) for a following stride-2 convolution.
-  const unsigned short* tapmask = nullptr;  // [nct][nch] bit t set = tap t of that K-chunk is non-zero
-  const float* res = nullptr;
-  float* out2 = nullptr;
-  int split = 0, C_out1 = 0, C_out2 = 0, s2d = 0;
 };
 
 int conv_pack_mt(int cout);
@@ -37,9 +29,6 @@ int launch_conv3x3(const ConvLayer& L, const float* in0, int C0, const float* in
 // Input-gradient convolution: L holds the transposed, tap-flipped weights (pack_conv_weights_transposed).
 int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const float* dmask, int B, int H, int W,
                         hipStream_t s);
-// Policy-network convolution (PolicyConv: common.h; epilogue: see ConvArgs).
-int launch_conv3x3_policy(const PolicyConv& L, const float* in, float* out, float* out2, const float* res, bool s2d,
-                          int B, int H, int W, hipStream_t s);
 // w[cout][cin][3][3] -> packed weights of the adjoint convolution: wt[ci][co][tap] = w[co][ci][8 - tap], with the
 // adjoint's output channels (= cin) zero-padded to cout_pad.
 void pack_conv_weights_transposed(const float* w, int cout, int cin, int cout_pad, int mt, int cc, float* dst);

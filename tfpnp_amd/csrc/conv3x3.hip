@@ -59,7 +59,7 @@ struct ConvGeom {
   static constexpr int MTB = MT / 32;
 };
 
-template <int MT, int NBW, int CC, int MBW, bool POL = false>
+template <int MT, int NBW, int CC, int MBW>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   using G = ConvGeom<MT, NBW, CC, MBW>;
   __shared__ __attribute__((aligned(16))) float lds[2 * G::STAGE];
@@ -143,8 +143,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     float* nstage = lds + ((ch + 1) & 1) * G::STAGE;
     const float* lin = lds + (ch & 1) * G::STAGE + b_lane;
     const float* lw = lds + (ch & 1) * G::STAGE + G::IN_PAD + a_lane;
-    // policy variant: K-chunks of a space-to-depth input (and of the fused 1x1 shortcut) use only some taps
-    const unsigned tmask = POL ? __builtin_amdgcn_readfirstlane((unsigned)a.tapmask[ct * nch + ch]) : 0x1ffu;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
@@ -152,7 +150,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int sl = tap; sl < NS; sl += 9) issue_slot(sl, nsrc, nw, nstage);
       }
-      if (POL && !((tmask >> tap) & 1u)) continue;
 #pragma unroll
       for (int cp = 0; cp < CC / 2; ++cp) {
         float av[G::MTB], bv[NBW];
@@ -167,43 +164,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
       }
     }
-  }
-
-  if constexpr (POL) {
-    // ---- policy epilogue: folded-BN bias (+ residual) + ReLU (linear for the shortcut tiles), optional
-    //      space-to-depth store
-    const bool second = ct >= a.split;
-    float* obase = second ? a.out2 : a.out;
-    const int Cthis = second ? a.C_out2 : a.C_out1;
-    const int c0 = (second ? ct - a.split : ct) * MT;
-    const int Hh = a.H >> 1, Wh = a.W >> 1;
-    const int Hp2 = padded_h(Hh), Wp2 = padded_w(Wh);
-#pragma unroll
-    for (int m = 0; m < G::MTB; ++m) {
-#pragma unroll
-      for (int n = 0; n < NBW; ++n) {
-        const int y = y0 + (wave * NBW + n) * G::MBH + py;
-        const int x = x0 + px;
-        if (y < a.H && x < a.W) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int cl = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            const int c = c0 + cl;
-            float v = acc[m][n][r] + a.bias[ct * MT + cl];
-            const size_t off = (((size_t)b * Cthis + c) * a.Hp + (y + 1)) * a.Wp + x + PADL;
-            if (a.res) v += a.res[off];
-            if (!second) v = fmaxf(v, 0.f);
-            if (a.s2d) {
-              const int ph = (y & 1) * 2 + (x & 1);
-              obase[(((size_t)b * 4 * Cthis + ph * Cthis + c) * Hp2 + (y >> 1) + 1) * Wp2 + (x >> 1) + PADL] = v;
-            } else {
-              obase[off] = v;
-            }
-          }
-        }
-      }
-    }
-    return;
   }
 
   // ---- epilogue: bias + LeakyReLU, coalesced row stores into the padded output
@@ -234,19 +194,19 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   }
 }
 
-template <int MT, int NBW, int CC, int MBW, bool POL = false>
+template <int MT, int NBW, int CC, int MBW>
 static int launch_cfg(const ConvArgs& a0, int B, hipStream_t s) {
   using G = ConvGeom<MT, NBW, CC, MBW>;
   ConvArgs a = a0;
   a.tilesX = (a.W + G::TW - 1) / G::TW;
   a.tilesY = (a.H + G::TH - 1) / G::TH;
   const long long grid = (long long)a.nct * a.tilesX * a.tilesY * B;
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<MT, NBW, CC, MBW, POL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<MT, NBW, CC, MBW>), dim3((unsigned)grid), dim3(256), 0, s, a);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
 
-template <int MT, int CC, bool POL = false>
+template <int MT, int CC>
 static int launch_mt_cc(const ConvArgs& a, int B, hipStream_t s) {
   // pixel-block shape by image width; 2 blocks per wave unless the grid would be too small to fill
   // 256 CUs twice over.
@@ -256,11 +216,9 @@ static int launch_mt_cc(const ConvArgs& a, int B, hipStream_t s) {
     return (long long)a.nct * ((a.W + mbw - 1) / mbw) * ((a.H + th - 1) / th) * B;
   };
   const int nbw = (blocks(2) >= 1024) ? 2 : 1;
-  if (mbw == 32)
-    return nbw == 2 ? launch_cfg<MT, 2, CC, 32, POL>(a, B, s) : launch_cfg<MT, 1, CC, 32, POL>(a, B, s);
-  if (mbw == 16)
-    return nbw == 2 ? launch_cfg<MT, 2, CC, 16, POL>(a, B, s) : launch_cfg<MT, 1, CC, 16, POL>(a, B, s);
-  return nbw == 2 ? launch_cfg<MT, 2, CC, 8, POL>(a, B, s) : launch_cfg<MT, 1, CC, 8, POL>(a, B, s);
+  if (mbw == 32) return nbw == 2 ? launch_cfg<MT, 2, CC, 32>(a, B, s) : launch_cfg<MT, 1, CC, 32>(a, B, s);
+  if (mbw == 16) return nbw == 2 ? launch_cfg<MT, 2, CC, 16>(a, B, s) : launch_cfg<MT, 1, CC, 16>(a, B, s);
+  return nbw == 2 ? launch_cfg<MT, 2, CC, 8>(a, B, s) : launch_cfg<MT, 1, CC, 8>(a, B, s);
 }
 
 int conv_pack_mt(int cout) { return cout >= 64 ? 64 : 32; }
@@ -319,38 +277,6 @@ int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const
   }
   if (L.mt == 64) return launch_mt_cc<64, 8>(a, B, s);
   return launch_mt_cc<32, 8>(a, B, s);
-}
-
-int launch_conv3x3_policy(const PolicyConv& L, const float* in, float* out, float* out2, const float* res, bool s2d,
-                          int B, int H, int W, hipStream_t s) {
-  if (L.cin % 8 != 0 || L.cout % 64 != 0 || L.split_c % 64 != 0 || (s2d && ((H | W) & 1))) {
-    set_error("policy conv: unsupported geometry (cin %d cout %d split %d H %d W %d)", L.cin, L.cout, L.split_c, H, W);
-    return PNPX_ERR_SHAPE;
-  }
-  ConvArgs a;
-  a.in0 = in;
-  a.C0 = L.cin;
-  a.in1 = in;
-  a.C1 = 0;
-  a.wpk = L.w;
-  a.bias = L.bias;
-  a.out = out;
-  a.H = H;
-  a.W = W;
-  a.Hp = padded_h(H);
-  a.Wp = padded_w(W);
-  a.nct = L.cout / 64;
-  a.slope = 0.f;
-  a.mode = 3;
-  a.dmask = nullptr;
-  a.tapmask = L.tapmask;
-  a.res = res;
-  a.out2 = out2;
-  a.split = L.split_c / 64;
-  a.C_out1 = L.split_c;
-  a.C_out2 = L.cout - L.split_c;
-  a.s2d = s2d ? 1 : 0;
-  return launch_mt_cc<64, 8, true>(a, B, s);
 }
 
 void pack_conv_weights_transposed(const float* w, int cout, int cin, int cout_pad, int mt, int cc, float* dst) {

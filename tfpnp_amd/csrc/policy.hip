@@ -9,7 +9,7 @@
 // both the rollout, trainer.py:216-221, and the evaluator, evaluator.py:23, run the actor that way).  Sampling /
 // arg-max of idx_stop, log-probabilities and the action range mapping stay in the host mirror (O(B) scalars).
 //
-// MI355X design: every convolution is one launch of the fp32 MFMA kernel (conv3x3.hip, POL variant):
+// MI355X design: every convolution is one launch of the fp32 MFMA kernel in policy_conv.hip:
 //   * BatchNorm folded into weights and bias on the host; ReLU / residual add in the epilogue.
 //   * stride-2 3x3 convolutions read a SPACE-TO-DEPTH copy of their input ([4*C][H/2][W/2], written directly by the
 //     producer's epilogue): on that grid the convolution is stride 1, and of the 36 (phase, tap) pairs only 9 are
@@ -20,7 +20,7 @@
 #include <cstring>
 
 #include "common.h"
-#include "conv3x3.h"
+#include "policy_conv.h"
 
 namespace pnpx {
 namespace {
@@ -174,33 +174,50 @@ struct HostBlob {
   }
 };
 struct ConvOff {
-  size_t w, bias, mask;
+  size_t w, bias, steps, nsteps;
 };
+// Pack one launch: per cout tile the list of K-chunks that carry any weight (PolStep), and only their present tap
+// slices [8 channels][64 couts], in list order.  Presence is decided on the values (an all-zero slice contributes
+// exactly nothing).
 ConvOff pack_eff(HostBlob& H, Eff& E) {
   const int nct = E.cout / 64, nch = E.K / 8;
   ConvOff o;
   H.align();
   o.w = H.f.size();
-  H.f.resize(H.f.size() + (size_t)E.cout * E.K * 9);
-  std::vector<unsigned short> mask((size_t)nct * nch, 0);
-  float* dst = H.f.data() + o.w;
+  std::vector<PolStep> steps((size_t)nct * nch, PolStep{0, 0, 0});
+  std::vector<int> nsteps(nct, 0);
+  std::vector<float> slice(512);
+  unsigned int nslices = 0;
   for (int ct = 0; ct < nct; ++ct)
-    for (int ch = 0; ch < nch; ++ch)
+    for (int ch = 0; ch < nch; ++ch) {
+      unsigned short mask = 0;
+      const unsigned int first = nslices;
       for (int tap = 0; tap < 9; ++tap) {
         bool any = false;
         for (int c = 0; c < 8; ++c)
           for (int m = 0; m < 64; ++m) {
             const float v = E.at(ct * 64 + m, ch * 8 + c, tap);
             any |= (v != 0.f);
-            dst[((((size_t)ct * nch + ch) * 9 + tap) * 8 + c) * 64 + m] = v;
+            slice[c * 64 + m] = v;
           }
-        if (any) mask[(size_t)ct * nch + ch] |= (unsigned short)(1u << tap);
+        if (!any) continue;
+        mask |= (unsigned short)(1u << tap);
+        H.f.insert(H.f.end(), slice.begin(), slice.end());
+        ++nslices;
       }
+      if (mask) steps[(size_t)ct * nch + nsteps[ct]++] = PolStep{mask, (unsigned short)ch, first};
+    }
+  H.f.resize(H.f.size() + 1024, 0.f);   // the 16-byte DMA of the last slice may not over-read, but keep a guard
   o.bias = H.add(E.bias.data(), E.bias.size());
+  static_assert(sizeof(PolStep) == 8, "PolStep layout");
   H.align();
-  o.mask = H.f.size();
-  H.f.resize(H.f.size() + (mask.size() + 1) / 2, 0.f);
-  std::memcpy(H.f.data() + o.mask, mask.data(), mask.size() * sizeof(unsigned short));
+  o.steps = H.f.size();
+  H.f.resize(H.f.size() + steps.size() * 2, 0.f);
+  std::memcpy(H.f.data() + o.steps, steps.data(), steps.size() * sizeof(PolStep));
+  H.align();
+  o.nsteps = H.f.size();
+  H.f.resize(H.f.size() + nsteps.size(), 0.f);
+  std::memcpy(H.f.data() + o.nsteps, nsteps.data(), nsteps.size() * sizeof(int));
   return o;
 }
 
@@ -353,7 +370,8 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
   for (int i = 0; i < 17; ++i) {
     N.conv[i].w = base + off[i].w;
     N.conv[i].bias = base + off[i].bias;
-    N.conv[i].tapmask = reinterpret_cast<const unsigned short*>(base + off[i].mask);
+    N.conv[i].steps = reinterpret_cast<const PolStep*>(base + off[i].steps);
+    N.conv[i].nsteps = reinterpret_cast<const int*>(base + off[i].nsteps);
     N.conv[i].cin = cins[i];
     N.conv[i].cout = couts[i];
     N.conv[i].split_c = splits[i];
@@ -409,15 +427,15 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
   hipLaunchKernelGGL(pack_ob_s2d_kernel, g1(n), dim3(256), 0, s, ob, ptr(P.ob), N.num_inputs, N.cin_pad, H, W, n);
   PNPX_LAUNCH_CHECK();
   // stem (on the H/2 grid) -> space-to-depth for stage 1
-  PNPX_TRY(launch_conv3x3_policy(N.conv[0], ptr(P.ob), ptr(P.stem), nullptr, nullptr, true, B, H / 2, W / 2, s));
+  PNPX_TRY(launch_policy_conv(N.conv[0], ptr(P.ob), ptr(P.stem), nullptr, nullptr, true, B, H / 2, W / 2, s));
   const float* xin = ptr(P.stem);
   for (int st = 0; st < 4; ++st) {
     const int h = H >> (st + 2), w = W >> (st + 2);
     const PolicyConv* L = &N.conv[1 + 4 * st];
-    PNPX_TRY(launch_conv3x3_policy(L[0], xin, ptr(P.t1[st]), ptr(P.sc[st]), nullptr, false, B, h, w, s));
-    PNPX_TRY(launch_conv3x3_policy(L[1], ptr(P.t1[st]), ptr(P.o0[st]), nullptr, ptr(P.sc[st]), false, B, h, w, s));
-    PNPX_TRY(launch_conv3x3_policy(L[2], ptr(P.o0[st]), ptr(P.t2[st]), nullptr, nullptr, false, B, h, w, s));
-    PNPX_TRY(launch_conv3x3_policy(L[3], ptr(P.t2[st]), ptr(P.o1[st]), nullptr, ptr(P.o0[st]), st < 3, B, h, w, s));
+    PNPX_TRY(launch_policy_conv(L[0], xin, ptr(P.t1[st]), ptr(P.sc[st]), nullptr, false, B, h, w, s));
+    PNPX_TRY(launch_policy_conv(L[1], ptr(P.t1[st]), ptr(P.o0[st]), nullptr, ptr(P.sc[st]), false, B, h, w, s));
+    PNPX_TRY(launch_policy_conv(L[2], ptr(P.o0[st]), ptr(P.t2[st]), nullptr, nullptr, false, B, h, w, s));
+    PNPX_TRY(launch_policy_conv(L[3], ptr(P.t2[st]), ptr(P.o1[st]), nullptr, ptr(P.o0[st]), st < 3, B, h, w, s));
     xin = ptr(P.o1[st]);
   }
   hipLaunchKernelGGL(pool_heads_kernel, dim3(B), dim3(256), 0, s, ptr(P.o1[3]), H / 32, W / 32, N.fc_sm_w, N.fc_sm_b,

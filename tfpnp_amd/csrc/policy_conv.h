@@ -1,0 +1,18 @@
+// Convolution kernel of the policy actor (policy_conv.hip).
+#pragma once
+#include "common.h"
+
+namespace pnpx {
+
+// One (cout tile, K-chunk) work item of a policy convolution: which of the 9 taps are non-zero and where their
+// weights live.  Only chunks with a non-zero mask are listed, only present taps are stored.
+struct PolStep {
+  unsigned short mask;    // bit t = tap t present
+  unsigned short chunk;   // K-chunk index (8 input channels)
+  unsigned int wofs;      // offset of the first present tap slice, in 512-float ([8][64]) slices
+};
+
+int launch_policy_conv(const PolicyConv& L, const float* in, float* out, float* out2, const float* res, bool s2d, int B,
+                       int H, int W, hipStream_t s);
+
+}  // namespace pnpx
