@@ -109,6 +109,36 @@ class Radon_norm:
     def normal_operator(self, x):
         return self.backprojection_norm(self.forward(x))
 
+    def filter_sinogram(self, sinogram, filter_name='ramp'):
+        """Ramp-filter every projection along the detector axis (torch_radon.Radon.filter_sinogram as used by
+        transforms.py:479-481): zero-pad to max(64, next power of two >= 2*det), multiply the spectrum by the
+        Kak-Slaney ramp (the DFT of the band-limited spatial kernel, not |f|), crop, scale by pi / (2 * n_views).
+        The 1-D FFTs are native (H = 1 images)."""
+        if filter_name != 'ramp':
+            raise NotImplementedError(filter_name)
+        B, C, V, D = sinogram.shape
+        L = max(64, 1 << int(np.ceil(np.log2(2 * D))))
+        x = torch.zeros(B * C * V, 1, L, 2, device=sinogram.device, dtype=torch.float32)
+        x[:, 0, :D, 0] = sinogram.reshape(-1, D)
+        spec = ops.fft2(x, inverse=False, centered=False)
+        filt = torch.from_numpy(ramp_filter(L)).to(sinogram.device)
+        out = ops.fft2(spec * filt.view(1, 1, L, 1), inverse=True, centered=False)
+        return (out[:, 0, :D, 0] * (np.pi / (2 * V))).reshape(B, C, V, D).contiguous()
+
+    def filter_backprojection(self, sinogram):
+        """transforms.py:479-481"""
+        return self.backprojection(self.filter_sinogram(sinogram, filter_name='ramp'))
+
+
+def ramp_filter(size):
+    """Frequency response of the discrete ramp filter (Kak & Slaney eq. 61; the construction skimage / torch_radon
+    use): spatial kernel f[0] = 1/4, f[odd n] = -1/(pi n)^2, response = 2 Re FFT(f).  float32 [size]."""
+    n = np.concatenate((np.arange(1, size // 2 + 1, 2), np.arange(size // 2 - 1, 0, -2)))
+    f = np.zeros(size)
+    f[0] = 0.25
+    f[1::2] = -1.0 / (np.pi * n) ** 2
+    return (2 * np.real(np.fft.fft(f))).astype(np.float32)
+
 
 class RadonGenerator:
     """transforms.py:494-508: caches the operator norm per (resolution, view)."""
