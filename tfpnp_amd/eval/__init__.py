@@ -1,0 +1,1 @@
+from .evaluator import Evaluator, eval_single, psnr_qrnn3d  # noqa: F401

@@ -1,0 +1,101 @@
+"""Evaluation loop over the native path -- mirror of tfpnp/eval/evaluator.py (Evaluator.eval :21-73, eval_single
+:75-118) and of the PSNR it reports (tfpnp/utils/metric.py:23-25: skimage peak_signal_noise_ratio, data_range 255,
+averaged over channels).  Policy -> actions -> solver -> env all run on the MI355X; this file is host-side bookkeeping
+(per-sample PSNR trace, action sequences, optional image dump)."""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+
+def psnr_qrnn3d(X, Y, data_range=255):
+    """Band-wise PSNR of [C,H,W] arrays in the 0..255 range (float64, as skimage computes it)."""
+    X, Y = np.asarray(X, np.float64), np.asarray(Y, np.float64)
+    vals = []
+    for ch in range(X.shape[-3]):
+        mse = np.mean((X[ch] - Y[ch]) ** 2)
+        vals.append(10 * np.log10(data_range ** 2 / mse))
+    return float(np.mean(vals))
+
+
+def eval_single(env, data, policy, max_episode_step, metric=psnr_qrnn3d):
+    """One sample (batch of 1) driven by the policy until it stops or max_episode_step is reached."""
+    observation = env.reset(data=data)
+    hidden = policy.init_state(observation.shape[0])
+    _, output_init, gt = env.get_images(observation)
+    psnr_init = metric(output_init[0], gt[0])
+    episode_steps = 0
+    psnr_seq = [psnr_init]
+    action_seqs = {}
+    ob = observation
+    time_stamp = time.time()
+    while episode_steps < max_episode_step:
+        action, _, _, hidden = policy(env.get_policy_ob(ob), idx_stop=None, train=False, hidden=hidden)
+        ob, _, _, done, _ = env.step(action)
+        episode_steps += 1
+        _, output, gt = env.get_images(ob)
+        psnr_seq.append(float(metric(output[0], gt[0])))
+        action.pop('idx_stop')
+        for k, v in action.items():
+            action_seqs.setdefault(k, [])
+            for i in range(v.shape[0]):
+                action_seqs[k] += list(v[i].detach().cpu().numpy())
+        if done:
+            break
+    if ob.gt.is_cuda:
+        torch.cuda.synchronize(ob.gt.device)
+    run_time = time.time() - time_stamp
+    input, output, gt = env.get_images(ob)
+    psnr_finished = metric(output[0], gt[0])
+    info = (episode_steps, psnr_seq, action_seqs, run_time)
+    imgs = (input[0], output_init[0], output[0], gt[0])
+    return psnr_init, psnr_finished, info, imgs
+
+
+class Evaluator:
+    def __init__(self, env, val_loaders, savedir=None, metric=psnr_qrnn3d):
+        self.env = env
+        self.val_loaders = val_loaders      # {name: iterable of batch-1 data dicts}
+        self.savedir = savedir
+        self.metric = metric
+        self.history = []
+
+    @torch.no_grad()
+    def eval(self, policy, step):
+        if hasattr(policy, 'eval'):
+            policy.eval()
+        total = 0.0
+        for name, loader in self.val_loaders.items():
+            rows = []
+            for index, data in enumerate(loader):
+                data = dict(data)
+                assert data['gt'].shape[0] == 1
+                sample = data.pop('name', 'case' + str(index))
+                sample = sample[0] if isinstance(sample, (list, tuple)) else sample
+                psnr_init, psnr_finished, info, imgs = eval_single(self.env, data, policy,
+                                                                   max_episode_step=self.env.max_episode_step,
+                                                                   metric=self.metric)
+                episode_steps, psnr_seq, action_seqs, run_time = info
+                rows.append({'iters': episode_steps, 'psnr_init': psnr_init, 'psnr': psnr_finished, 'time': run_time})
+                if self.savedir is not None:
+                    base = os.path.join(self.savedir, name, str(sample), str(step))
+                    os.makedirs(base, exist_ok=True)
+                    for tag, img in zip(('input', 'output_init', 'output', 'gt'), imgs):
+                        _save_img(img, os.path.join(base, tag + '.png'))
+                    json.dump({'psnr': [float(p) for p in psnr_seq],
+                               **{str(k): [float(x) for x in v] for k, v in action_seqs.items()}},
+                              open(os.path.join(base, 'action_seqs.json'), 'w'))
+            summary = {k: float(np.mean([r[k] for r in rows])) for k in rows[0]} if rows else {}
+            self.history.append((step, name, summary))
+            total += summary.get('psnr', 0.0)
+        return total / max(1, len(self.val_loaders))
+
+
+def _save_img(img, path):
+    from PIL import Image
+    a = np.asarray(img)
+    a = a[..., 0] if a.ndim == 4 else a           # complex [C,H,W,2] inputs: real part
+    a = a[0] if a.ndim == 3 else a
+    Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(path)
