@@ -178,9 +178,9 @@ __global__ void psnr_final_kernel(const float* __restrict__ part, float* __restr
 // =================================================================================== CT (own discretisation)
 // Ray-driven forward projector: one thread per (b, view, detector).  See oracle/pnp_oracle.py:radon_forward and
 // DESIGN.md for the geometry.  cs = [n_view] (cos, sin) pairs computed on the host in double precision.
-__global__ void radon_forward_kernel(const float* __restrict__ img, size_t istride, const float* __restrict__ sub,
-                                     float* __restrict__ sino, const float2* __restrict__ cs, int R, int V, int det,
-                                     int B) {
+__global__ void radon_forward_kernel(const float* __restrict__ img, size_t istride, const float* __restrict__ imgT,
+                                     const float* __restrict__ sub, float* __restrict__ sino,
+                                     const float2* __restrict__ cs, int R, int V, int det, int B) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)B * V * det) return;
   const int s = (int)(i % det);
@@ -189,27 +189,78 @@ __global__ void radon_forward_kernel(const float* __restrict__ img, size_t istri
   const float c = cs[v].x, sn = cs[v].y;
   const float half = (float)det / 2.f - 0.5f, off = (float)R / 2.f - 0.5f;
   const float sp = subr((float)s, half);
-  const float* im = img + (size_t)b * istride;
+  // adjacent lanes are adjacent bins: their samples lie 1 px apart along (c, sn).  Read the transposed copy when
+  // that direction is closer to the y axis, so a wave's loads stay within few cache lines.
+  const bool tr = imgT && fabsf(sn) > fabsf(c);
+  const float* im = tr ? imgT + (size_t)b * R * R : img + (size_t)b * istride;
   const float sc = mulr(sp, c), ss = mulr(sp, sn);
+  // Only samples with px, py in [-1, R) touch the image.  Both coordinates are affine in k, so the contributing k
+  // form one interval; it is computed loosely (widened by 2) and every sample still carries its exact validity
+  // mask, so the sum is the oracle's term by term (skipped samples add +0).  The loop body is branch-free with
+  // clamped addresses so that the loads of several samples can be in flight together.
+  int k0 = 0, k1 = det;
+  {
+    auto clip = [&](float base, float slope) {   // base + (k - half) * slope in [-1, R)
+      if (fabsf(slope) < 1e-6f) return;
+      const float ka = (-1.f - base) / slope + half, kb = ((float)R - base) / slope + half;
+      const float lo = fminf(ka, kb), hi = fmaxf(ka, kb);
+      k0 = max(k0, (int)floorf(lo) - 2);
+      k1 = min(k1, (int)ceilf(hi) + 3);
+    };
+    clip(sc + off, -sn);
+    clip(ss + off, c);
+  }
   float acc = 0.f;
-  for (int k = 0; k < det; ++k) {
+#pragma unroll 4
+  for (int k = k0; k < k1; ++k) {
     const float t = subr((float)k, half);
     const float px = addr(subr(sc, mulr(t, sn)), off);
     const float py = addr(addr(ss, mulr(t, c)), off);
     const float fx0 = floorf(px), fy0 = floorf(py);
     const int x0 = (int)fx0, y0 = (int)fy0;
-    if (x0 < -1 || x0 >= R || y0 < -1 || y0 >= R) continue;
     const float fx = subr(px, fx0), fy = subr(py, fy0);
     const float wx0 = subr(1.f, fx), wy0 = subr(1.f, fy);
+    const bool in = !(x0 < -1 || x0 >= R || y0 < -1 || y0 >= R);
+    const bool xa = in && x0 >= 0, xb = in && x0 + 1 < R, ya = y0 >= 0, yb = y0 + 1 < R;
+    const int cx0 = min(max(x0, 0), R - 1), cx1 = min(max(x0 + 1, 0), R - 1);
+    const int cy0 = min(max(y0, 0), R - 1), cy1 = min(max(y0 + 1, 0), R - 1);
+    const int r0 = tr ? cx0 : cy0, r1 = tr ? cx1 : cy1, q0 = tr ? cy0 : cx0, q1 = tr ? cy1 : cx1;
+    // (row, col) = (y, x) in the image, (x, y) in its transpose: v[y][x] for y in {0,1}, x in {0,1}
+    const float v00 = im[r0 * R + q0];
+    const float v01 = tr ? im[r1 * R + q0] : im[r0 * R + q1];
+    const float v10 = tr ? im[r0 * R + q1] : im[r1 * R + q0];
+    const float v11 = im[r1 * R + q1];
     float sm = 0.f;
-    const bool xa = x0 >= 0, xb = x0 + 1 < R, ya = y0 >= 0, yb = y0 + 1 < R;
-    if (ya && xa) sm = addr(sm, mulr(im[(size_t)y0 * R + x0], mulr(wx0, wy0)));
-    if (ya && xb) sm = addr(sm, mulr(im[(size_t)y0 * R + x0 + 1], mulr(fx, wy0)));
-    if (yb && xa) sm = addr(sm, mulr(im[(size_t)(y0 + 1) * R + x0], mulr(wx0, fy)));
-    if (yb && xb) sm = addr(sm, mulr(im[(size_t)(y0 + 1) * R + x0 + 1], mulr(fx, fy)));
+    sm = addr(sm, (ya && xa) ? mulr(v00, mulr(wx0, wy0)) : 0.f);
+    sm = addr(sm, (ya && xb) ? mulr(v01, mulr(fx, wy0)) : 0.f);
+    sm = addr(sm, (yb && xa) ? mulr(v10, mulr(wx0, fy)) : 0.f);
+    sm = addr(sm, (yb && xb) ? mulr(v11, mulr(fx, fy)) : 0.f);
     acc = addr(acc, sm);
   }
   sino[i] = sub ? subr(acc, sub[i]) : acc;
+}
+// [B][R][R] -> transposed copy (32x32 LDS tiles).  The projector reads it for the views whose detector axis is
+// closer to vertical than to horizontal, so that the 64 lanes of a wave (adjacent bins) always walk along the
+// contiguous dimension: 0.49 -> see DESIGN.md (L1 line-rate bound: lines touched per load ~ 64*min(|sin|,|cos|)).
+__global__ __launch_bounds__(256) void transpose_image_kernel(const float* __restrict__ img, size_t istride,
+                                                              float* __restrict__ out, int R) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* im = img + (size_t)b * istride;
+  for (int r = ty; r < 32; r += 8)
+    if (y0 + r < R && x0 + tx < R) tile[r][tx] = im[(size_t)(y0 + r) * R + x0 + tx];
+  __syncthreads();
+  float* o = out + (size_t)b * R * R;
+  for (int r = ty; r < 32; r += 8)
+    if (x0 + r < R && y0 + tx < R) o[(size_t)(x0 + r) * R + y0 + tx] = tile[tx][r];
+}
+static void launch_radon_forward(const float* img, size_t istride, const float* sub, float* sino, const float2* cs,
+                                 float* imgT, int R, int V, int det, int B, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_image_kernel, dim3((R + 31) / 32, (R + 31) / 32, B), dim3(256), 0, s, img, istride, imgT,
+                     R);
+  hipLaunchKernelGGL(radon_forward_kernel, dim3((unsigned)(((size_t)B * V * det + 255) / 256)), dim3(256), 0, s, img,
+                     istride, imgT, sub, sino, cs, R, V, det, B);
 }
 // Pixel-driven backprojection: one thread per pixel, linear interpolation along the detector.
 __global__ void radon_backproject_kernel(const float* __restrict__ sino, float* __restrict__ img,
@@ -460,13 +511,13 @@ int pnpx_radon_forward(pnpx_ctx* ctx, const float* img, float* sino, int B, int 
   REQUIRE(img && sino && B > 0 && R > 0 && n_view > 0, "pnpx_radon_forward: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
   void* p;
-  PNPX_TRY(ctx_scratch(ctx, sizeof(float2) * n_view + 4096, &p));
+  PNPX_TRY(ctx_scratch(ctx, sizeof(float2) * n_view + (size_t)B * R * R * sizeof(float) + 8192, &p));
   Carver cv{static_cast<char*>(p)};
   const float2* cs;
   int det;
   PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &cs, &det));
-  hipLaunchKernelGGL(radon_forward_kernel, g1((size_t)B * n_view * det), dim3(256), 0, s, img, (size_t)R * R,
-                     (const float*)nullptr, sino, cs, R, n_view, det, B);
+  float* imgT = cv.take<float>((size_t)B * R * R);
+  launch_radon_forward(img, (size_t)R * R, nullptr, sino, cs, imgT, R, n_view, det, B, s);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
@@ -503,7 +554,7 @@ int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
   }
   const int det = pnpx_radon_det_count(R);
   void* p;
-  PNPX_TRY(ctx_scratch(ctx, (3 * n + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 8192, &p));
+  PNPX_TRY(ctx_scratch(ctx, (4 * n + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 16384, &p));
   Carver cv{static_cast<char*>(p)};
   const float2* cs;
   int det2;
@@ -512,6 +563,7 @@ int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
   float* xr = cv.take<float>(n);
   float* g = cv.take<float>(n);
   float* sino = cv.take<float>((size_t)B * n_view * det);
+  float* imgT = cv.take<float>(n);
   const float op2 = (float)((double)opnorm * (double)opnorm);  // backprojection / opnorm**2   transforms.py:476-477
   hipLaunchKernelGGL(real_diff_slots_kernel, g1(n), dim3(256), 0, s, vars_in + HW, vars_in + 2 * HW, is, d, HW, B);
   PNPX_LAUNCH_CHECK();
@@ -519,8 +571,7 @@ int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
     PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, xr, nullptr, B, R, R, s, nullptr));
     const float* zi = ((i == 0) ? vars_in : vars_out) + HW;
     const float* ui = ((i == 0) ? vars_in : vars_out) + 2 * HW;
-    hipLaunchKernelGGL(radon_forward_kernel, g1((size_t)B * n_view * det), dim3(256), 0, s, zi, is, y0, sino, cs, R,
-                       n_view, det, B);
+    launch_radon_forward(zi, is, y0, sino, cs, imgT, R, n_view, det, B, s);
     PNPX_LAUNCH_CHECK();
     hipLaunchKernelGGL(radon_backproject_kernel, g1(n), dim3(256), 0, s, sino, g, cs, R, n_view, det, B, op2);
     PNPX_LAUNCH_CHECK();
@@ -546,7 +597,7 @@ int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float
   }
   const int det = pnpx_radon_det_count(R);
   void* p;
-  PNPX_TRY(ctx_scratch(ctx, (2 * n + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 8192, &p));
+  PNPX_TRY(ctx_scratch(ctx, (3 * n + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 16384, &p));
   Carver cv{static_cast<char*>(p)};
   const float2* cs;
   int det2;
@@ -554,11 +605,11 @@ int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float
   float* d = cv.take<float>(n);
   float* g = cv.take<float>(n);
   float* sino = cv.take<float>((size_t)B * n_view * det);
+  float* imgT = cv.take<float>(n);
   const float op2 = (float)((double)opnorm * (double)opnorm);
   for (int i = 0; i < T; ++i) {
     const float* xi = (i == 0) ? vars_in : vars_out;
-    hipLaunchKernelGGL(radon_forward_kernel, g1((size_t)B * n_view * det), dim3(256), 0, s, xi, (size_t)HW, y0, sino,
-                       cs, R, n_view, det, B);
+    launch_radon_forward(xi, (size_t)HW, y0, sino, cs, imgT, R, n_view, det, B, s);
     PNPX_LAUNCH_CHECK();
     hipLaunchKernelGGL(radon_backproject_kernel, g1(n), dim3(256), 0, s, sino, g, cs, R, n_view, det, B, op2);
     PNPX_LAUNCH_CHECK();
