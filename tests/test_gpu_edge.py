@@ -1,0 +1,156 @@
+"""GPU edge cases: empty and ragged batches, the largest BASELINE configurations (PR 36 x 256^2, CT 32 x 256^2 / 30
+views, SPI 64 x 512^2), maximum FFT length -- through size-independent properties and small-slice oracle checks."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_inputs import csmri_actions, denoiser_inputs
+from tfpnp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def g(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def den(unet_params):
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    return UNetDenoiser2D(state_dict=unet_params)
+
+
+@pytest.fixture(scope="module")
+def oden(unet_params):
+    from oracle import pnp_oracle as O
+    return O.Denoiser(unet_params)
+
+
+def test_empty_batch_everywhere(den):
+    """All items stopped (idx_left empty): every entry point returns an empty tensor of the right shape."""
+    from tfpnp_amd.env import torch_psnr
+    from tfpnp_amd.tasks import csmri, ct, pr, spi
+    e = lambda *s: torch.empty(*s, device=dev())
+    assert den(e(0, 1, 64, 64), e(0)).shape == (0, 1, 64, 64)
+    sol = csmri.ADMMSolver_CSMRI(den)
+    out = sol((e(0, 3, 64, 64, 2), (e(0, 1, 64, 64, 2), torch.empty(0, 1, 64, 64, dtype=torch.bool, device=dev()))),
+              (e(0, 5), e(0, 5)))
+    assert out.shape == (0, 3, 64, 64, 2)
+    assert pr.IADMMSolver_PR(den)((e(0, 3, 32, 32, 2), (e(0, 4, 32, 32), e(0, 4, 32, 32, 2))),
+                                  (e(0, 5), e(0, 5), e(0, 5))).shape == (0, 3, 32, 32, 2)
+    assert spi.ADMMSolver_SPI(den)((e(0, 3, 32, 32), (e(0, 1, 32, 32), e(0, 1, 32, 32))), (e(0, 5), e(0, 5))).shape[0] == 0
+    assert torch_psnr(e(0, 1, 8, 8), e(0, 1, 8, 8)).shape == (0, 1)
+
+
+def test_env_runs_to_the_last_item(den):
+    """Ragged compaction 5 -> 3 -> 1 -> 0 live items: stopped rows are frozen, rewards of stopped rows are zero."""
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI, CSMRIEnv
+    B, H, W = 5, 64, 64
+    d = synth.make_csmri_batch(B, H, W, seed=33)
+    env = CSMRIEnv(None, ADMMSolver_CSMRI(den), max_episode_step=6)
+    env.reset({k: g(v) for k, v in d.items()})
+    stops = [[0, 1, 0, 1, 0], [1, 0, 1], [1]]
+    frozen = {}
+    for s, stop in enumerate(stops):
+        live = env.idx_left.clone()
+        a = csmri_actions(len(stop), 2, 40 + s)
+        before = env.state["solver"].clone()
+        ob, ob_masked, reward, all_done, info = env.step({"sigma_d": g(a["sigma_d"]), "mu": g(a["mu"]),
+                                                          "idx_stop": g(np.array(stop))})
+        dead = [i for i in range(B) if i not in live.tolist()]
+        assert torch.equal(env.state["solver"][dead], before[dead])
+        assert float(reward[dead].abs().max()) == 0.0 if dead else True
+        assert len(ob) == len(stop) and len(ob_masked) == stop.count(0)
+    assert all_done and len(env.idx_left) == 0
+
+
+def test_pr_full_config_slice_vs_oracle(den, oden):
+    """BASELINE config #3 (PR, B=36, 256^2, S=4): one iADMM iteration; two items re-checked against the CPU oracle."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import pr
+    B, H, W, S = 36, 256, 256, 4
+    d = synth.make_pr_batch(B, H, W, S=S, alpha=9.0, seed=77)
+    a = csmri_actions(B, 1, 78, ("sigma_d", "mu", "tau"))
+    a["tau"] = (0.5 * a["tau"]).astype(np.float32)
+    sol = pr.IADMMSolver_PR(den)
+    v0 = sol.reset({"x0": g(d["x0"])})
+    st = sol((v0, (g(d["y0"]), g(d["mask"]))), (g(a["sigma_d"]), g(a["mu"]), g(a["tau"])))
+    for i in (0, 35):
+        sl = slice(i, i + 1)
+        ref = O.pr_iadmm(oden, O.pr_reset(t(d["x0"][sl])), t(d["y0"][sl]), t(d["mask"][sl]), t(a["sigma_d"][sl]),
+                         t(a["mu"][sl]), t(a["tau"][sl]))
+        assert rel(st[sl], ref) < 1e-4
+    assert torch.equal(st, sol((v0, (g(d["y0"]), g(d["mask"]))), (g(a["sigma_d"]), g(a["mu"]), g(a["tau"]))))
+
+
+def test_spi_full_config_slice_vs_oracle(den, oden):
+    """BASELINE config #5 (SPI, B=64, 512^2): one iteration; one item re-checked against the CPU oracle."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import spi
+    B, H, W = 64, 512, 512
+    d = synth.make_spi_batch(B, H, W, K=6, seed=88)
+    sg = np.full((B, 1), 40 / 255.0, np.float32)
+    m = np.full((B, 1), 85.0, np.float32)
+    sol = spi.ADMMSolver_SPI(den)
+    v0 = sol.reset({"x0": g(d["x0"])})
+    st = sol((v0, (g(d["x0"]), g(d["K"]))), (g(sg), g(m)))
+    ref = O.spi_admm(oden, O.admm_reset(t(d["x0"][63:64])), t(d["x0"][63:64]), t(d["K"][63:64]), t(sg[63:64]), t(m[63:64]))
+    assert rel(st[63:64], ref) < 5e-4          # bisection quantum, see test_spi_golden
+    x, z, u = torch.split(st, 1, dim=1)
+    assert float(z.min()) >= 0.0 and float(z.max()) <= 1.0 and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+
+
+def test_ct_full_config_slice_vs_oracle(den, oden):
+    """BASELINE config #4 (CT, B=32, 256^2, 30 views): sinogram + one iADMM iteration, one item vs the CPU oracle."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import ct
+    from tfpnp_amd.utils import transforms as T
+    B, R, V = 32, 256, 30
+    gt = synth.phantom_batch(B, R, R, 99)
+    radon = T.Radon_norm(R, V, device=dev())
+    y0 = radon.forward(g(gt))
+    angles, det = O.radon_geometry(R, V)
+    assert tuple(y0.shape) == (B, 1, V, det) and det == 363
+    assert rel(y0[31:32], O.radon_forward(t(gt[31:32]), angles, det)) < 1e-5
+    x0 = radon.backprojection_norm(y0)
+    a = csmri_actions(B, 1, 98, ("sigma_d", "mu", "tau"))
+    sol = ct.IADMMSolver_CT(den)
+    sol.radon_generator.opnorms[(R, V)] = radon.opnorm
+    view = torch.full((B, 1, R, R), V / 120.0, device=dev())
+    st = sol((sol.reset({"x0": x0}), (y0, view)), (g(a["sigma_d"]), g(a["mu"]), g(a["tau"])))
+    ref = O.ct_iadmm(oden, O.admm_reset(x0[31:32].cpu()), y0[31:32].cpu(), V, radon.opnorm, t(a["sigma_d"][31:32]),
+                     t(a["mu"][31:32]), t(a["tau"][31:32]))
+    assert rel(st[31:32], ref) < 1e-4
+
+
+def test_fft_maximum_length_roundtrip_and_parseval():
+    from tfpnp_amd.utils import transforms as T
+    x = torch.randn(2, 1, 2048, 2048, 2, device=dev())
+    k = T.fft2(x)
+    assert abs(float((k ** 2).sum() / (x ** 2).sum()) - 1) < 1e-5
+    assert rel(T.ifft2(k), x) < 1e-5
+    from tfpnp_amd._lib import PnpxError
+    with pytest.raises(PnpxError):
+        T.fft2(torch.randn(1, 1, 4096, 8, 2, device=dev()))
+
+
+def test_denoiser_ragged_batches_reuse_workspace(den, oden):
+    """B = 1 .. capB in arbitrary order on one context (idx_left compaction) -> same per-item results."""
+    x, s = denoiser_inputs(7, 96, 96, 5)
+    full = den(g(x), g(s)).clone()
+    for idx in ([6], [0, 3], [1, 2, 4, 5, 6], [5, 1], list(range(7))):
+        assert torch.equal(den(g(x[idx]), g(s[idx])), full[idx])
+    assert rel(full[:2], oden(t(x[:2]), t(s[:2]))) < 1e-4

@@ -160,6 +160,8 @@ def unet_denoise(ctx, x, sigma, return_preclamp=False):
         raise PnpxError(f"sigma must have {B} entries, got {sigma.numel()}")
     out = torch.empty_like(x)
     pre = torch.empty_like(x) if return_preclamp else None
+    if B == 0:                       # every item already stopped: empty in, empty out (as the reference's modules)
+        return (out, pre) if return_preclamp else out
     with torch.cuda.device(x.device):
         check(_lib.lib().pnpx_unet_denoise(ctx.handle, _p(x), _p(sigma), _p(out), _p(pre) if pre is not None else None,
                                            B, H, W, _stream(x)))
@@ -270,10 +272,12 @@ def psnr(output, gt, ctx=None):
     output = _f32(output, "output")
     gt = _f32(gt, "gt")
     B = output.shape[0]
-    n = output.numel() // B
     if gt.numel() != output.numel():
         raise PnpxError("psnr: output and gt differ in size")
     out = torch.empty((B, 1), device=output.device, dtype=torch.float32)
+    if B == 0:
+        return out
+    n = output.numel() // B
     ctx = ctx or default_context(output.device)
     with torch.cuda.device(output.device):
         check(_lib.lib().pnpx_psnr(ctx.handle, _p(output), _p(gt), _p(out), B, n, _stream(output)))
@@ -302,6 +306,8 @@ def _csmri_common(fn_name, nvar, ctx, variables, y0, mask, params, iter_num):
             raise PnpxError(f"iter_num {iter_num} exceeds the {T} hyper-parameter columns provided")
         T = iter_num
     out = torch.empty_like(v)
+    if B == 0:
+        return out
     stride = ps[0].shape[1]
     fn = getattr(_lib.lib(), fn_name)
     with torch.cuda.device(v.device):
@@ -340,6 +346,8 @@ def pr_iadmm(ctx, variables, y0, mask, sigma_d, mu, tau, iter_num=None):
     ps, T = _params(B, sigma_d, mu, tau)
     T = T if iter_num is None else iter_num
     out = torch.empty_like(v)
+    if B == 0:
+        return out
     with torch.cuda.device(v.device):
         check(_lib.lib().pnpx_pr_iadmm(ctx.handle, _p(v), _p(out), _p(y0), _p(mask), *[_p(p) for p in ps],
                                        ps[0].shape[1], B, S, H, W, T, _stream(v)))
@@ -356,6 +364,8 @@ def spi_admm(ctx, variables, x0, Kmap, sigma_d, mu, iter_num=None):
     ps, T = _params(B, sigma_d, mu)
     T = T if iter_num is None else iter_num
     out = torch.empty_like(v)
+    if B == 0:
+        return out
     with torch.cuda.device(v.device):
         check(_lib.lib().pnpx_spi_admm(ctx.handle, _p(v), _p(out), _p(x0), _p(Kmap), *[_p(p) for p in ps],
                                        ps[0].shape[1], B, H, W, T, _stream(v)))
@@ -398,6 +408,8 @@ def ct_iadmm(ctx, variables, y0, n_view, opnorm, sigma_d, mu, tau, iter_num=None
     ps, T = _params(B, sigma_d, mu, tau)
     T = T if iter_num is None else iter_num
     out = torch.empty_like(v)
+    if B == 0:
+        return out
     with torch.cuda.device(v.device):
         check(_lib.lib().pnpx_ct_iadmm(ctx.handle, _p(v), _p(out), _p(y0), int(n_view), float(opnorm),
                                        *[_p(p) for p in ps], ps[0].shape[1], B, R, T, _stream(v)))
@@ -411,6 +423,8 @@ def ct_pg(ctx, variables, y0, n_view, opnorm, sigma_d, tau, iter_num=None):
     ps, T = _params(B, sigma_d, tau)
     T = T if iter_num is None else iter_num
     out = torch.empty_like(v)
+    if B == 0:
+        return out
     with torch.cuda.device(v.device):
         check(_lib.lib().pnpx_ct_pg(ctx.handle, _p(v), _p(out), _p(y0), int(n_view), float(opnorm),
                                     *[_p(p) for p in ps], ps[0].shape[1], B, R, T, _stream(v)))
