@@ -32,10 +32,11 @@ def rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-@pytest.fixture(scope="module")
-def den(unet_params):
+@pytest.fixture(scope="module", params=[1, 0], ids=["hs_f16x3", "f32_mfma"])
+def den(unet_params, request):
+    """Both kernel families: the backward re-computes the forward with the context's own family."""
     from tfpnp_amd.pnp import UNetDenoiser2D
-    return UNetDenoiser2D(state_dict=unet_params)
+    return UNetDenoiser2D(state_dict=unet_params, conv_mode=request.param)
 
 
 @pytest.fixture(scope="module")

@@ -93,7 +93,7 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   if (ctx->weights.p) (void)hipFree(ctx->weights.p);
-  for (pnpx::UNetArena* a : {&ctx->arena, &ctx->arena_f32, &ctx->arena_grad})
+  for (pnpx::UNetArena* a : {&ctx->arena, &ctx->arena_grad})
     if (a->buf.p) (void)hipFree(a->buf.p);
   policy_free(ctx);
   if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
@@ -144,7 +144,7 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
 }
 
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
-  return ctx ? ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_f32.buf.bytes + ctx->arena_grad.buf.bytes +
+  return ctx ? ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_grad.buf.bytes +
                    ctx->scratch.bytes
              : 0;
 }

@@ -116,9 +116,9 @@ struct pnpx_ctx {
   float* outc_b = nullptr;   // [1]
   pnpx::DeviceBuf weights;   // single allocation holding all of the above
   // --- UNet activation arenas (capacity capB images of capH x capW, zero borders valid for one layout `mode`):
-  //     arena = forward pass in the ctx's conv_mode; arena_f32 = fp32 re-computation inside the backward pass;
+  //     arena = forward pass in the ctx's conv_mode (also the re-computation inside the backward pass);
   //     arena_grad = gradients of every activation (fp32 planar)
-  pnpx::UNetArena arena, arena_f32, arena_grad;
+  pnpx::UNetArena arena, arena_grad;
   // --- policy actor
   pnpx::PolicyNet policy;
   // --- solver scratch (complex fields etc.), grown on demand
@@ -146,7 +146,8 @@ struct ProfileSink {      // optional per-launch event recording for pnpx_unet_p
 // Denoiser forward on padded input already resident in the arena is internal; these are the pieces the
 // solver loops call.  x/sigma/out are unpadded [B,1,H,W] / [B] tensors (C-ABI layout).
 int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
-                 int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena = nullptr, int mode = -1);
+                 int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena = nullptr, int mode = -1,
+                 bool keep_all = false);   // keep_all: store every activation (no fused network tail) -- backward pass
 // VJP of the denoiser wrt x and sigma (unet_bwd.hip): recomputes the forward pass in fp32 and back-propagates.
 int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out,
                           float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s);

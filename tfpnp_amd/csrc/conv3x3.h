@@ -17,8 +17,11 @@ struct ConvArgs {
   // epilogue mode: 0 = bias + LeakyReLU (forward); 1 = raw accumulator (no bias, no activation);
   // 2 = raw accumulator x LeakyReLU'(dmask) -- the input-gradient convolution of the backward pass, where dmask is
   // the saved forward activation that this gradient flows into (same [B][Cout][Hp][Wp] geometry as `out`)
+  // 4 = like 2, but the saved activation is a half-split HS8 tensor (conv_hs.hip layout: [B][C/8][H+2][W+2] records of
+  // hi[8] | lo[8] f16); only the sign of `hi` is used
   int mode;
   const float* dmask;
+  const char* dmask_hs = nullptr;
 };
 
 int conv_pack_mt(int cout);
@@ -28,7 +31,7 @@ int launch_conv3x3(const ConvLayer& L, const float* in0, int C0, const float* in
                    int H, int W, hipStream_t s);
 // Input-gradient convolution: L holds the transposed, tap-flipped weights (pack_conv_weights_transposed).
 int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const float* dmask, int B, int H, int W,
-                        hipStream_t s);
+                        hipStream_t s, const char* dmask_hs = nullptr);
 // w[cout][cin][3][3] -> packed weights of the adjoint convolution: wt[ci][co][tap] = w[co][ci][8 - tap], with the
 // adjoint's output channels (= cin) zero-padded to cout_pad.
 void pack_conv_weights_transposed(const float* w, int cout, int cin, int cout_pad, int mt, int cc, float* dst);

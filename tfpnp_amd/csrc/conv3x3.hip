@@ -181,12 +181,27 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
       if (y < a.H && x < a.W) {
         const size_t off = (((size_t)b * Cout + ct * MT + m * 32 + 4 * khalf) * a.Hp + (y + 1)) * a.Wp + x + PADL;
         float* o = a.out + off;
+        unsigned hsbits = 0;   // mode 4: bit r = saved activation of register r's channel is > 0
+        if (a.mode == 4) {
+          const int g0 = (ct * MT + m * 32) >> 3;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const size_t rec = (((size_t)b * (Cout >> 3) + g0 + q) * (a.H + 2) + (y + 1)) * (size_t)(a.W + 2) + (x + 1);
+            const uint2 w = *reinterpret_cast<const uint2*>(a.dmask_hs + rec * 32 + 8 * khalf);   // hi[4*khalf .. +3]
+            const unsigned short hh[4] = {(unsigned short)(w.x & 0xffff), (unsigned short)(w.x >> 16),
+                                          (unsigned short)(w.y & 0xffff), (unsigned short)(w.y >> 16)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)   // f16 > 0: sign bit clear and not (+)zero
+              hsbits |= (unsigned)((hh[j] & 0x8000u) == 0 && (hh[j] & 0x7fffu) != 0) << (q * 4 + j);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const size_t ro = (size_t)((r & 3) + 8 * (r >> 2)) * HpWp;
           float v = acc[m][n][r] + bias[r];
           if (a.mode == 0) v = v > 0.f ? v : v * a.slope;
           else if (a.mode == 2) v = a.dmask[off + ro] > 0.f ? v : v * a.slope;
+          else if (a.mode == 4) v = ((hsbits >> r) & 1u) ? v : v * a.slope;
           o[ro] = v;
         }
       }
@@ -254,7 +269,7 @@ int launch_conv3x3(const ConvLayer& L, const float* in0, int C0, const float* in
 }
 
 int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const float* dmask, int B, int H, int W,
-                        hipStream_t s) {
+                        hipStream_t s, const char* dmask_hs) {
   ConvArgs a;
   a.in0 = gin;
   a.C0 = L.cin;
@@ -269,8 +284,9 @@ int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const
   a.Wp = padded_w(W);
   a.nct = L.cout / L.mt;
   a.slope = 0.2f;
-  a.mode = dmask ? 2 : 1;
+  a.mode = dmask_hs ? 4 : (dmask ? 2 : 1);
   a.dmask = dmask;
+  a.dmask_hs = dmask_hs;
   if (L.cc != 8 || L.cin % 8 != 0 || L.cout % L.mt != 0) {
     set_error("conv3x3_grad: unsupported packing (cin %d cout %d mt %d cc %d)", L.cin, L.cout, L.mt, L.cc);
     return PNPX_ERR_SHAPE;

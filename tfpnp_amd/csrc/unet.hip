@@ -259,12 +259,12 @@ inline dim3 g1d(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 // gain is small; 24 is the default.  Deeper levels always run the whole batch.
 static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, const float* x, const float* sigma,
                            int sigma_stride, float* out, float* out_pre, int B, int H, int W, hipStream_t s,
-                           Recorder& rec) {
+                           Recorder& rec, bool keep_all) {
   char* A = static_cast<char*>(ar.buf.p);
   auto bpi = [&](const Act& d) { return act_bytes_per_image(CONV_HS, d.C, d.H, d.W); };
   auto at = [&](const Act& d, int b0) { return A + d.off + (size_t)b0 * bpi(d); };
   auto rat = [&](const Act& d, int b0) { return reinterpret_cast<HsRec*>(at(d, b0)); };
-  const bool no_pool_fuse = getenv("PNPX_NO_POOL_FUSE") != nullptr, no_outc_fuse = getenv("PNPX_NO_OUTC_FUSE") != nullptr;
+  const bool no_pool_fuse = getenv("PNPX_NO_POOL_FUSE") != nullptr, no_outc_fuse = keep_all || getenv("PNPX_NO_OUTC_FUSE") != nullptr;
   // Fused bilinear upsample inside the conv loader (ConvHsFuse::up_in1) is implemented and parity-tested but OFF by
   // default: the interpolation costs ~190 VALU ops per 32-byte record in the MFMA waves and, measured at B=48/256^2,
   // conv0 of the decoder blocks got 0.14/0.07/0.00 ms slower at levels 3/2/1 and only 0.06 ms faster at level 0 than
@@ -373,7 +373,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
 }
 
 int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
-                 int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena, int mode) {
+                 int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena, int mode, bool keep_all) {
   if (!ctx->has_weights) {
     set_error("denoiser called before pnpx_unet_load");
     return PNPX_ERR_NO_WEIGHTS;
@@ -389,7 +389,7 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
   const UNetPlan P = make_plan(mode, ar.capB, H, W);
   Recorder rec{prof, s};
   if (prof) PNPX_HIP(hipEventRecord((*prof->events)[0], s));
-  if (hs) return unet_forward_hs(ctx, ar, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec);
+  if (hs) return unet_forward_hs(ctx, ar, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec, keep_all);
 
   // ---- plain-fp32 path (conv_mode 0): padded planar fp32 activations, whole batch per launch
   char* A = static_cast<char*>(ar.buf.p);

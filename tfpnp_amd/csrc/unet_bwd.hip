@@ -5,9 +5,9 @@
 // through UNetDenoiser2D.forward (tfpnp/pnp/denoiser/base.py:23-32; weights frozen) into sigma_d and into the
 // image argument.  This file is that backward pass:
 //     (gx, gsigma) = J^T g,   out = clamp(in[:, :1] + UNet(cat[x, sigma*1]), 0, 1)
-// Strategy: gradient checkpointing per call -- the forward pass is RE-COMPUTED here in exact fp32 (conv3x3.hip, its
-// own arena) and then back-propagated layer by layer, so nothing has to be kept alive between the forward and the
-// backward of the autograd graph.  Gradients are fp32 planar tensors in a third arena with the same zero-border
+// Strategy: gradient checkpointing per call -- the forward pass is RE-COMPUTED here (same kernel family and arena as
+// the inference forward, all activations kept) and then back-propagated layer by layer, so nothing has to be kept
+// alive between the forward and the backward of the autograd graph.  Gradients are fp32 planar tensors in a third arena with the same zero-border
 // layout, so every input-gradient convolution is the SAME MFMA kernel run on transposed, tap-flipped weights
 // (pack_conv_weights_transposed) with the LeakyReLU derivative of the saved activation fused in its epilogue.
 #include "common.h"
@@ -21,11 +21,26 @@ inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 __device__ __forceinline__ float dlrelu(float a) { return a > 0.f ? 1.f : 0.2f; }
 
+// A saved forward activation: fp32 padded planar (conv_mode 0) or half-split HS8 records (conv_hs.hip: [B][C/8][H+2][W+2]
+// records of hi[8] | lo[8] f16, value * 16 = hi + lo).  Only signs and orderings are needed here, so the scale drops out.
+struct SavedAct {
+  const void* p;
+  int hs;
+};
+__device__ __forceinline__ float act_at(const SavedAct& A, size_t b, int C, int c, int H, int W, int y, int x) {
+  if (A.hs) {
+    const size_t rec = ((b * (C >> 3) + (c >> 3)) * (H + 2) + (y + 1)) * (size_t)(W + 2) + (x + 1);
+    const _Float16* r = reinterpret_cast<const _Float16*>(static_cast<const char*>(A.p) + rec * 32);
+    return (float)r[c & 7] + (float)r[8 + (c & 7)];
+  }
+  return static_cast<const float*>(A.p)[((b * C + c) * (size_t)padded_h(H) + (y + 1)) * padded_w(W) + x + PADL];
+}
+
 // d/d(feat) of  out = clamp(x + sum_c w[c] feat[c] + b):  g_feat[c] = w[c] * g_out * 1[0 <= pre <= 1] * lrelu'(feat[c])
 // (feat = y[0], the last conv's activation; the result is the gradient wrt that conv's PRE-activation).
 // Also emits g_res = g_out * 1[0 <= pre <= 1], the gradient reaching the residual path in[:, :1].
 __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ pre,
-                                                       const float* __restrict__ w, const float* __restrict__ feat,
+                                                       const float* __restrict__ w, SavedAct feat,
                                                        float* __restrict__ g_feat, float* __restrict__ g_res, int H,
                                                        int W, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,14 +57,14 @@ __global__ __launch_bounds__(256) void outc_bwd_kernel(const float* __restrict__
 #pragma unroll 4
   for (int c = 0; c < 32; ++c) {
     const size_t oc = o + (size_t)c * Hp * Wp;
-    g_feat[oc] = w[c] * g * dlrelu(feat[oc]);
+    g_feat[oc] = w[c] * g * dlrelu(act_at(feat, b, 32, c, H, W, y, x));
   }
 }
 
 // Adjoint of bilinear x2 (align_corners) restricted to the channel range [c_off, c_off + C) of the concat gradient,
 // as a gather: every source pixel sums the destination pixels that interpolate from it; then x lrelu'(saved source).
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ gcat, int Ccat, int c_off,
-                                                           const float* __restrict__ src_act, float* __restrict__ g_src,
+                                                           SavedAct src_act, float* __restrict__ g_src,
                                                            int C, int h, int w, int Ht, int Wt, float sy, float sx,
                                                            size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,7 +103,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     }
   }
   const size_t o = (b * C + c) * (size_t)hp * wp + (size_t)(ys + 1) * wp + xs + PADL;
-  g_src[o] = acc * dlrelu(src_act[o]);
+  g_src[o] = acc * dlrelu(act_at(src_act, b, C, c, h, w, ys, xs));
 }
 
 // Gradient reaching an encoder output x[l] (H x W, C channels): the skip part of the decoder's concat gradient
@@ -96,7 +111,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 // all times lrelu'(x[l]).
 __global__ __launch_bounds__(256) void skip_pool_merge_kernel(const float* __restrict__ gcat, int Ccat,
                                                               const float* __restrict__ g_pool,
-                                                              const float* __restrict__ xact, float* __restrict__ g_x,
+                                                              SavedAct xact, float* __restrict__ g_x,
                                                               int C, int H, int W, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -114,8 +129,9 @@ __global__ __launch_bounds__(256) void skip_pool_merge_kernel(const float* __res
     const int Ho = H / 2, Wo = W / 2;
     const int yo = y >> 1, xo = x >> 1;
     if (yo < Ho && xo < Wo) {
-      const float* a = xact + (b * C + c) * plane + (size_t)(2 * yo + 1) * Wp + 2 * xo + PADL;
-      const float v00 = a[0], v01 = a[1], v10 = a[Wp], v11 = a[Wp + 1];
+      const float v00 = act_at(xact, b, C, c, H, W, 2 * yo, 2 * xo), v01 = act_at(xact, b, C, c, H, W, 2 * yo, 2 * xo + 1);
+      const float v10 = act_at(xact, b, C, c, H, W, 2 * yo + 1, 2 * xo);
+      const float v11 = act_at(xact, b, C, c, H, W, 2 * yo + 1, 2 * xo + 1);
       int arg = 0;
       float m = v00;
       if (v01 > m) { m = v01; arg = 1; }
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(256) void skip_pool_merge_kernel(const float* __res
       }
     }
   }
-  g_x[o] = g * dlrelu(xact[o]);
+  g_x[o] = g * dlrelu(act_at(xact, b, C, c, H, W, y, x));
 }
 
 // gx = g_in0[:, 0] + g_res;  gsigma[b] = sum over pixels of g_in0[:, 1]   (two-stage, deterministic)
@@ -216,11 +232,15 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
   float* g_res = pre + npix;
   float* part = g_res + npix;
 
-  // 1. recompute the forward pass in exact fp32 into its own arena (activations stay there for the masks)
-  PNPX_TRY(unet_denoise(ctx, x, sigma, sigma_stride, out_tmp, pre, B, H, W, s, nullptr, &ctx->arena_f32, CONV_F32));
-  const UNetPlan F = make_plan(CONV_F32, ctx->arena_f32.capB, H, W);
-  char* FA = static_cast<char*>(ctx->arena_f32.buf.p);
-  auto fact = [&](const Act& d) { return reinterpret_cast<const float*>(FA + d.off); };
+  // 1. recompute the forward pass with the context's own kernel family into the context's activation arena, keeping
+  //    every activation (no fused network tail): the backward needs signs (LeakyReLU'), orderings (max-pool routing)
+  //    and the pre-clamp output only, which the half-split activations give exactly as well as fp32 ones.
+  const int fmode = ctx->conv_mode;
+  const bool hs = (fmode == CONV_HS);
+  PNPX_TRY(unet_denoise(ctx, x, sigma, sigma_stride, out_tmp, pre, B, H, W, s, nullptr, &ctx->arena, fmode, true));
+  const UNetPlan F = make_plan(fmode, ctx->arena.capB, H, W);
+  char* FA = static_cast<char*>(ctx->arena.buf.p);
+  auto sact = [&](const Act& d) { return SavedAct{FA + d.off, hs ? 1 : 0}; };
 
   // 2. gradient arena (zero borders: gradients are convolution INPUTS of the adjoint convs)
   {
@@ -255,19 +275,21 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
   auto gptr = [&](const Act& d) { return reinterpret_cast<float*>(GA + d.off); };
 
   // 3. tail: clamp + residual + 1x1 out-conv -> gradient wrt the pre-activation of the last conv (y[0])
-  hipLaunchKernelGGL(outc_bwd_kernel, g1(npix), dim3(256), 0, s, grad_out, pre, ctx->outc_w, fact(F.y[0]), gptr(G.y[0]),
+  hipLaunchKernelGGL(outc_bwd_kernel, g1(npix), dim3(256), 0, s, grad_out, pre, ctx->outc_w, sact(F.y[0]), gptr(G.y[0]),
                      g_res, H, W, npix);
   PNPX_LAUNCH_CHECK();
 
-  auto convT = [&](int li, const Act& gin, const Act& gout, const float* dmask) -> int {
-    return launch_conv3x3_grad(ctx->conv_bwd[li], gptr(gin), gptr(gout), dmask, B, gout.H, gout.W, s);
+  auto convT = [&](int li, const Act& gin, const Act& gout, const Act* saved) -> int {
+    const float* dm = (saved && !hs) ? reinterpret_cast<const float*>(FA + saved->off) : nullptr;
+    const char* dmh = (saved && hs) ? FA + saved->off : nullptr;
+    return launch_conv3x3_grad(ctx->conv_bwd[li], gptr(gin), gptr(gout), dm, B, gout.H, gout.W, s, dmh);
   };
 
   // 4. decoder blocks, top (level 0) to bottom (level 3)
   for (int l = 0; l <= 3; ++l) {
     const int li = 15 + 3 * (3 - l);
-    PNPX_TRY(convT(li + 2, G.y[l], G.b[l], fact(F.db[l])));  // through conv2, x lrelu'(decoder b)
-    PNPX_TRY(convT(li + 1, G.b[l], G.a[l], fact(F.da[l])));  // through conv1, x lrelu'(decoder a)
+    PNPX_TRY(convT(li + 2, G.y[l], G.b[l], &F.db[l]));  // through conv2, x lrelu'(decoder b)
+    PNPX_TRY(convT(li + 1, G.b[l], G.a[l], &F.da[l]));  // through conv1, x lrelu'(decoder a)
     PNPX_TRY(convT(li, G.a[l], G.cat[l], nullptr));          // through conv0 -> gradient of cat[skip, up]
     // up part -> through the bilinear upsample -> pre-activation gradient of the tensor below
     const Act& below_f = (l == 3) ? F.x[4] : F.y[l + 1];
@@ -276,7 +298,7 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
     const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
     const size_t n = (size_t)B * Cb * h * w;
-    hipLaunchKernelGGL(upsample_bwd_kernel, g1(n), dim3(256), 0, s, gptr(G.cat[l]), G.cat[l].C, F.x[l].C, fact(below_f),
+    hipLaunchKernelGGL(upsample_bwd_kernel, g1(n), dim3(256), 0, s, gptr(G.cat[l]), G.cat[l].C, F.x[l].C, sact(below_f),
                        gptr(below_g), Cb, h, w, G.cat[l].H, G.cat[l].W, sy, sx, n);
     PNPX_LAUNCH_CHECK();
   }
@@ -285,11 +307,11 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
     if (l < 4) {   // gradient reaching x[l]: skip part of the decoder concat + max-pool routing from level l+1
       const size_t n = (size_t)B * F.x[l].C * F.x[l].H * F.x[l].W;
       hipLaunchKernelGGL(skip_pool_merge_kernel, g1(n), dim3(256), 0, s, gptr(G.cat[l]), G.cat[l].C, gptr(G.p[l + 1]),
-                         fact(F.x[l]), gptr(G.x[l]), F.x[l].C, F.x[l].H, F.x[l].W, n);
+                         sact(F.x[l]), gptr(G.x[l]), F.x[l].C, F.x[l].H, F.x[l].W, n);
       PNPX_LAUNCH_CHECK();
     }
-    PNPX_TRY(convT(3 * l + 2, G.x[l], G.b[l], fact(F.b[l])));
-    PNPX_TRY(convT(3 * l + 1, G.b[l], G.a[l], fact(F.a[l])));
+    PNPX_TRY(convT(3 * l + 2, G.x[l], G.b[l], &F.b[l]));
+    PNPX_TRY(convT(3 * l + 1, G.b[l], G.a[l], &F.a[l]));
     PNPX_TRY(convT(3 * l, G.a[l], l == 0 ? G.in0 : G.p[l], nullptr));
   }
   // 6. input gradients
