@@ -221,6 +221,37 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
     ctx->conv_bwd[i].mt = mt;
     ctx->conv_bwd[i].cc = 8;
   }
+  // ... and the same adjoint convolutions for the half-split kernel family (backward pass of conv_mode 1)
+  size_t thoff[27];
+  float thscale[27];
+  {
+    std::vector<float> wt;
+    for (int i = 0; i < 27; ++i) {
+      const int cin_t = L[i].cout;                                 // adjoint input channels (multiple of 32)
+      const int cout_t = (L[i].cin + 31) / 32 * 32;                // adjoint output channels, zero-padded
+      const int mt = (cout_t % 64 == 0) ? 64 : 32;
+      const float* wsrc = params_host;
+      for (int k = 0; k < i; ++k) wsrc += (size_t)L[k].cin * L[k].cout * 9 + L[k].cout;
+      wt.assign((size_t)cout_t * cin_t * 9, 0.f);
+      for (int ci = 0; ci < L[i].cin; ++ci)
+        for (int co = 0; co < cin_t; ++co)
+          for (int tap = 0; tap < 9; ++tap)
+            wt[((size_t)ci * cin_t + co) * 9 + tap] = wsrc[((size_t)co * L[i].cin + ci) * 9 + (8 - tap)];
+      align();
+      thoff[i] = host.size();
+      const size_t n16 = (size_t)cout_t * cin_t * 9 * 2;
+      host.resize(host.size() + (n16 + 1) / 2, 0.f);
+      thscale[i] = pack_conv_weights_hs(wt.data(), cout_t, cin_t, mt, reinterpret_cast<uint16_t*>(host.data() + thoff[i]));
+      ctx->conv_hs_bwd[i].cin = cin_t;
+      ctx->conv_hs_bwd[i].cout = cout_t;
+      ctx->conv_hs_bwd[i].cin_pad = cin_t;
+      ctx->conv_hs_bwd[i].mt = mt;
+      ctx->conv_hs_bwd[i].inv_scale = 1.0f / (thscale[i] * HS_ASCALE);
+    }
+  }
+  align();
+  const size_t ozero = host.size();
+  host.resize(host.size() + 768, 0.f);
   align();
   const size_t ow = host.size();
   host.insert(host.end(), src, src + 32);
@@ -247,7 +278,9 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
     ctx->conv_hs[i].w = reinterpret_cast<char*>(d + hoff[i]);
     ctx->conv_bwd[i].w = d + toff[i];
     ctx->conv_bwd[i].b = nullptr;
+    ctx->conv_hs_bwd[i].w = reinterpret_cast<char*>(d + thoff[i]);
   }
+  ctx->zero_bias = d + ozero;
   ctx->outc_w = d + ow;
   ctx->outc_b = d + ob;
   ctx->weights.p = p;

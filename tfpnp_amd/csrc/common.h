@@ -112,6 +112,8 @@ struct pnpx_ctx {
   pnpx::ConvLayerHsDev conv_hs[27];
   int conv_mode = pnpx::CONV_HS;   // which conv kernel family the denoiser runs (pnpx_ctx_set_option)
   pnpx::ConvLayer conv_bwd[27];    // adjoint (input-gradient) convolutions, fp32 kernel family
+  pnpx::ConvLayerHsDev conv_hs_bwd[27];  // ... and packed for the half-split kernel family
+  float* zero_bias = nullptr;      // [768] zeros (bias operand of the adjoint convolutions)
   float* outc_w = nullptr;   // [32]
   float* outc_b = nullptr;   // [1]
   pnpx::DeviceBuf weights;   // single allocation holding all of the above

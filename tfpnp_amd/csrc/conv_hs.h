@@ -35,6 +35,9 @@ struct ConvHsArgs {
   // fused bilinear x2 upsample of the second source: in1 is [B][G1][h1+2][w1+2] (H = 2*h1, W = 2*w1)
   int up1, h1, w1;
   float sy, sx;
+  // backward pass (input-gradient convolution): LeakyReLU' taken from the sign of a saved HS8 activation with the
+  // geometry of `out` instead of from the result itself
+  const char* dmask;
 };
 
 int conv_hs_mt(int cout);
@@ -47,6 +50,8 @@ struct ConvHsFuse {       // optional fused work
   const float* x_in = nullptr;
   float* out_img = nullptr;
   float* out_pre = nullptr;
+  const char* dmask = nullptr;  // input-gradient mode: out = acc * (dmask > 0 ? 1 : slope), no bias expected (pass zeros)
+  float slope = 0.2f;           // 1.0 = linear epilogue
 };
 // true when launch_conv_hs will honour ConvHsFuse::pool_out for this geometry
 bool conv_hs_can_pool(int H, int W);

@@ -381,13 +381,35 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) bias[r] = a.bias[T.ct * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
       float v[NBW][16];
+      if (a.dmask) {
+        // input-gradient convolution: the LeakyReLU derivative comes from the saved forward activation (same record
+        // position as the output record; this lane's 4 channels of group q are hi[4*kg .. 4*kg+3])
 #pragma unroll
-      for (int n = 0; n < NBW; ++n)
+        for (int n = 0; n < NBW; ++n) {
+          const int y = min(T.y0 + (wave * NBW + n) * G::MBH + py, a.H - 1), x = min(T.x0 + px, a.W - 1);
+          const size_t rec = img_rec + (size_t)(y + 1) * a.Wp + (x + 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float t = acc[m][n][r] * a.inv_scale + bias[r];
-          v[n][r] = (t > 0.f ? t : t * a.slope) * HS_ASCALE;
+          for (int q = 0; q < 4; ++q) {
+            const uint2 w = *reinterpret_cast<const uint2*>(a.dmask + (rec + (size_t)(T.ct * (MT / 8) + m * 4 + q) * HpWp) * 32 +
+                                                            8 * kg);
+            const unsigned hh[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool pos = (hh[j] & 0x8000u) == 0 && (hh[j] & 0x7fffu) != 0;
+              const float t = acc[m][n][q * 4 + j] * a.inv_scale;
+              v[n][q * 4 + j] = (pos ? t : t * a.slope) * HS_ASCALE;
+            }
+          }
         }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float t = acc[m][n][r] * a.inv_scale + bias[r];
+            v[n][r] = (t > 0.f ? t : t * a.slope) * HS_ASCALE;
+          }
+      }
       if constexpr (MT == 32) {
         if (a.outc_w) {   // out = clamp(x + outc(v) ...): accumulate this lane's 16 channels
           float w16[16];
@@ -627,7 +649,8 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.Wp = W + 2;
   a.nct = L.cout / L.mt;
   a.inv_scale = L.inv_scale;
-  a.slope = 0.2f;
+  a.slope = fuse.slope;
+  a.dmask = fuse.dmask;
   a.tilesX = a.tilesY = 0;
   a.B = B;
   if (L.mt == 64) return launch_hs_mt<64>(a, B, s);

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "conv3x3.h"
 #include "conv_hs.h"
+#include "hs_rec.h"
 #include "unet_plan.h"
 
 namespace pnpx {
@@ -96,24 +97,7 @@ __global__ void outc_residual_kernel(const float* __restrict__ feat, const float
 // ----------------------------------------------------------------------------------------- HS8 kernels
 // Same four ops on the half-split layout of conv_hs.hip: records of 32 B = hi[8] | lo[8] f16 per (group, pixel),
 // values scaled by HS_ASCALE, tensor [B][G][H+2][W+2] records with a zero border.  One thread per record.
-typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-struct HsRec {
-  h8v hi, lo;
-};
-__device__ __forceinline__ void hs_unpack(const HsRec& r, float v[8]) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (float)r.hi[e] + (float)r.lo[e];
-}
-__device__ __forceinline__ HsRec hs_pack(const float v[8]) {
-  HsRec r;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    r.hi[e] = (_Float16)v[e];
-    r.lo[e] = (_Float16)(v[e] - (float)r.hi[e]);
-  }
-  return r;
-}
-
+// (record type and pack / unpack helpers: hs_rec.h)
 __global__ __launch_bounds__(256) void prep_input_hs_kernel(const float* __restrict__ x, const float* __restrict__ sigma,
                                                             int sigma_stride, HsRec* __restrict__ dst, int H, int W,
                                                             size_t n) {

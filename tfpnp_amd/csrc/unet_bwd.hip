@@ -12,6 +12,8 @@
 // (pack_conv_weights_transposed) with the LeakyReLU derivative of the saved activation fused in its epilogue.
 #include "common.h"
 #include "conv3x3.h"
+#include "conv_hs.h"
+#include "hs_rec.h"
 #include "unet_plan.h"
 
 namespace pnpx {
@@ -178,13 +180,183 @@ __global__ void sigma_grad_final_kernel(const float* __restrict__ part, float* _
   gsigma[b] = s;
 }
 
+
+// ------------------------------------------------------------------------------------ half-split (HS8) variants
+// conv_mode 1: gradients live in HS8 tensors too, so that the 27 adjoint convolutions run on the f16x3 MFMA kernel
+// (conv_hs.hip, LeakyReLU' from the saved activation's sign in its epilogue).  f16 has a narrow exponent range, so the
+// whole backward pass runs on grad_out / m with m = the power of two >= max|grad_out| and the two results are
+// multiplied by m at the end (exact: power-of-two scaling commutes with every linear step).  One thread per record.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, size_t n, unsigned* __restrict__ bits) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(g[i]));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(bits, __float_as_uint(m));   // non-negative floats order like their bits
+}
+__global__ void grad_scale_kernel(const unsigned* __restrict__ bits, float2* __restrict__ sc) {
+  const float m = __uint_as_float(*bits);
+  if (!(m > 0.f) || !isfinite(m)) {
+    *sc = make_float2(m > 0.f ? 1.f : 0.f, m > 0.f ? 1.f : 0.f);   // all-zero gradient -> zeros; inf/nan -> pass through
+    return;
+  }
+  int e;
+  (void)frexpf(m, &e);                    // m = f * 2^e, f in [0.5, 1)
+  *sc = make_float2(ldexpf(1.f, -e), ldexpf(1.f, e));
+}
+
+__global__ __launch_bounds__(256) void outc_bwd_hs_kernel(const float* __restrict__ g_out, const float* __restrict__ pre,
+                                                          const float* __restrict__ w, const HsRec* __restrict__ feat,
+                                                          HsRec* __restrict__ g_feat, float* __restrict__ g_res,
+                                                          const float2* __restrict__ sc, int H, int W, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = (int)(i & 3);
+  const size_t pix = i >> 2;
+  const int x = (int)(pix % W);
+  const size_t t = pix / W;
+  const int y = (int)(t % H);
+  const size_t b = t / H;
+  const float p = pre[pix];
+  const float gn = (p >= 0.f && p <= 1.f) ? g_out[pix] * sc->x : 0.f;
+  if (g == 0) g_res[pix] = gn;
+  const size_t r = ((b * 4 + g) * (H + 2) + (y + 1)) * (size_t)(W + 2) + (x + 1);
+  float f[8], o[8];
+  hs_unpack(feat[r], f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = w[g * 8 + k] * gn * dlrelu(f[k]) * HS_ASCALE;
+  g_feat[r] = hs_pack(o);
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_hs_kernel(const HsRec* __restrict__ gcat, int Gcat, int g_off,
+                                                              const HsRec* __restrict__ src_act,
+                                                              HsRec* __restrict__ g_src, int Gs, int h, int w, int Ht,
+                                                              int Wt, float sy, float sx, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int xs = (int)(i % w);
+  size_t t = i / w;
+  const int ys = (int)(t % h);
+  t /= h;
+  const int g = (int)(t % Gs);
+  const size_t b = t / Gs;
+  const int H = 2 * h, W = 2 * w;
+  const HsRec* gc = gcat + (b * Gcat + g_off + g) * (size_t)(Ht + 2) * (Wt + 2);
+  const int ylo = max(0, 2 * ys - 3), yhi = min(H - 1, 2 * ys + 3);
+  const int xlo = max(0, 2 * xs - 3), xhi = min(W - 1, 2 * xs + 3);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int yd = ylo; yd <= yhi; ++yd) {
+    const float fy = sy * yd;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = fy - y0;
+    float wy = 0.f;
+    if (y0 == ys) wy += 1.f - ly;
+    if (y1 == ys) wy += ly;
+    if (wy == 0.f) continue;
+    for (int xd = xlo; xd <= xhi; ++xd) {
+      const float fx = sx * xd;
+      const int x0 = (int)fx;
+      const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float lx = fx - x0;
+      float wx = 0.f;
+      if (x0 == xs) wx += 1.f - lx;
+      if (x1 == xs) wx += lx;
+      if (wx == 0.f) continue;
+      float v[8];
+      hs_unpack(gc[(size_t)(yd + 1) * (Wt + 2) + xd + 1], v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += wy * wx * v[k];
+    }
+  }
+  const size_t r = ((b * Gs + g) * (h + 2) + (ys + 1)) * (size_t)(w + 2) + (xs + 1);
+  float a[8];
+  hs_unpack(src_act[r], a);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] *= dlrelu(a[k]);
+  g_src[r] = hs_pack(acc);
+}
+
+__global__ __launch_bounds__(256) void skip_pool_merge_hs_kernel(const HsRec* __restrict__ gcat, int Gcat,
+                                                                 const HsRec* __restrict__ g_pool,
+                                                                 const HsRec* __restrict__ xact, HsRec* __restrict__ g_x,
+                                                                 int G, int H, int W, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W);
+  size_t t = i / W;
+  const int y = (int)(t % H);
+  t /= H;
+  const int g = (int)(t % G);
+  const size_t b = t / G;
+  const size_t plane = (size_t)(H + 2) * (W + 2);
+  const size_t r = (b * G + g) * plane + (size_t)(y + 1) * (W + 2) + (x + 1);
+  float gv[8], a[8];
+  if (gcat) {
+    hs_unpack(gcat[(b * Gcat + g) * plane + (size_t)(y + 1) * (W + 2) + (x + 1)], gv);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gv[k] = 0.f;
+  }
+  hs_unpack(xact[r], a);
+  if (g_pool) {
+    const int Ho = H / 2, Wo = W / 2, yo = y >> 1, xo = x >> 1;
+    if (yo < Ho && xo < Wo) {
+      const HsRec* w0 = xact + (b * G + g) * plane + (size_t)(2 * yo + 1) * (W + 2) + (2 * xo + 1);
+      float v00[8], v01[8], v10[8], v11[8], gp[8];
+      hs_unpack(w0[0], v00);
+      hs_unpack(w0[1], v01);
+      hs_unpack(w0[W + 2], v10);
+      hs_unpack(w0[W + 3], v11);
+      hs_unpack(g_pool[((b * G + g) * (Ho + 2) + (yo + 1)) * (size_t)(Wo + 2) + (xo + 1)], gp);
+      const int me = (y & 1) * 2 + (x & 1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int arg = 0;
+        float m = v00[k];
+        if (v01[k] > m) { m = v01[k]; arg = 1; }
+        if (v10[k] > m) { m = v10[k]; arg = 2; }
+        if (v11[k] > m) { m = v11[k]; arg = 3; }
+        if (arg == me) gv[k] += gp[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gv[k] *= dlrelu(a[k]);
+  g_x[r] = hs_pack(gv);
+}
+
+__global__ __launch_bounds__(256) void input_grad_hs_kernel(const HsRec* __restrict__ g_in0, const float* __restrict__ g_res,
+                                                            float* __restrict__ gx, float* __restrict__ part,
+                                                            const float2* __restrict__ sc, int H, int W) {
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int n = H * W, per = (n + SIG_CHUNKS - 1) / SIG_CHUNKS;
+  const int lo = chunk * per, hi = min(n, lo + per);
+  const HsRec* g0 = g_in0 + (size_t)b * 4 * (H + 2) * (W + 2);     // group 0 of 4: channels 0 (image) and 1 (noise map)
+  const float m = sc->y, inv = 1.f / HS_ASCALE;
+  float acc = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const int y = i / W, x = i - y * W;
+    float v[8];
+    hs_unpack(g0[(size_t)(y + 1) * (W + 2) + x + 1], v);
+    gx[(size_t)b * n + i] = (v[0] * inv + g_res[(size_t)b * n + i]) * m;
+    acc += v[1] * inv;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ float w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[b * SIG_CHUNKS + chunk] = ((w[0] + w[1]) + (w[2] + w[3])) * m;
+}
+
 // gradient arena: one tensor per forward activation + the concat gradients of the four decoder blocks
 struct GradPlan {
   Act in0;        // 32 channels (the adjoint of the first conv is padded from 2 to 32 output channels)
   Act a[5], b[5], x[5], p[5], y[4], cat[4];
   size_t total = 0;
 };
-GradPlan make_grad_plan(int capB, int H, int W) {
+GradPlan make_grad_plan(int mode, int capB, int H, int W) {
   GradPlan P;
   size_t off = 0;
   auto add = [&](Act& d, int C, int h, int w) {
@@ -192,7 +364,7 @@ GradPlan make_grad_plan(int capB, int H, int W) {
     d.C = C;
     d.H = h;
     d.W = w;
-    off += act_bytes_per_image(CONV_F32, C, h, w) * (size_t)capB;
+    off += act_bytes_per_image(mode, C, h, w) * (size_t)capB;
     off = (off + 255) & ~(size_t)255;
   };
   add(P.in0, 32, H, W);
@@ -226,11 +398,13 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
   const size_t npix = (size_t)B * H * W;
   // scratch: recomputed clamped output (unused), pre-clamp output, residual gradient, sigma partials
   void* sp;
-  PNPX_TRY(ctx_scratch(ctx, (3 * npix + (size_t)B * SIG_CHUNKS) * sizeof(float) + 4096, &sp));
+  PNPX_TRY(ctx_scratch(ctx, (3 * npix + (size_t)B * SIG_CHUNKS) * sizeof(float) + 8192, &sp));
   float* out_tmp = static_cast<float*>(sp);
   float* pre = out_tmp + npix;
   float* g_res = pre + npix;
   float* part = g_res + npix;
+  float2* gscale = reinterpret_cast<float2*>(part + (((size_t)B * SIG_CHUNKS + 63) & ~(size_t)63));   // {1/m, m}
+  unsigned* gmax_bits = reinterpret_cast<unsigned*>(gscale + 1);
 
   // 1. recompute the forward pass with the context's own kernel family into the context's activation arena, keeping
   //    every activation (no fused network tail): the backward needs signs (LeakyReLU'), orderings (max-pool routing)
@@ -245,10 +419,10 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
   // 2. gradient arena (zero borders: gradients are convolution INPUTS of the adjoint convs)
   {
     UNetArena& ga = ctx->arena_grad;
-    if (!(B <= ga.capB && H == ga.capH && W == ga.capW)) {
+    if (!(B <= ga.capB && H == ga.capH && W == ga.capW && ga.mode == fmode)) {
       const bool same = (H == ga.capH && W == ga.capW);
       const int nb = same ? (B > ga.capB ? B : ga.capB) : B;
-      const GradPlan GP = make_grad_plan(nb, H, W);
+      const GradPlan GP = make_grad_plan(fmode, nb, H, W);
       PNPX_HIP(hipDeviceSynchronize());
       if (ga.buf.bytes < GP.total) {
         if (ga.buf.p) PNPX_HIP(hipFree(ga.buf.p));
@@ -267,12 +441,76 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
       ga.capB = nb;
       ga.capH = H;
       ga.capW = W;
-      ga.mode = CONV_F32;
+      ga.mode = fmode;
     }
   }
-  const GradPlan G = make_grad_plan(ctx->arena_grad.capB, H, W);
+  const GradPlan G = make_grad_plan(fmode, ctx->arena_grad.capB, H, W);
   char* GA = static_cast<char*>(ctx->arena_grad.buf.p);
   auto gptr = [&](const Act& d) { return reinterpret_cast<float*>(GA + d.off); };
+
+  if (hs) {
+    // ---- half-split backward: HS8 gradients, f16x3 MFMA adjoint convolutions
+    auto grec = [&](const Act& d) { return reinterpret_cast<HsRec*>(GA + d.off); };
+    auto frec = [&](const Act& d) { return reinterpret_cast<const HsRec*>(FA + d.off); };
+    PNPX_HIP(hipMemsetAsync(gmax_bits, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, s, grad_out, npix, gmax_bits);
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, s, gmax_bits, gscale);
+    hipLaunchKernelGGL(outc_bwd_hs_kernel, g1(npix * 4), dim3(256), 0, s, grad_out, pre, ctx->outc_w, frec(F.y[0]),
+                       grec(G.y[0]), g_res, gscale, H, W, npix * 4);
+    PNPX_LAUNCH_CHECK();
+    auto convH = [&](int li, const Act& gin, const Act& gout, const Act* saved) -> int {
+      const ConvLayerHsDev& D = ctx->conv_hs_bwd[li];
+      ConvLayerHs Lh;
+      Lh.cin = D.cin;
+      Lh.cout = D.cout;
+      Lh.cin_pad = D.cin_pad;
+      Lh.mt = D.mt;
+      Lh.w = D.w;
+      Lh.b = ctx->zero_bias;
+      Lh.inv_scale = D.inv_scale;
+      if (gin.C != D.cin || gout.C != D.cout) {
+        set_error("backward: gradient tensor channels %d -> %d do not match adjoint layer %d (%d -> %d)", gin.C, gout.C,
+                  li, D.cin, D.cout);
+        return PNPX_ERR_SHAPE;
+      }
+      ConvHsFuse f;
+      f.dmask = saved ? FA + saved->off : nullptr;
+      f.slope = saved ? 0.2f : 1.0f;
+      return launch_conv_hs(Lh, GA + gin.off, gin.C / 8, nullptr, 0, GA + gout.off, B, gout.H, gout.W, f, s);
+    };
+    for (int l = 0; l <= 3; ++l) {
+      const int li = 15 + 3 * (3 - l);
+      PNPX_TRY(convH(li + 2, G.y[l], G.b[l], &F.db[l]));
+      PNPX_TRY(convH(li + 1, G.b[l], G.a[l], &F.da[l]));
+      PNPX_TRY(convH(li, G.a[l], G.cat[l], nullptr));
+      const Act& below_f = (l == 3) ? F.x[4] : F.y[l + 1];
+      const Act& below_g = (l == 3) ? G.x[4] : G.y[l + 1];
+      const int h = below_f.H, w = below_f.W, Gs = below_f.C / 8;
+      const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+      const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+      const size_t n = (size_t)B * Gs * h * w;
+      hipLaunchKernelGGL(upsample_bwd_hs_kernel, g1(n), dim3(256), 0, s, grec(G.cat[l]), G.cat[l].C / 8, F.x[l].C / 8,
+                         frec(below_f), grec(below_g), Gs, h, w, G.cat[l].H, G.cat[l].W, sy, sx, n);
+      PNPX_LAUNCH_CHECK();
+    }
+    for (int l = 4; l >= 0; --l) {
+      if (l < 4) {
+        const size_t n = (size_t)B * (F.x[l].C / 8) * F.x[l].H * F.x[l].W;
+        hipLaunchKernelGGL(skip_pool_merge_hs_kernel, g1(n), dim3(256), 0, s, grec(G.cat[l]), G.cat[l].C / 8,
+                           grec(G.p[l + 1]), frec(F.x[l]), grec(G.x[l]), F.x[l].C / 8, F.x[l].H, F.x[l].W, n);
+        PNPX_LAUNCH_CHECK();
+      }
+      PNPX_TRY(convH(3 * l + 2, G.x[l], G.b[l], &F.b[l]));
+      PNPX_TRY(convH(3 * l + 1, G.b[l], G.a[l], &F.a[l]));
+      PNPX_TRY(convH(3 * l, G.a[l], l == 0 ? G.in0 : G.p[l], nullptr));
+    }
+    hipLaunchKernelGGL(input_grad_hs_kernel, dim3(SIG_CHUNKS, B), dim3(256), 0, s, grec(G.in0), g_res, grad_x, part,
+                       gscale, H, W);
+    PNPX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sigma_grad_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, part, grad_sigma, B);
+    PNPX_LAUNCH_CHECK();
+    return PNPX_OK;
+  }
 
   // 3. tail: clamp + residual + 1x1 out-conv -> gradient wrt the pre-activation of the last conv (y[0])
   hipLaunchKernelGGL(outc_bwd_kernel, g1(npix), dim3(256), 0, s, grad_out, pre, ctx->outc_w, sact(F.y[0]), gptr(G.y[0]),
