@@ -90,6 +90,10 @@ struct PolicyNet {
   bool loaded = false;
   int num_inputs = 0, cin_pad = 0, n_det = 0, spi_head = 0;
   PolicyConv conv[17];       // stem, then per stage: conv1+shortcut, conv2, block-2 conv1, block-2 conv2
+  // the twelve stride-1 convolutions (per stage: conv2, block-2 conv1, block-2 conv2) packed for the half-split
+  // f16x3 MFMA kernel (conv_hs.hip); conv[] keeps their fp32 packing only for the stride-2 launches and the stem
+  ConvLayerHsDev conv_hs[12];
+  const float* bias_hs[12] = {};
   const float* fc_sm_w = nullptr;   // [2][512], [2]
   const float* fc_sm_b = nullptr;
   const float* fc_det_w = nullptr;  // [n_det][512] ([64][512] with the SPI head)

@@ -38,6 +38,8 @@ struct ConvHsArgs {
   // backward pass (input-gradient convolution): LeakyReLU' taken from the sign of a saved HS8 activation with the
   // geometry of `out` instead of from the result itself
   const char* dmask;
+  // residual add before the activation (policy ResNet blocks): HS8 tensor with the geometry of `out`
+  const char* res;
 };
 
 int conv_hs_mt(int cout);
@@ -51,7 +53,8 @@ struct ConvHsFuse {       // optional fused work
   float* out_img = nullptr;
   float* out_pre = nullptr;
   const char* dmask = nullptr;  // input-gradient mode: out = acc * (dmask > 0 ? 1 : slope), no bias expected (pass zeros)
-  float slope = 0.2f;           // 1.0 = linear epilogue
+  float slope = 0.2f;           // 1.0 = linear epilogue, 0.0 = ReLU
+  const char* res = nullptr;    // out = act(conv + bias + res)
 };
 // true when launch_conv_hs will honour ConvHsFuse::pool_out for this geometry
 bool conv_hs_can_pool(int H, int W);

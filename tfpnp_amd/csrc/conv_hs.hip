@@ -32,6 +32,7 @@ namespace pnpx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -401,6 +402,24 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
             }
           }
         }
+      } else if (a.res) {
+        // residual block tail: act(conv + bias + res); res is an HS8 tensor laid out like the output
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+          const int y = min(T.y0 + (wave * NBW + n) * G::MBH + py, a.H - 1), x = min(T.x0 + px, a.W - 1);
+          const size_t rec = img_rec + (size_t)(y + 1) * a.Wp + (x + 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const char* rp = a.res + (rec + (size_t)(T.ct * (MT / 8) + m * 4 + q) * HpWp) * 32 + 8 * kg;
+            const h4 rh = *reinterpret_cast<const h4*>(rp), rl = *reinterpret_cast<const h4*>(rp + 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float t = acc[m][n][q * 4 + j] * a.inv_scale + bias[q * 4 + j] +
+                              ((float)rh[j] + (float)rl[j]) * (1.f / HS_ASCALE);
+              v[n][q * 4 + j] = (t > 0.f ? t : t * a.slope) * HS_ASCALE;
+            }
+          }
+        }
       } else {
 #pragma unroll
         for (int n = 0; n < NBW; ++n)
@@ -651,6 +670,7 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.inv_scale = L.inv_scale;
   a.slope = fuse.slope;
   a.dmask = fuse.dmask;
+  a.res = fuse.res;
   a.tilesX = a.tilesY = 0;
   a.B = B;
   if (L.mt == 64) return launch_hs_mt<64>(a, B, s);

@@ -20,6 +20,8 @@
 #include <cstring>
 
 #include "common.h"
+#include "conv_hs.h"
+#include "hs_rec.h"
 #include "policy_conv.h"
 
 namespace pnpx {
@@ -45,7 +47,27 @@ __global__ __launch_bounds__(256) void pack_ob_s2d_kernel(const float* __restric
 }
 
 // global average pool over [B][512][h][w] (padded planar) + the two heads.  One workgroup per observation.
-__global__ __launch_bounds__(256) void pool_heads_kernel(const float* __restrict__ feat, int h, int w,
+// half-split HS8 [B][C/8][h+2][w+2] -> space-to-depth fp32 planar [B][4*C][h/2+2][w/2+8] (input of a stride-2 conv)
+__global__ __launch_bounds__(256) void hs8_to_s2d_kernel(const HsRec* __restrict__ src, float* __restrict__ dst, int C,
+                                                         int h, int w, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % w);
+  size_t t = i / w;
+  const int y = (int)(t % h);
+  t /= h;
+  const int g = (int)(t % (C >> 3));
+  const size_t b = t / (C >> 3);
+  float v[8];
+  hs_unpack(src[((b * (C >> 3) + g) * (h + 2) + (y + 1)) * (size_t)(w + 2) + (x + 1)], v);
+  const int Hp2 = padded_h(h >> 1), Wp2 = padded_w(w >> 1);
+  const int ph = (y & 1) * 2 + (x & 1);
+  float* o = dst + ((b * 4 * C + (size_t)ph * C + g * 8) * Hp2 + (y >> 1) + 1) * Wp2 + (x >> 1) + PADL;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[(size_t)k * Hp2 * Wp2] = v[k] * (1.f / HS_ASCALE);
+}
+
+__global__ __launch_bounds__(256) void pool_heads_kernel(const HsRec* __restrict__ feat, int h, int w,
                                                          const float* __restrict__ sm_w, const float* __restrict__ sm_b,
                                                          const float* __restrict__ d_w, const float* __restrict__ d_b,
                                                          const float* __restrict__ d2_w, const float* __restrict__ d2_b,
@@ -55,13 +77,15 @@ __global__ __launch_bounds__(256) void pool_heads_kernel(const float* __restrict
   __shared__ float hid[64];
   __shared__ float logit[2];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int Hp = padded_h(h), Wp = padded_w(w);
-  const float inv = 1.f / (float)(h * w);
+  const float inv = 1.f / ((float)(h * w) * HS_ASCALE);
   for (int c = tid; c < 512; c += 256) {
-    const float* p = feat + ((size_t)b * 512 + c) * Hp * Wp;
+    const HsRec* p = feat + ((size_t)b * 64 + (c >> 3)) * (h + 2) * (w + 2);
     float s = 0.f;
     for (int y = 0; y < h; ++y)
-      for (int x = 0; x < w; ++x) s += p[(y + 1) * Wp + x + PADL];
+      for (int x = 0; x < w; ++x) {
+        const HsRec& r = p[(y + 1) * (w + 2) + x + 1];
+        s += (float)r.hi[c & 7] + (float)r.lo[c & 7];
+      }
     f[c] = s * inv;
   }
   __syncthreads();
@@ -227,8 +251,9 @@ struct PolAct {
   int C = 0, H = 0, W = 0;
 };
 struct PolicyPlan {
-  PolAct ob, stem;               // both space-to-depth
-  PolAct t1[4], sc[4], o0[4], t2[4], o1[4];
+  PolAct ob, stem;               // fp32, space-to-depth
+  PolAct t1[4], sc[4], o0[4], t2[4], o1[4];   // half-split HS8 (same 4 bytes per value)
+  PolAct o1s[3];                 // fp32 space-to-depth copy of o1 for the next stage's stride-2 convolution
   size_t total = 0;              // floats for capB observations
 };
 PolicyPlan make_policy_plan(int capB, int cin_pad, int H, int W) {
@@ -242,16 +267,24 @@ PolicyPlan make_policy_plan(int capB, int cin_pad, int H, int W) {
     off += (size_t)C * padded_h(h) * padded_w(w) * capB;
     off = (off + 63) & ~(size_t)63;
   };
+  auto add_hs = [&](PolAct& d, int C, int h, int w) {   // [C/8][h+2][w+2] records of 8 floats' worth
+    d.off = off;
+    d.C = C;
+    d.H = h;
+    d.W = w;
+    off += (size_t)C * (h + 2) * (w + 2) * capB;
+    off = (off + 63) & ~(size_t)63;
+  };
   add(P.ob, 4 * cin_pad, H / 2, W / 2);
   add(P.stem, 4 * 64, H / 4, W / 4);
   for (int n = 0; n < 4; ++n) {
     const int p = stage_planes(n), h = H >> (n + 2), w = W >> (n + 2);
-    add(P.t1[n], p, h, w);
-    add(P.sc[n], p, h, w);
-    add(P.o0[n], p, h, w);
-    add(P.t2[n], p, h, w);
-    if (n < 3) add(P.o1[n], 4 * p, h / 2, w / 2);
-    else add(P.o1[n], p, h, w);
+    add_hs(P.t1[n], p, h, w);
+    add_hs(P.sc[n], p, h, w);
+    add_hs(P.o0[n], p, h, w);
+    add_hs(P.t2[n], p, h, w);
+    add_hs(P.o1[n], p, h, w);
+    if (n < 3) add(P.o1s[n], 4 * p, h / 2, w / 2);
   }
   P.total = off + (1u << 18);   // slack: overhanging tiles read past their tensor
   return P;
@@ -299,6 +332,26 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
   ConvOff off[17];
   int cins[17], couts[17], splits[17];
   int li = 0;
+  auto skip_fp32 = [&]() {                  // slot kept for indexing; the stride-1 convolutions only exist half-split
+    off[li] = ConvOff{0, 0, 0, 0};
+    cins[li] = couts[li] = splits[li] = 0;
+    ++li;
+  };
+  // half-split packing of the stride-1 convolutions (folded weights E.w are [cout][K][9] dense, E.bias the shift)
+  size_t hs_w[12], hs_b[12];
+  float hs_scale[12];
+  int hs_c[12];
+  int hi_ = 0;
+  auto finish_hs = [&](Eff& E) {
+    H.align();
+    hs_w[hi_] = H.f.size();
+    const size_t n16 = (size_t)E.cout * E.K * 9 * 2;
+    H.f.resize(H.f.size() + (n16 + 1) / 2, 0.f);
+    hs_scale[hi_] = pack_conv_weights_hs(E.w.data(), E.cout, E.K, 64, reinterpret_cast<uint16_t*>(H.f.data() + hs_w[hi_]));
+    hs_b[hi_] = H.add(E.bias.data(), E.bias.size());
+    hs_c[hi_] = E.cout;
+    ++hi_;
+  };
   auto finish = [&](Eff& E, int split) {
     off[li] = pack_eff(H, E);
     cins[li] = E.K;
@@ -332,7 +385,8 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
     {
       Eff E(p, p);
       put_conv_s1(E, 0, w2, b2, p, p);
-      finish(E, p);
+      skip_fp32();
+      finish_hs(E);
     }
     // block 1 (stride 1, identity shortcut)
     for (int j = 0; j < 2; ++j) {
@@ -340,7 +394,8 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
       const BnView b = R.bn(p);
       Eff E(p, p);
       put_conv_s1(E, 0, w, b, p, p);
-      finish(E, p);
+      skip_fp32();
+      finish_hs(E);
     }
     in_planes = p;
   }
@@ -375,6 +430,13 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
     N.conv[i].cin = cins[i];
     N.conv[i].cout = couts[i];
     N.conv[i].split_c = splits[i];
+  }
+  for (int i = 0; i < 12; ++i) {
+    N.conv_hs[i].cin = N.conv_hs[i].cout = N.conv_hs[i].cin_pad = hs_c[i];
+    N.conv_hs[i].mt = 64;
+    N.conv_hs[i].w = const_cast<char*>(reinterpret_cast<const char*>(base + hs_w[i]));
+    N.conv_hs[i].inv_scale = 1.0f / (hs_scale[i] * HS_ASCALE);
+    N.bias_hs[i] = base + hs_b[i];
   }
   N.fc_sm_w = base + o_smw;
   N.fc_sm_b = base + o_smb;
@@ -428,17 +490,42 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
   PNPX_LAUNCH_CHECK();
   // stem (on the H/2 grid) -> space-to-depth for stage 1
   PNPX_TRY(launch_policy_conv(N.conv[0], ptr(P.ob), ptr(P.stem), nullptr, nullptr, true, B, H / 2, W / 2, s));
+  // residual stages.  The stride-2 entry (conv1 + 1x1 shortcut, one fp32 tap-sparse launch) writes its two outputs as
+  // half-split HS8 tensors; the three stride-1 convolutions of the stage run on the f16x3 MFMA kernel (conv_hs.hip:
+  // folded-BN bias, residual add and ReLU in its epilogue); the stage output is re-laid out space-to-depth in fp32 for
+  // the next stage's stride-2 launch.
+  auto hsc = [&](const PolAct& d) { return reinterpret_cast<char*>(A + d.off); };
+  auto conv_hs = [&](int i, const PolAct& in, const PolAct& out, const PolAct* res, int h, int w) -> int {
+    const ConvLayerHsDev& D = N.conv_hs[i];
+    ConvLayerHs Lh;
+    Lh.cin = D.cin;
+    Lh.cout = D.cout;
+    Lh.cin_pad = D.cin_pad;
+    Lh.mt = D.mt;
+    Lh.w = D.w;
+    Lh.b = N.bias_hs[i];
+    Lh.inv_scale = D.inv_scale;
+    ConvHsFuse f;
+    f.slope = 0.f;                          // ReLU
+    f.res = res ? hsc(*res) : nullptr;
+    return launch_conv_hs(Lh, hsc(in), in.C / 8, nullptr, 0, hsc(out), B, h, w, f, s);
+  };
   const float* xin = ptr(P.stem);
   for (int st = 0; st < 4; ++st) {
     const int h = H >> (st + 2), w = W >> (st + 2);
-    const PolicyConv* L = &N.conv[1 + 4 * st];
-    PNPX_TRY(launch_policy_conv(L[0], xin, ptr(P.t1[st]), ptr(P.sc[st]), nullptr, false, B, h, w, s));
-    PNPX_TRY(launch_policy_conv(L[1], ptr(P.t1[st]), ptr(P.o0[st]), nullptr, ptr(P.sc[st]), false, B, h, w, s));
-    PNPX_TRY(launch_policy_conv(L[2], ptr(P.o0[st]), ptr(P.t2[st]), nullptr, nullptr, false, B, h, w, s));
-    PNPX_TRY(launch_policy_conv(L[3], ptr(P.t2[st]), ptr(P.o1[st]), nullptr, ptr(P.o0[st]), st < 3, B, h, w, s));
-    xin = ptr(P.o1[st]);
+    PNPX_TRY(launch_policy_conv(N.conv[1 + 4 * st], xin, ptr(P.t1[st]), ptr(P.sc[st]), nullptr, false, B, h, w, s, true));
+    PNPX_TRY(conv_hs(3 * st + 0, P.t1[st], P.o0[st], &P.sc[st], h, w));
+    PNPX_TRY(conv_hs(3 * st + 1, P.o0[st], P.t2[st], nullptr, h, w));
+    PNPX_TRY(conv_hs(3 * st + 2, P.t2[st], P.o1[st], &P.o0[st], h, w));
+    if (st < 3) {
+      const size_t n8 = (size_t)B * (P.o1[st].C / 8) * h * w;
+      hipLaunchKernelGGL(hs8_to_s2d_kernel, g1(n8), dim3(256), 0, s, reinterpret_cast<const HsRec*>(hsc(P.o1[st])),
+                         ptr(P.o1s[st]), P.o1[st].C, h, w, n8);
+      PNPX_LAUNCH_CHECK();
+      xin = ptr(P.o1s[st]);
+    }
   }
-  hipLaunchKernelGGL(pool_heads_kernel, dim3(B), dim3(256), 0, s, ptr(P.o1[3]), H / 32, W / 32, N.fc_sm_w, N.fc_sm_b,
+  hipLaunchKernelGGL(pool_heads_kernel, dim3(B), dim3(256), 0, s, reinterpret_cast<const HsRec*>(hsc(P.o1[3])), H / 32, W / 32, N.fc_sm_w, N.fc_sm_b,
                      N.fc_det_w, N.fc_det_b, N.fc_det2_w, N.fc_det2_b, N.n_det, N.spi_head, probs, det);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;

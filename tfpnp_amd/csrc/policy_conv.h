@@ -12,7 +12,9 @@ struct PolStep {
   unsigned int wofs;      // offset of the first present tap slice, in 512-float ([8][64]) slices
 };
 
+// out_hs: both outputs are written as half-split HS8 tensors ([B][C/8][H+2][W+2] records, conv_hs.hip) for the
+// stride-1 convolutions of the residual blocks, which run on the f16x3 MFMA kernel.
 int launch_policy_conv(const PolicyConv& L, const float* in, float* out, float* out2, const float* res, bool s2d, int B,
-                       int H, int W, hipStream_t s);
+                       int H, int W, hipStream_t s, bool out_hs = false);
 
 }  // namespace pnpx

@@ -16,6 +16,8 @@
 //     optional space-to-depth store for a following stride-2 convolution.
 #include "policy_conv.h"
 
+#include "conv_hs.h"
+
 namespace pnpx {
 namespace {
 
@@ -46,6 +48,7 @@ struct PolArgs {
   int VH;
   int tilesX, tilesY, nct;
   int split, C_out1, C_out2, s2d;
+  int out_hs;
 };
 
 constexpr int MT = 64, CC = 8;
@@ -217,6 +220,32 @@ __global__ __launch_bounds__(256) void policy_conv_kernel(PolArgs a) {
       ok = ok && rr >= 1 && rr <= a.H && img < a.B;
     }
     if (!ok) continue;
+    if (a.out_hs) {
+      // half-split store: this lane holds 4 of the 8 channels of each record (channels 4*khalf .. +3 of group q)
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int m = 0; m < MTB; ++m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          h4 hi, lo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int cl = (m + mhalf) * 32 + j + 8 * q + 4 * khalf;
+            float v = acc[m][n][q * 4 + j] + a.bias[ct * MT + cl];
+            if (!second) v = fmaxf(v, 0.f);
+            v *= HS_ASCALE;
+            hi[j] = (_Float16)v;
+            lo[j] = (_Float16)(v - (float)hi[j]);
+          }
+          const int g = ((c0 + (m + mhalf) * 32) >> 3) + q;
+          char* rp = reinterpret_cast<char*>(obase) +
+                     ((((size_t)img * (Cthis >> 3) + g) * (a.H + 2) + (y + 1)) * (size_t)(a.W + 2) + (x + 1)) * 32 + 8 * khalf;
+          *reinterpret_cast<h4*>(rp) = hi;
+          *reinterpret_cast<h4*>(rp + 16) = lo;
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int m = 0; m < MTB; ++m) {
 #pragma unroll
@@ -256,7 +285,7 @@ int launch_cfg(PolArgs a, hipStream_t s) {
 }  // namespace
 
 int launch_policy_conv(const PolicyConv& L, const float* in, float* out, float* out2, const float* res, bool s2d, int B,
-                       int H, int W, hipStream_t s) {
+                       int H, int W, hipStream_t s, bool out_hs) {
   if (L.cin % 8 != 0 || L.cout % 64 != 0 || L.split_c % 64 != 0 || (s2d && ((H | W) & 1))) {
     set_error("policy conv: unsupported geometry (cin %d cout %d split %d H %d W %d)", L.cin, L.cout, L.split_c, H, W);
     return PNPX_ERR_SHAPE;
@@ -283,6 +312,7 @@ int launch_policy_conv(const PolicyConv& L, const float* in, float* out, float* 
   a.C_out1 = L.split_c;
   a.C_out2 = L.cout - L.split_c;
   a.s2d = s2d ? 1 : 0;
+  a.out_hs = out_hs ? 1 : 0;
   a.tilesX = a.tilesY = 0;
   const int mbw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
   auto blocks = [&](int nbw) {
