@@ -154,3 +154,14 @@ def test_denoiser_ragged_batches_reuse_workspace(den, oden):
     for idx in ([6], [0, 3], [1, 2, 4, 5, 6], [5, 1], list(range(7))):
         assert torch.equal(den(g(x[idx]), g(s[idx])), full[idx])
     assert rel(full[:2], oden(t(x[:2]), t(s[:2]))) < 1e-4
+
+
+@pytest.mark.parametrize("B,R,V", [(3, 100, 17), (2, 64, 180), (1, 511, 7)])
+def test_radon_forward_odd_geometries_vs_oracle(B, R, V):
+    """Transposed-copy projector (steep views read the transposed image): odd sizes, many / few views."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.utils import transforms as T
+    gt = torch.rand(B, 1, R, R, generator=torch.Generator().manual_seed(R))
+    radon = T.Radon_norm(R, V, device=dev(), opnorm=1.0)
+    angles, det = O.radon_geometry(R, V)
+    assert rel(radon.forward(gt.to(dev())), O.radon_forward(gt, angles, det)) < 1e-5

@@ -13,12 +13,3 @@ for (B, R, V) in [(32, 256, 30), (32, 256, 120), (8, 512, 60)]:
         for _ in range(10): f()
         torch.cuda.synchronize()
         print(f"B={B} R={R} V={V} radon {name}: {(time.perf_counter()-t0)/10*1e3:.3f} ms", flush=True)
-# exactness of the LDS-staged projector against the direct one is covered by tests (oracle parity at 1e-5); here: odd sizes
-for (B, R, V) in [(3, 100, 17), (2, 64, 180), (1, 511, 7)]:
-    gt = torch.rand(B, 1, R, R, device=dev)
-    radon = T.Radon_norm(R, V, device=dev, opnorm=1.0)
-    y = radon.forward(gt)
-    from oracle import pnp_oracle as O
-    a, d = O.radon_geometry(R, V)
-    ref = O.radon_forward(gt.cpu(), a, d)
-    print(f"B={B} R={R} V={V}: rel err vs oracle {float((y.cpu()-ref).norm()/ref.norm()):.2e}", flush=True)
