@@ -41,9 +41,9 @@ __global__ __launch_bounds__(256) void pack_ob_s2d_kernel(const float* __restric
   t /= H;
   const int c = (int)(t % C);
   const size_t b = t / C;
-  const int Hp2 = padded_h(H >> 1), Wp2 = padded_w(W >> 1);
+  const int Hp2 = padded_h(H >> 1), Wp2 = pol_wp(W >> 1);
   const int ph = (y & 1) * 2 + (x & 1);
-  out[((b * 4 * Cp + (size_t)ph * Cp + c) * Hp2 + (y >> 1) + 1) * Wp2 + (x >> 1) + PADL] = ob[i];
+  out[((b * 4 * Cp + (size_t)ph * Cp + c) * Hp2 + (y >> 1) + 1) * Wp2 + (x >> 1) + POL_PADL] = ob[i];
 }
 
 // global average pool over [B][512][h][w] (padded planar) + the two heads.  One workgroup per observation.
@@ -60,9 +60,9 @@ __global__ __launch_bounds__(256) void hs8_to_s2d_kernel(const HsRec* __restrict
   const size_t b = t / (C >> 3);
   float v[8];
   hs_unpack(src[((b * (C >> 3) + g) * (h + 2) + (y + 1)) * (size_t)(w + 2) + (x + 1)], v);
-  const int Hp2 = padded_h(h >> 1), Wp2 = padded_w(w >> 1);
+  const int Hp2 = padded_h(h >> 1), Wp2 = pol_wp(w >> 1);
   const int ph = (y & 1) * 2 + (x & 1);
-  float* o = dst + ((b * 4 * C + (size_t)ph * C + g * 8) * Hp2 + (y >> 1) + 1) * Wp2 + (x >> 1) + PADL;
+  float* o = dst + ((b * 4 * C + (size_t)ph * C + g * 8) * Hp2 + (y >> 1) + 1) * Wp2 + (x >> 1) + POL_PADL;
 #pragma unroll
   for (int k = 0; k < 8; ++k) o[(size_t)k * Hp2 * Wp2] = v[k] * (1.f / HS_ASCALE);
 }
@@ -264,7 +264,7 @@ PolicyPlan make_policy_plan(int capB, int cin_pad, int H, int W) {
     d.C = C;
     d.H = h;
     d.W = w;
-    off += (size_t)C * padded_h(h) * padded_w(w) * capB;
+    off += (size_t)C * padded_h(h) * pol_wp(w) * capB;
     off = (off + 63) & ~(size_t)63;
   };
   auto add_hs = [&](PolAct& d, int C, int h, int w) {   // [C/8][h+2][w+2] records of 8 floats' worth

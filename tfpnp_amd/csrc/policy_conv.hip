@@ -58,12 +58,13 @@ struct Geom {
   static constexpr int MBH = 32 / MBW;
   static constexpr int TW = MBW;
   static constexpr int TH = 4 * NBW * MBH;
-  static constexpr int LW = TW + 2;
+  static constexpr int LW4 = (TW + 2 + 3) / 4;      // 16-byte units per LDS halo row
+  static constexpr int LW = LW4 * 4;                // LDS row pitch in floats (>= TW + 2)
   static constexpr int LH = TH + 2;
   static constexpr int PLANE = LW * LH;
-  static constexpr int IN_ELEMS = CC * PLANE;
-  static constexpr int IN_INSTR = (IN_ELEMS + 63) / 64;
-  static constexpr int IN_PAD = IN_INSTR * 64;
+  static constexpr int IN_UNITS = CC * LH * LW4;    // 16-byte lane loads per chunk
+  static constexpr int IN_INSTR = (IN_UNITS + 63) / 64;
+  static constexpr int IN_PAD = IN_INSTR * 256;     // floats
   static constexpr int NI = (IN_INSTR + 3) / 4;
   static constexpr int W_ELEMS = 9 * CC * MT;      // LDS slot for all 9 taps (absent ones stay unused)
   static constexpr int W_INSTR = 18;               // two 256-float copies per tap
@@ -96,17 +97,18 @@ __global__ __launch_bounds__(256) void policy_conv_kernel(PolArgs a) {
   const size_t img_stride = (size_t)a.K * HpWp;
   const int nchunk = a.K / CC;
 
-  // ---- per-thread gather offsets of the halo (relative to channel 0 of the chunk, image b)
+  // ---- per-thread source offsets (floats) of the halo's 16-byte units (relative to channel 0 of the chunk, image b);
+  //      the LDS image [c][hy][LW] is lane-linear in that order, so unit idx lands at float 4 * idx
   int ioff[G::NI];
 #pragma unroll
   for (int k = 0; k < G::NI; ++k) {
     const int idx = (wave + 4 * k) * 64 + lane;
-    const int c = idx / G::PLANE;
-    const int r = idx - c * G::PLANE;
-    const int hy = r / G::LW;
-    const int hx = r - hy * G::LW;
+    const int c = idx / (G::LH * G::LW4);
+    const int r = idx - c * (G::LH * G::LW4);
+    const int hy = r / G::LW4;
+    const int hx = (r - hy * G::LW4) * 4;
     int off = 0;
-    if (idx < G::IN_ELEMS) {
+    if (idx < G::IN_UNITS) {
       if (a.vstack) {
         const int vr = y0 + hy;                   // padded virtual row
         const int img = vr / a.Hp;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void policy_conv_kernel(PolArgs a) {
     }
     ioff[k] = off;
   }
-  const float* in_base = a.in + (size_t)b * img_stride + x0 + (PADL - 1);
+  const float* in_base = a.in + (size_t)b * img_stride + x0 + (POL_PADL - 1);
   const PolStep* steps = a.steps + (size_t)ct * nchunk;
   const int nsteps = a.nsteps[ct];
 
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void policy_conv_kernel(PolArgs a) {
   auto issue_slot = [&](int slot, const float* src, const float* wsrc, unsigned mask, float* lstage) {
     if (slot < G::NI) {
       const int instr = wave + 4 * slot;
-      if (instr < G::IN_INSTR) glds4(src + ioff[slot], lstage + instr * 64);
+      if (instr < G::IN_INSTR) glds16(src + ioff[slot], lstage + instr * 256);
     } else {
       const int j = wave + 4 * (slot - G::NI);    // copy j: tap j/2, half j%2
       if (j < G::W_INSTR) {
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void policy_conv_kernel(PolArgs a) {
   float* obase = second ? a.out2 : a.out;
   const int Cthis = second ? a.C_out2 : a.C_out1;
   const int c0 = (second ? ct - a.split : ct) * MT;
-  const int Hp2 = padded_h(a.H >> 1), Wp2 = padded_w(a.W >> 1);
+  const int Hp2 = padded_h(a.H >> 1), Wp2 = pol_wp(a.W >> 1);
 #pragma unroll
   for (int n = 0; n < NBW; ++n) {
     const int vy = y0 + (wave * NBW + n) * G::MBH + py;     // interior row of the (virtual) image
@@ -253,12 +255,12 @@ __global__ __launch_bounds__(256) void policy_conv_kernel(PolArgs a) {
         const int cl = (m + mhalf) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         const int c = c0 + cl;
         float v = acc[m][n][r] + a.bias[ct * MT + cl];
-        const size_t off = (((size_t)img * Cthis + c) * a.Hp + (y + 1)) * a.Wp + x + PADL;
+        const size_t off = (((size_t)img * Cthis + c) * a.Hp + (y + 1)) * a.Wp + x + POL_PADL;
         if (a.res) v += a.res[off];
         if (!second) v = fmaxf(v, 0.f);
         if (a.s2d) {
           const int ph = (y & 1) * 2 + (x & 1);
-          obase[(((size_t)img * 4 * Cthis + ph * Cthis + c) * Hp2 + (y >> 1) + 1) * Wp2 + (x >> 1) + PADL] = v;
+          obase[(((size_t)img * 4 * Cthis + ph * Cthis + c) * Hp2 + (y >> 1) + 1) * Wp2 + (x >> 1) + POL_PADL] = v;
         } else {
           obase[off] = v;
         }
@@ -303,7 +305,7 @@ int launch_policy_conv(const PolicyConv& L, const float* in, float* out, float* 
   a.H = H;
   a.W = W;
   a.Hp = padded_h(H);
-  a.Wp = padded_w(W);
+  a.Wp = pol_wp(W);
   a.B = B;
   a.vstack = (H <= 16 && B > 1 && (size_t)B * L.cin * a.Hp * a.Wp < (1u << 30)) ? 1 : 0;   // int gather offsets
   a.VH = a.vstack ? B * a.Hp - 2 : H;
