@@ -81,8 +81,11 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
   // SAME XCD that run at the same time (consecutive "slots"): step k of workgroup (xcd, slot) handles
   //   j = slot + nslot*k,  pixel region p = 8*(j / nct) + xcd,  cout tile ct = j % nct.
   // nct divides nslot, so a workgroup keeps one cout tile (its weight slice stays hot) for its whole life.
+  // With few pixel regions (small batches / deep levels) that grouping would leave whole XCDs idle and funnel every
+  // weight byte through one XCD (measured at B=1, 8x8 level: 386 us with the 8 cout tiles on one XCD, 53 us spread
+  // over eight), so below 32 regions the work items are simply dealt out to consecutive workgroups (= XCDs).
   const int nregions = a.tilesX * a.tilesY * a.B;
-  const int nx = (gridDim.x % 8 == 0) ? 8 : 1;
+  const int nx = (gridDim.x % 8 == 0 && nregions >= 32) ? 8 : 1;
   const int xcd = blockIdx.x % nx, nslot = gridDim.x / nx;
 
   // per-thread byte offsets of the halo gather (identical for every chunk and tile)
