@@ -1,178 +1,117 @@
-"""Solver state containers -- mirror of tfpnp/pnp/solver/base.py:5-232 (same class names, same
-reset / get_output / num_var / filter_hyperparameter / prox_mapping surface).
+"""Solver state containers -- the surface of tfpnp/pnp/solver/base.py:5-232 (same class names, same
+reset / get_output / num_var / filter_hyperparameter / prox_mapping contract).
 
-State packing is pure tensor bookkeeping (cat / split / clone on whatever device the data lives on); the
-iteration loops themselves are native and live in tfpnp_amd/tasks/*.
+The reference spells the packing out once per solver family; here a family is described by data -- how many state
+variables it carries, how each is initialised from the input dictionary, which policy outputs drive it -- and one
+implementation does the tensor bookkeeping (cat / split / clone on whatever device the data lives on).  The iteration
+loops themselves are native and live in tfpnp_amd/tasks/*.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
 
 class PnPSolver(nn.Module):
-    """tfpnp/pnp/solver/base.py:5-84"""
+    """tfpnp/pnp/solver/base.py:5-84.  Sub-classes set `init_vars` and `hyper_keys`, or override the methods."""
+
+    # state variables in packing order: 'x0' = copy of data['x0'], 'zero' = zeros like x0, 'y0' = copy of data['y0']
+    init_vars = None
+    # policy outputs consumed by forward(), in order
+    hyper_keys = None
 
     def __init__(self, denoiser):
         super().__init__()
         self.denoiser = denoiser
 
+    # ---- contract used by PnPEnv ---------------------------------------------------------------------------
+    @property
+    def num_var(self):
+        if self.init_vars is None:
+            raise NotImplementedError
+        return len(self.init_vars)
+
     def reset(self, data):
+        if self.init_vars is None:
+            raise NotImplementedError
+        parts = []
+        for kind in self.init_vars:
+            if kind == 'zero':
+                parts.append(torch.zeros_like(data['x0']))
+            else:
+                parts.append(data[kind].clone().detach())
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
+    def get_output(self, state):
+        if self.init_vars is None:
+            raise NotImplementedError
+        n = len(self.init_vars)
+        return state if n == 1 else state[:, :state.shape[1] // n]
+
+    def filter_hyperparameter(self, action):
+        if self.hyper_keys is None:
+            raise NotImplementedError
+        picked = tuple(action[k] for k in self.hyper_keys)
+        return picked[0] if len(picked) == 1 else picked
+
+    def filter_aux_inputs(self, state):
         raise NotImplementedError
 
     def forward(self, inputs, parameters, iter_num):
         raise NotImplementedError
 
-    def get_output(self, state):
-        raise NotImplementedError
-
     def prox_mapping(self, x, sigma):
         return self.denoiser(x, sigma)
-
-    @property
-    def num_var(self):
-        raise NotImplementedError
-
-    def filter_aux_inputs(self, state):
-        raise NotImplementedError
-
-    def filter_hyperparameter(self, action):
-        raise NotImplementedError
 
     # native context of the denoiser for the device the state lives on
     def _ctx(self, t):
         return self.denoiser.context(t.device)
 
 
-def _first(state, n):
-    return torch.split(state, state.shape[1] // n, dim=1)[0]
-
-
 class ADMMSolver(PnPSolver):
-    """tfpnp/pnp/solver/base.py:87-107"""
-
-    @property
-    def num_var(self):
-        return 3
-
-    def reset(self, data):
-        x = data['x0'].clone().detach()
-        z = x.clone().detach()
-        u = torch.zeros_like(x)
-        return torch.cat((x, z, u), dim=1)
-
-    def get_output(self, state):
-        return _first(state, 3)
-
-    def filter_hyperparameter(self, action):
-        return action['sigma_d'], action['mu']
+    """base.py:87-107 -- (x, z, u) = (x0, x0, 0); hyper-parameters (sigma_d, mu)"""
+    init_vars = ('x0', 'x0', 'zero')
+    hyper_keys = ('sigma_d', 'mu')
 
 
 class IADMMSolver(ADMMSolver):
-    """tfpnp/pnp/solver/base.py:110-116"""
-
-    def filter_hyperparameter(self, action):
-        return action['sigma_d'], action['mu'], action['tau']
+    """base.py:110-116 -- inexact ADMM adds the step size tau"""
+    hyper_keys = ('sigma_d', 'mu', 'tau')
 
 
 class HQSSolver(PnPSolver):
-    """tfpnp/pnp/solver/base.py:118-138"""
-
-    @property
-    def num_var(self):
-        return 2
-
-    def reset(self, data):
-        x = data['x0'].clone().detach()
-        z = x.clone().detach()
-        return torch.cat([x, z], dim=1)
-
-    def get_output(self, state):
-        return _first(state, 2)
-
-    def filter_hyperparameter(self, action):
-        return action['sigma_d'], action['mu']
+    """base.py:118-138 -- (x, z) = (x0, x0)"""
+    init_vars = ('x0', 'x0')
+    hyper_keys = ('sigma_d', 'mu')
 
 
 class PGSolver(PnPSolver):
-    """tfpnp/pnp/solver/base.py:140-158"""
-
-    @property
-    def num_var(self):
-        return 1
-
-    def reset(self, data):
-        return data['x0'].clone().detach()
-
-    def get_output(self, state):
-        return state
-
-    def filter_hyperparameter(self, action):
-        return action['sigma_d'], action['tau']
+    """base.py:140-158 -- x = x0"""
+    init_vars = ('x0',)
+    hyper_keys = ('sigma_d', 'tau')
 
 
 class APGSolver(PnPSolver):
-    """tfpnp/pnp/solver/base.py:160-186"""
+    """base.py:160-186 -- (x, s) = (x0, x0); `qs` is the FISTA momentum sequence q_{k+1} = (1 + sqrt(1 + 4 q_k^2)) / 2
+    the reference tabulates (unused by its forward, kept for attribute parity)."""
+    init_vars = ('x0', 'x0')
+    hyper_keys = ('sigma_d', 'tau', 'beta')
 
     def __init__(self, denoiser):
         super().__init__(denoiser)
-        import numpy as np
-        self.qs = np.zeros(30)
-        q = 1
-        for i in range(30):
-            self.qs[i] = q
-            q_prev = q
-            q = (1 + (1 + 4 * q_prev ** 2) ** 0.5) / 2
-
-    @property
-    def num_var(self):
-        return 2
-
-    def reset(self, data):
-        x = data['x0'].clone().detach()
-        s = x.clone().detach()
-        return torch.cat([x, s], dim=1)
-
-    def get_output(self, state):
-        return _first(state, 2)
-
-    def filter_hyperparameter(self, action):
-        return action['sigma_d'], action['tau'], action['beta']
+        qs = [1.0]
+        while len(qs) < 30:
+            qs.append((1 + (1 + 4 * qs[-1] ** 2) ** 0.5) / 2)
+        self.qs = np.asarray(qs)
 
 
 class REDADMMSolver(PnPSolver):
-    """tfpnp/pnp/solver/base.py:189-209"""
-
-    @property
-    def num_var(self):
-        return 3
-
-    def reset(self, data):
-        x = data['x0'].clone().detach()
-        z = x.clone().detach()
-        u = torch.zeros_like(x)
-        return torch.cat([x, z, u], dim=1)
-
-    def get_output(self, state):
-        return _first(state, 3)
-
-    def filter_hyperparameter(self, action):
-        return action['sigma_d'], action['mu'], action['lamda']
+    """base.py:189-209 -- (x, z, u) = (x0, x0, 0); hyper-parameters (sigma_d, mu, lamda)"""
+    init_vars = ('x0', 'x0', 'zero')
+    hyper_keys = ('sigma_d', 'mu', 'lamda')
 
 
 class AMPSolver(PnPSolver):
-    """tfpnp/pnp/solver/base.py:212-232.  State packing only: the reference's AMPSolver_CSMRI.forward calls an
+    """base.py:212-232 -- (x, z) = (0, y0).  State packing only: the reference's AMPSolver_CSMRI.forward calls an
     undefined self.prox_fun (tasks/csmri/solver.py:238) and cannot run, so no AMP loop exists here either."""
-
-    @property
-    def num_var(self):
-        return 2
-
-    def reset(self, data):
-        z = data['y0'].clone().detach()
-        x = torch.zeros_like(data['x0'])
-        return torch.cat([x, z], dim=1)
-
-    def get_output(self, state):
-        return _first(state, 2)
-
-    def filter_hyperparameter(self, action):
-        return action['sigma_d']
+    init_vars = ('zero', 'y0')
+    hyper_keys = ('sigma_d',)
