@@ -165,3 +165,48 @@ def test_radon_forward_odd_geometries_vs_oracle(B, R, V):
     radon = T.Radon_norm(R, V, device=dev(), opnorm=1.0)
     angles, det = O.radon_geometry(R, V)
     assert rel(radon.forward(gt.to(dev())), O.radon_forward(gt, angles, det)) < 1e-5
+
+
+def test_two_contexts_from_two_threads_and_side_streams(unet_params):
+    """Threading / stream contract of the boundary (include/pnpx.h): one ctx per thread, work enqueued on the caller's
+    current stream.  Two host threads drive two contexts concurrently on side streams; results equal the serial ones."""
+    import threading
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
+    B, H, W = 3, 64, 64
+    jobs = []
+    for k in range(2):
+        d = synth.make_csmri_batch(B, H, W, seed=200 + k)
+        a = csmri_actions(B, 4, 210 + k)
+        jobs.append((d, a))
+    serial = []
+    for d, a in jobs:
+        sol = ADMMSolver_CSMRI(UNetDenoiser2D(state_dict=unet_params))
+        v0 = sol.reset({"x0": g(d["x0"])})
+        serial.append(sol((v0, (g(d["y0"]), g(d["mask"]))), (g(a["sigma_d"]), g(a["mu"]))).clone())
+    out = [None, None]
+    errs = []
+
+    def work(k):
+        try:
+            d, a = jobs[k]
+            sol = ADMMSolver_CSMRI(UNetDenoiser2D(state_dict=unet_params))     # its own denoiser -> its own pnpx_ctx
+            st = torch.cuda.Stream(device=dev())
+            with torch.cuda.stream(st):
+                v0 = sol.reset({"x0": g(d["x0"])})
+                args = ((v0, (g(d["y0"]), g(d["mask"]))), (g(a["sigma_d"]), g(a["mu"])))
+                for _ in range(3):
+                    r = sol(*args)
+                out[k] = r.clone()
+            st.synchronize()
+        except Exception as e:   # surfaced in the main thread
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join()
+    assert not errs, errs
+    for k in range(2):
+        assert torch.equal(out[k], serial[k])
