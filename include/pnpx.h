@@ -31,7 +31,7 @@ typedef struct pnpx_ctx pnpx_ctx; /* opaque: device id, packed UNet weights, wor
 enum pnpx_status {
   PNPX_OK = 0,
   PNPX_ERR_ARG = 1,         /* null pointer / non-positive size                                  */
-  PNPX_ERR_SHAPE = 2,       /* unsupported geometry (e.g. FFT size not a power of two)           */
+  PNPX_ERR_SHAPE = 2,       /* unsupported geometry (e.g. FFT length > 2048, image side < 16)    */
   PNPX_ERR_NO_WEIGHTS = 3,  /* denoiser used before pnpx_unet_load                               */
   PNPX_ERR_ALLOC = 4,       /* device allocation failed                                          */
   PNPX_ERR_HIP = 5          /* a HIP runtime call failed; see pnpx_last_error()                  */
