@@ -58,3 +58,84 @@ def test_single_process_passthrough():
     x = torch.arange(6.0).view(3, 2)
     assert torch.equal(D.all_gather_rows(x, 3), x)
     assert D.max_over_ranks(1.5, torch.device("cpu")) == 1.5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Episode loop over two ranks (ShardedEnv): uneven shards, per-item early stopping, one rank finishing first.
+class _StubSolver(torch.nn.Module):
+    """CPU stand-in with the PnPSolver contract: x <- x + mu * (gt_hint - x) per call (no GPU needed)."""
+
+    def reset(self, data):
+        return data['x0'].clone()
+
+    def get_output(self, state):
+        return state
+
+    def filter_aux_inputs(self, state):
+        return (state['gt'],)
+
+    def filter_hyperparameter(self, action):
+        return (action['mu'],)
+
+    def forward(self, inputs, parameters):
+        x, (gt,) = inputs
+        (mu,) = parameters
+        return x + mu.view(-1, 1, 1, 1) * (gt - x)
+
+
+def _episode_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from tfpnp_amd import dist as D
+    from tfpnp_amd.env.base import PnPEnv
+    D.init_from_env(backend="gloo")
+
+    class StubEnv(PnPEnv):
+        ob_keys = ()
+
+    B = 5
+    rs = np.random.RandomState(0)
+    gt = torch.from_numpy(rs.rand(B, 1, 4, 4).astype(np.float32))
+    data = {'gt': gt, 'x0': torch.zeros_like(gt), 'output': torch.zeros_like(gt)}
+    env = StubEnv(None, _StubSolver(), max_episode_step=4)
+    env.metric_fn = lambda out, g: -((out - g) ** 2).reshape(out.shape[0], -1).mean(1, keepdim=True)   # CPU metric
+    senv = D.ShardedEnv(env)
+    ob = senv.reset(data)
+    # item i stops after step stop_at[i]; rank 1's shard (items 3, 4) finishes after step 1, rank 0's after step 3
+    stop_at = torch.tensor([3, 2, 3, 1, 1])
+    lo, hi = D.shard_bounds(B, world, rank)
+    log = []
+    for step in range(1, 5):
+        live = env.idx_left.clone() if not senv._local_done else torch.empty(0, dtype=torch.long)
+        action = {'mu': torch.full((len(live),), 0.5), 'idx_stop': (stop_at[lo:hi][live] <= step).long()}
+        ob, rewards, finished, info = senv.step(action)
+        log.append((rewards.view(-1).tolist(), info['done'].tolist(), finished))
+        if finished:
+            break
+    q.put((rank, log))
+    dist.destroy_process_group()
+
+
+def test_sharded_env_episode_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_episode_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]                                   # every rank sees the same global trajectory
+    log = res[0]
+    assert len(log) == 3 and [f for _, _, f in log] == [False, False, True]
+    rew1, done1, _ = log[0]
+    assert all(r > 0 for r in rew1)                           # every item improved in step 1
+    assert done1 == [False, False, False, True, True]
+    rew2, done2, _ = log[1]
+    assert rew2[3] == 0.0 and rew2[4] == 0.0 and rew2[0] > 0  # rank 1 finished: zero rewards, still in the collectives
+    assert done2 == [False, True, False, True, True]
+    rew3, done3, _ = log[2]
+    assert rew3[1] == 0.0 and rew3[0] > 0 and done3 == [True] * 5

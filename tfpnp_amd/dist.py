@@ -72,3 +72,73 @@ def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_true(flag, device):
+    """logical AND of a python bool over ranks."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+class ShardedEnv:
+    """A PnPEnv over this rank's contiguous shard of a global env batch -- what the reference does with
+    DataParallelWithCallback(solver) (tasks/csmri/main.py:79-80), without moving images between GPUs.
+
+        env = ShardedEnv(CSMRIEnv(None, solver, max_episode_step))
+        ob = env.reset(global_batch_dict)                 # every rank passes the same dict (or pre-sharded=True)
+        while True:
+            action = policy(env.get_policy_ob(ob), ...)   # local live items only
+            ob, reward, all_done, info = env.step(action) # reward: [B_global, 1] on every rank
+            if all_done: break
+
+    Per step the ranks exchange one all_gather of [B_local] rewards, one of [B_local] done flags and one 4-byte
+    all-reduce ("is every rank finished?").  A rank whose items have all stopped keeps taking part in the collectives
+    with zero rewards until the last rank finishes.
+    """
+
+    def __init__(self, env, group=None):
+        self.env = env
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_global = self.n_local = 0
+        self.lo = self.hi = 0
+        self._local_done = False
+
+    def __getattr__(self, name):          # get_policy_ob, get_images, solver, max_episode_step, ...
+        return getattr(self.env, name)
+
+    def reset(self, data, pre_sharded=False, n_global=None):
+        if pre_sharded:
+            if n_global is None:
+                raise ValueError('pre_sharded batches need n_global')
+            self.n_global = int(n_global)
+            local = dict(data)
+        else:
+            self.n_global = len(next(iter(data.values())))
+            local = shard_batch(data, self.world, self.rank)
+        self.lo, self.hi = shard_bounds(self.n_global, self.world, self.rank)
+        self.n_local = self.hi - self.lo
+        self._local_done = self.n_local == 0
+        return self.env.reset(local) if self.n_local else None
+
+    def step(self, action):
+        """-> (local observation of the still-live items, global reward [B_global,1], all ranks done?, info)"""
+        ref = self.env.state['gt'] if self.n_local else None
+        device = ref.device if ref is not None else torch.device('cpu')
+        done_full = torch.ones(self.n_local, dtype=torch.float32, device=device)
+        ob = None
+        if not self._local_done:
+            live_before = self.env.idx_left.clone()
+            _, ob, reward, local_all_done, info = self.env.step(action)
+            done_full[live_before] = info['done'].to(torch.float32)
+            self._local_done = bool(local_all_done)
+        else:
+            reward = torch.zeros(self.n_local, 1, dtype=torch.float32, device=device)
+        rewards = all_gather_rows(reward, self.n_global, self.group)
+        done = all_gather_rows(done_full.view(-1, 1), self.n_global, self.group)
+        finished = all_true(self._local_done, device)
+        return ob, rewards, finished, {'done': done.view(-1) != 0, 'local_done': self._local_done}
