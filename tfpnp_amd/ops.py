@@ -192,6 +192,8 @@ def policy_forward(ctx, ob):
     B, _, H, W = ob.shape
     probs = torch.empty((B, 2), device=ob.device, dtype=torch.float32)
     det = torch.empty((B, ctx._policy[1]), device=ob.device, dtype=torch.float32)
+    if B == 0:
+        return probs, det
     with torch.cuda.device(ob.device):
         check(_lib.lib().pnpx_policy_forward(ctx.handle, _p(ob), _p(probs), _p(det), B, H, W, _stream(ob)))
     return probs, det
