@@ -10,7 +10,7 @@ import threading
 import torch  # noqa: F401  -- must come first: libpnpx.so has to bind to the HIP runtime PyTorch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnpx.so")
+LIB_PATH = os.environ.get("PNPX_LIB", os.path.join(_HERE, "libpnpx.so"))   # PNPX_LIB: A/B builds of the same ABI
 
 _lib = None
 _lock = threading.Lock()
