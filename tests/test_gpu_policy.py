@@ -156,3 +156,22 @@ def test_evaluator_over_mat_items(unet_params, tmp_path):
     # psnr_init equals the PSNR of the zero-filled reconstruction stored in the item
     zf = np.clip(d["ATy0"][1][..., 0], 0, 1)
     assert abs(p0 - 10 * np.log10(1.0 / np.mean((zf - d["gt"][1]) ** 2))) < 1e-3
+
+
+def test_batched_evaluation_matches_single(unet_params):
+    """eval_batch over 3 samples == three eval_single runs (same policy decisions, same PSNRs)."""
+    from tfpnp_amd.eval import eval_batch, eval_single, Evaluator
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI, CSMRIEnv
+    d = synth.make_csmri_batch(3, 64, 64, ratio=4, sigma_n=15.0, seed=111)
+    env = CSMRIEnv(None, ADMMSolver_CSMRI(UNetDenoiser2D(state_dict=unet_params)), max_episode_step=3)
+    actor, _ = make_actor("admm", 9, 10, False, continue_bias=1.0)
+    batch = {k: g(v) for k, v in d.items()}
+    p0, p1, steps, _ = eval_batch(env, batch, actor, 3)
+    for b in range(3):
+        one = {k: v[b:b + 1] for k, v in batch.items()}
+        q0, q1, info, _ = eval_single(env, one, actor, 3)
+        assert abs(q0 - p0[b]) < 1e-6 and abs(q1 - p1[b]) < 2e-3 and info[0] == steps[b]
+    ev = Evaluator(env, {"set": [batch]})
+    mean_psnr = ev.eval(actor, step=0)
+    assert abs(mean_psnr - float(np.mean(p1))) < 2e-3 and ev.history[-1][2]["iters"] == float(np.mean(steps))

@@ -54,6 +54,37 @@ def eval_single(env, data, policy, max_episode_step, metric=psnr_qrnn3d):
     return psnr_init, psnr_finished, info, imgs
 
 
+def eval_batch(env, data, policy, max_episode_step, metric=psnr_qrnn3d):
+    """Like eval_single for a batch of B > 1 samples at once (the reference evaluates one sample per call because its
+    bookkeeping indexes [0]; the native path is ~10x more efficient per image at env_batch 48 than at 1).  Items stop
+    individually (`idx_stop`), exactly as in training rollouts.  Returns per-item lists
+    (psnr_init, psnr_finished, episode_steps) and the wall time of the whole batch."""
+    ob = env.reset(data=data)
+    B = ob.shape[0]
+    hidden = policy.init_state(B)
+    _, out0, gt = env.get_images(ob)
+    psnr_init = [metric(out0[b], gt[b]) for b in range(B)]
+    steps = [0] * B
+    live = list(range(B))
+    time_stamp = time.time()
+    for _ in range(max_episode_step):
+        action, _, _, hidden = policy(env.get_policy_ob(ob), idx_stop=None, train=False, hidden=hidden)
+        for b in live:
+            steps[b] += 1
+        stop = action['idx_stop'].detach().cpu().numpy()
+        _, ob, _, all_done, _ = env.step(action)
+        live = [b for b, s_ in zip(live, stop) if s_ == 0]
+        if all_done:
+            break
+    if env.state['gt'].is_cuda:
+        torch.cuda.synchronize(env.state['gt'].device)
+    run_time = time.time() - time_stamp
+    from ..env.base import torch2img255
+    out, gt = torch2img255(env.state['output']), torch2img255(env.state['gt'])
+    psnr_finished = [metric(out[b], gt[b]) for b in range(B)]
+    return psnr_init, psnr_finished, steps, run_time
+
+
 class Evaluator:
     def __init__(self, env, val_loaders, savedir=None, metric=psnr_qrnn3d):
         self.env = env
@@ -71,7 +102,12 @@ class Evaluator:
             rows = []
             for index, data in enumerate(loader):
                 data = dict(data)
-                assert data['gt'].shape[0] == 1
+                if data['gt'].shape[0] > 1:       # batched evaluation: metrics only, no per-sample image dump
+                    data.pop('name', None)
+                    p0, p1, steps, run_time = eval_batch(self.env, data, policy, self.env.max_episode_step, self.metric)
+                    rows += [{'iters': st, 'psnr_init': a, 'psnr': b, 'time': run_time / len(p0)}
+                             for a, b, st in zip(p0, p1, steps)]
+                    continue
                 sample = data.pop('name', 'case' + str(index))
                 sample = sample[0] if isinstance(sample, (list, tuple)) else sample
                 psnr_init, psnr_finished, info, imgs = eval_single(self.env, data, policy,
