@@ -49,22 +49,6 @@ def test_subbatching_is_bit_identical(unet_params):
         assert torch.equal(o, outs[0])
 
 
-def test_fused_upsample_loader_matches_separate_kernel(unet_params):
-    """Opt-in path (PNPX_UP_FUSE=1): bilinear x2 interpolated inside the conv loader instead of a separate kernel."""
-    from tfpnp_amd.pnp import UNetDenoiser2D
-    den = UNetDenoiser2D(state_dict=unet_params)
-    for (B, H, W) in [(2, 64, 64), (2, 48, 80), (5, 256, 256)]:
-        x, s = denoiser_inputs(B, H, W, 10)
-        x, s = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
-        ref = den.forward_preclamp(x, s)[1].clone()
-        try:
-            os.environ["PNPX_UP_FUSE"] = "1"
-            got = den.forward_preclamp(x, s)[1]
-        finally:
-            os.environ.pop("PNPX_UP_FUSE", None)
-        assert rel(got, ref) < 2e-6
-
-
 def test_set_option_switches_layout_safely(unet_params):
     """Switching the conv mode on a live context re-initialises the arena (zero borders) for the new layout."""
     from tfpnp_amd.pnp import UNetDenoiser2D

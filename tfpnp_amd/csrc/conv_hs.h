@@ -32,9 +32,6 @@ struct ConvHsArgs {
   int H, W, Hp, Wp;
   int tilesX, tilesY, nct, B;
   float inv_scale, slope;
-  // fused bilinear x2 upsample of the second source: in1 is [B][G1][h1+2][w1+2] (H = 2*h1, W = 2*w1)
-  int up1, h1, w1;
-  float sy, sx;
   // backward pass (input-gradient convolution): LeakyReLU' taken from the sign of a saved HS8 activation with the
   // geometry of `out` instead of from the result itself
   const char* dmask;
@@ -45,7 +42,6 @@ struct ConvHsArgs {
 int conv_hs_mt(int cout);
 float pack_conv_weights_hs(const float* w, int cout, int cin, int mt, uint16_t* dst);
 struct ConvHsFuse {       // optional fused work
-  bool up_in1 = false;      // in1 is the low-resolution tensor; bilinear x2 (align_corners) inside the loader
   char* pool_out = nullptr;
   const float* outc_w = nullptr;
   const float* outc_b = nullptr;

@@ -118,8 +118,6 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
   };
   auto chunk_src = [&](const Tile& T, int chunk) -> const char* {
     const int g0 = chunk * 2;
-    if (g0 >= a.G0 && a.up1)   // low-resolution source of a fused-upsample chunk: base of (image, group), no tile origin
-      return a.in1 + ((size_t)T.b * a.G1 + (g0 - a.G0)) * ((size_t)(a.h1 + 2) * (a.w1 + 2)) * 32;
     const char* src = (g0 < a.G0) ? a.in0 + ((size_t)T.b * a.G0 + g0) * HpWp * 32
                                   : a.in1 + ((size_t)T.b * a.G1 + (g0 - a.G0)) * HpWp * 32;
     return src + ((size_t)T.y0 * a.Wp + T.x0) * 32;
@@ -176,101 +174,14 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
       f.bl[n] = *reinterpret_cast<const h8*>(lb + (G::PLANE + (n * G::MBH + dy) * G::LW + dx) * 16);
     }
   };
-  // ---- fused bilinear x2 upsample (align_corners=True, models/unet.py:99) of the second source ---------------
-  // When a.up1 is set, in1 is the LOW-resolution tensor [B][G1][h1+2][w1+2]; the halo records of an "up" chunk are
-  // interpolated by the threads themselves (4 source records -> 1 record, fp32 maths on hi+lo, re-split) and written
-  // to the next LDS stage while the current chunk is multiplied: loads are issued LAG taps ahead of their use.
-  constexpr int NREC = (2 * G::PLANE + 255) / 256;   // records per thread per chunk
-  constexpr int UP_LAG = (MT == 64 && NBW == 4) ? 1 : 2;   // records in flight are 32 VGPRs each
-  struct UpRec {
-    uint4 h[4], l[4];
-  };
-  const int hw1p = (a.h1 + 2) * (a.w1 + 2);
-  auto rec_coords = [&](int k, int& g, int& hy, int& hx) {
-    const int r = tid + 256 * k;
-    g = r / G::PLANE;
-    const int pix = r - g * G::PLANE;
-    hy = pix / G::LW;
-    hx = pix - hy * G::LW;
-    return r < 2 * G::PLANE;
-  };
-  auto up_src = [&](int Y, int X, int& ys0, int& ys1, int& xs0, int& xs1, float& ly, float& lx) {
-    const float fy = a.sy * (float)Y, fx = a.sx * (float)X;
-    ys0 = (int)fy;
-    xs0 = (int)fx;
-    ys1 = ys0 + (ys0 < a.h1 - 1 ? 1 : 0);
-    xs1 = xs0 + (xs0 < a.w1 - 1 ? 1 : 0);
-    ly = fy - (float)ys0;
-    lx = fx - (float)xs0;
-  };
-  auto up_issue = [&](UpRec& R, int k, const char* ubase, int ny0, int nx0) {
-    int g, hy, hx;
-    rec_coords(k, g, hy, hx);
-    if (g > 1) g = 1;
-    int Y = ny0 - 1 + hy, X = nx0 - 1 + hx;
-    Y = Y < 0 ? 0 : (Y > a.H - 1 ? a.H - 1 : Y);
-    X = X < 0 ? 0 : (X > a.W - 1 ? a.W - 1 : X);
-    int ys0, ys1, xs0, xs1;
-    float ly, lx;
-    up_src(Y, X, ys0, ys1, xs0, xs1, ly, lx);
-    const char* p = ubase + (size_t)g * hw1p * 32;
-    const int wp = a.w1 + 2;
-    const uint4* q00 = reinterpret_cast<const uint4*>(p + ((size_t)(ys0 + 1) * wp + xs0 + 1) * 32);
-    const uint4* q01 = reinterpret_cast<const uint4*>(p + ((size_t)(ys0 + 1) * wp + xs1 + 1) * 32);
-    const uint4* q10 = reinterpret_cast<const uint4*>(p + ((size_t)(ys1 + 1) * wp + xs0 + 1) * 32);
-    const uint4* q11 = reinterpret_cast<const uint4*>(p + ((size_t)(ys1 + 1) * wp + xs1 + 1) * 32);
-    R.h[0] = q00[0];
-    R.l[0] = q00[1];
-    R.h[1] = q01[0];
-    R.l[1] = q01[1];
-    R.h[2] = q10[0];
-    R.l[2] = q10[1];
-    R.h[3] = q11[0];
-    R.l[3] = q11[1];
-  };
-  auto up_finish = [&](const UpRec& R, int k, char* nstage, int ny0, int nx0) {
-    int g, hy, hx;
-    const bool live = rec_coords(k, g, hy, hx);
-    const int Y0 = ny0 - 1 + hy, X0 = nx0 - 1 + hx;
-    const bool inb = (Y0 >= 0) && (Y0 < a.H) && (X0 >= 0) && (X0 < a.W);
-    const int Y = Y0 < 0 ? 0 : (Y0 > a.H - 1 ? a.H - 1 : Y0);
-    const int X = X0 < 0 ? 0 : (X0 > a.W - 1 ? a.W - 1 : X0);
-    int ys0, ys1, xs0, xs1;
-    float ly, lx;
-    up_src(Y, X, ys0, ys1, xs0, xs1, ly, lx);
-    const float wy0 = 1.f - ly, wx0 = 1.f - lx;
-    h8 oh, ol;
-    h8 sh[4], sl[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      sh[q] = __builtin_bit_cast(h8, R.h[q]);
-      sl[q] = __builtin_bit_cast(h8, R.l[q]);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float v00 = (float)sh[0][e] + (float)sl[0][e], v01 = (float)sh[1][e] + (float)sl[1][e];
-      const float v10 = (float)sh[2][e] + (float)sl[2][e], v11 = (float)sh[3][e] + (float)sl[3][e];
-      float o = wy0 * (wx0 * v00 + lx * v01) + ly * (wx0 * v10 + lx * v11);
-      o = inb ? o : 0.f;
-      oh[e] = (_Float16)o;
-      ol[e] = (_Float16)(o - (float)oh[e]);
-    }
-    if (live) {
-      char* d = nstage + ((g * 2) * G::PLANE + hy * G::LW + hx) * 16;
-      *reinterpret_cast<h8*>(d) = oh;
-      *reinterpret_cast<h8*>(d + G::PLANE * 16) = ol;
-    }
-  };
-
-  // KIND: 0 = nothing follows, 1 = the next step's halo + weights come by DMA, 2 = next halo is interpolated (up chunk)
-  auto body = [&](auto kind_tag, int stage, const char* nsrc, const char* nw, int ny0, int nx0) {
+  // KIND: 0 = nothing follows, 1 = the next step's halo + weights come by DMA
+  auto body = [&](auto kind_tag, int stage, const char* nsrc, const char* nw) {
     constexpr int KIND = decltype(kind_tag)::value;
     constexpr bool MORE = (KIND == 1);
     char* nstage = lds + (NSTAGE == 2 ? (stage ^ 1) * G::STAGE : 0);
     const char* lb = lds + stage * G::STAGE + b_lane;
     const char* la = lds + stage * G::STAGE + a_lane;
     Frags fr[2];
-    [[maybe_unused]] UpRec ur[UP_LAG + 1];
     load_frags(fr[0], la, lb, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -286,13 +197,6 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
 #pragma unroll
         for (int sl = tap; sl < G::NS; sl += 9) issue_slot(sl, nsrc, nw, nstage);
       }
-      if constexpr (KIND == 2) {
-        // weights still come by DMA (slots NI..NS-1), the halo records are interpolated
-#pragma unroll
-        for (int sl = G::NI + tap; sl < G::NS; sl += 9) issue_slot(sl, nsrc, nw, nstage);
-        if (tap < NREC) up_issue(ur[tap % (UP_LAG + 1)], tap, nsrc, ny0, nx0);
-        if (tap >= UP_LAG && tap - UP_LAG < NREC) up_finish(ur[(tap - UP_LAG) % (UP_LAG + 1)], tap - UP_LAG, nstage, ny0, nx0);
-      }
 #pragma unroll
       for (int m = 0; m < G::MTB; ++m)
 #pragma unroll
@@ -305,19 +209,7 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[m], f.bh[n], acc[m][n], 0, 0, 0);
       // schedule of this tap: the next tap's fragment reads are drip-fed between this tap's MFMAs (one ds_read per
       // MFMA) instead of being issued as one burst that lets the matrix pipe run dry
-      if constexpr (NBW >= 2 && KIND == 2) {
-        // up chunk: spread the interpolation VALU work (and the LDS traffic) between the MFMAs
-        constexpr int NRD = 2 * G::MTB + 2 * NBW;
-        constexpr int NMF = 3 * G::MTB * NBW;
-#pragma unroll
-        for (int i = 0; i < NMF; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
-          if (i < NRD && tap + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-          __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);              // up to 10 VALU
-          if (i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // 1 VMEM read
-        }
-      }
-      if constexpr (NBW >= 2 && KIND != 2) {
+      if constexpr (NBW >= 2) {
         constexpr int NRD = 2 * G::MTB + 2 * NBW;   // ds_read_b128 per tap
         constexpr int NMF = 3 * G::MTB * NBW;
         if (tap + 1 < 9) {
@@ -331,7 +223,6 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
         }
       }
     }
-    static_assert(NREC + UP_LAG <= 9, "up-chunk records must all be finished inside the 9 taps");
   };
 
   const int Gout = a.nct * (MT / 8);
@@ -511,15 +402,13 @@ __global__ __launch_bounds__(256, 1) void conv_hs_kernel(ConvHsArgs a) {
     __syncthreads();
     if (NSTAGE == 2) {
       if (!has_next) {
-        body(std::integral_constant<int, 0>{}, stage, nullptr, nullptr, 0, 0);
-      } else if (a.up1 && nchk * 2 >= a.G0) {
-        body(std::integral_constant<int, 2>{}, stage, chunk_src(nxt, nchk), chunk_w(nxt, nchk), nxt.y0, nxt.x0);
+        body(std::integral_constant<int, 0>{}, stage, nullptr, nullptr);
       } else {
-        body(std::integral_constant<int, 1>{}, stage, chunk_src(nxt, nchk), chunk_w(nxt, nchk), 0, 0);
+        body(std::integral_constant<int, 1>{}, stage, chunk_src(nxt, nchk), chunk_w(nxt, nchk));
       }
     } else {
       // single LDS stage: several workgroups share a CU and cover each other's load latency
-      body(std::integral_constant<int, 0>{}, 0, nullptr, nullptr, 0, 0);
+      body(std::integral_constant<int, 0>{}, 0, nullptr, nullptr);
       __syncthreads();
       if (has_next) {
         const char* src = chunk_src(nxt, nchk);
@@ -646,15 +535,6 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.wpk = L.w;
   a.bias = L.b;
   a.out = out;
-  a.up1 = (fuse.up_in1 && G1 > 0) ? 1 : 0;
-  a.h1 = H / 2;
-  a.w1 = W / 2;
-  a.sy = (H > 1) ? (float)(a.h1 - 1) / (float)(H - 1) : 0.f;
-  a.sx = (W > 1) ? (float)(a.w1 - 1) / (float)(W - 1) : 0.f;
-  if (a.up1 && (G0 < 2 || (H & 1) || (W & 1))) {
-    set_error("conv_hs: fused upsample needs a skip source in front and even H, W");
-    return PNPX_ERR_SHAPE;
-  }
   a.pool_out = conv_hs_can_pool(H, W) ? fuse.pool_out : nullptr;
   a.outc_w = (L.mt == 32 && L.cout == 32) ? fuse.outc_w : nullptr;
   a.outc_b = fuse.outc_b;

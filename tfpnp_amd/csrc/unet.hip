@@ -249,11 +249,9 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
   auto at = [&](const Act& d, int b0) { return A + d.off + (size_t)b0 * bpi(d); };
   auto rat = [&](const Act& d, int b0) { return reinterpret_cast<HsRec*>(at(d, b0)); };
   const bool no_pool_fuse = getenv("PNPX_NO_POOL_FUSE") != nullptr, no_outc_fuse = keep_all || getenv("PNPX_NO_OUTC_FUSE") != nullptr;
-  // Fused bilinear upsample inside the conv loader (ConvHsFuse::up_in1) is implemented and parity-tested but OFF by
-  // default: the interpolation costs ~190 VALU ops per 32-byte record in the MFMA waves and, measured at B=48/256^2,
-  // conv0 of the decoder blocks got 0.14/0.07/0.00 ms slower at levels 3/2/1 and only 0.06 ms faster at level 0 than
-  // "separate upsample kernel + DMA loader" (6.48 vs 6.31 ms per forward).  PNPX_UP_FUSE=1 enables it.
-  const bool no_up_fuse = getenv("PNPX_UP_FUSE") == nullptr;
+  // (A variant that interpolated the bilinear x2 upsample inside the conv loader was built and parity-tested in r1; it cost
+  // ~190 VALU ops per 32-byte record in the MFMA waves, was slower than "separate upsample kernel + DMA loader" (6.48 vs
+  // 6.31 ms per forward) and was removed again -- it also cost every instance registers.)
   int sub_default = 24;
   if (const char* e = getenv("PNPX_SUBBATCH")) sub_default = atoi(e);
   auto sub_of = [&](int level) {   // images per sub-batch at this level
@@ -288,13 +286,9 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
                    const ConvHsFuse& fuse) -> int {
     const Act& ta = i1 ? P.da[lvl] : P.a[lvl];   // decoder blocks (two sources) have their own temporaries
     const Act& tb = i1 ? P.db[lvl] : P.b[lvl];
-    ConvHsFuse f0;
-    f0.up_in1 = fuse.up_in1;
-    PNPX_TRY(conv(li, i0, i1, ta, b0, nb, f0));
+    PNPX_TRY(conv(li, i0, i1, ta, b0, nb, ConvHsFuse()));
     PNPX_TRY(conv(li + 1, ta, nullptr, tb, b0, nb, ConvHsFuse()));
-    ConvHsFuse f2 = fuse;
-    f2.up_in1 = false;
-    return conv(li + 2, tb, nullptr, o, b0, nb, f2);
+    return conv(li + 2, tb, nullptr, o, b0, nb, fuse);
   };
 
   // encoder: the last conv of a block also writes the 2x2 max-pooled tensor (fused epilogue) when the level is wide
@@ -327,9 +321,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
     for (int b0 = 0; b0 < B; b0 += sb) {
       const int nb = (B - b0 < sb) ? (B - b0) : sb;
       ConvHsFuse f;
-      const bool fuse_up = !no_up_fuse && P.u[l].H == 2 * h && P.u[l].W == 2 * w;
-      f.up_in1 = fuse_up;
-      if (!fuse_up) {
+      {
         const size_t n_up = (size_t)nb * (below->C / 8) * (2 * h) * (2 * w);
         hipLaunchKernelGGL(upsample2x_hs_kernel, g1d(n_up), dim3(256), 0, s, rat(*below, b0), rat(P.u[l], b0), n_up, h, w,
                            P.u[l].H, P.u[l].W, sy, sx);
@@ -343,7 +335,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
         f.out_img = out + (size_t)b0 * H * W;
         f.out_pre = out_pre ? out_pre + (size_t)b0 * H * W : nullptr;
       }
-      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], fuse_up ? below : &P.u[l], l, P.y[l], b0, nb, f));
+      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l], b0, nb, f));
     }
     below = &P.y[l];
   }
