@@ -171,6 +171,10 @@ def roofline(den, dev, B, H, W, reps=3):
         "frac": achieved / PEAK_HS_TFLOPS,
         "peak_note": "dense f16 MFMA peak 2500 TF/s / 3 MFMAs per product; the exact-fp32 MFMA peak is 157.3 TF/s",
         "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+        # what the same MFMA stream sustains on this GPU (profiles/r1_mfma_microbench.md, tools/micro/mfma_rate.hip):
+        # register-only loop on toggling operands 1740 TF/s f16 (power-limited), with conv_hs's fragment reads 1491
+        "frac_of_sustained_mfma_loop": achieved / (1740.0 / 3.0),
+        "frac_of_sustained_mfma_loop_with_operand_reads": achieved / (1491.0 / 3.0),
         "traffic": pmc_traffic(B, H, W),
         "flops_per_forward": conv_fl / reps,
         "conv_ms_per_forward": conv_ms / reps,
