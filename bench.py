@@ -8,12 +8,18 @@
 One "step" = one episode of the hot path over one resident batch: solver.reset, 6 x ADMMSolver_CSMRI.forward
 (5 inner iterations each: UNet denoiser prox + masked-FFT data prox + dual update), 6 x PSNR reward, and -- for
 N > 1 -- 6 all_gathers of the per-item rewards over RCCL.  No early stop.  Inputs (y0, mask, x0, gt, the action
-schedule, packed weights) are in HBM before the timed region starts.  Weak scaling: every rank owns its own 48
-items.  value = ADMM inner iterations (each over a 48-image batch) per second, summed over ranks.
+schedule, packed weights) are in HBM before the timed region starts.
+  --scaling weak   (default) every rank owns its own 48 items; value = inner iterations, each over a 48-image batch,
+                   per second, summed over ranks.
+  --scaling strong the reference's own split (tasks/csmri/main.py:79-80: DataParallel scatters ONE env batch): the
+                   GLOBAL env batch of 48 is sharded contiguously, 48/N items per rank; value = inner iterations over
+                   the global 48-image batch per second.
 
 Prints ONE JSON line on rank 0 (fields: see the contract in the task statement) including
-  roofline     fp32-MFMA roofline of the dominant kernel (conv3x3), measured with HIP events per launch;
-  cpu_baseline the CPU oracle timed on the host cores on a bounded sample of the same workload (N=1 only).
+  roofline     MFMA roofline of the dominant kernel (conv_hs), measured with HIP events per launch;
+  cpu_baseline the CPU oracle timed on the host cores on a bounded sample of the same workload (N=1 only);
+  batch_table  (N=1) one ADMM iteration at B = 6, 12, 24, 48: what an 8/4/2-way strong split would run per rank;
+  fp32_mode    (N=1) the same episode and roofline with the exact-fp32 MFMA convolutions (conv_mode 0).
 """
 import argparse
 import json
@@ -59,6 +65,9 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=24, help="items in the bounded CPU-baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--no-batch-table", action="store_true")
+    ap.add_argument("--no-fp32-mode", action="store_true")
     args = ap.parse_args()
 
     rank, world, local_rank = D.init_from_env()
@@ -68,20 +77,31 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    B, H, W = args.batch, args.size, args.size
+    H, W = args.size, args.size
+    strong = args.scaling == "strong"
+    if strong:      # one global env batch, contiguous shards (uneven when world does not divide it)
+        lo, hi = D.shard_bounds(args.batch, world, rank)
+        B, n_global = hi - lo, args.batch
+        if B == 0:
+            raise SystemExit(f"--scaling strong: rank {rank} of {world} has no items of a batch of {args.batch}")
+    else:
+        B, n_global = args.batch, args.batch * world
 
     # ---- resident inputs --------------------------------------------------------------------------
     params = synth.make_unet_params(0)
     den = UNetDenoiser2D(state_dict=params)
     solver = ADMMSolver_CSMRI(den)
-    data_np = synth.make_csmri_batch(B, H, W, ratio=args.ratio, sigma_n=15.0, seed=1234 + 1000 * rank)
+    if strong:
+        full = synth.make_csmri_batch(n_global, H, W, ratio=args.ratio, sigma_n=15.0, seed=1234)
+        data_np = {k: v[lo:hi] for k, v in full.items()}
+    else:
+        data_np = synth.make_csmri_batch(B, H, W, ratio=args.ratio, sigma_n=15.0, seed=1234 + 1000 * rank)
     data = {k: t(v).to(dev) for k, v in data_np.items()}
     actions = [{k: t(v).to(dev) for k, v in a.items()} for a in synth.make_actions(B, N_POLICY_STEPS, ACTION_PACK)]
     for a in actions:
         a["idx_stop"] = torch.zeros(B, dtype=torch.int64, device=dev)
     den.context(dev).reserve(B, H, W)
     env = CSMRIEnv(None, solver, max_episode_step=N_POLICY_STEPS)
-    n_global = B * world
 
     def episode():
         env.reset(data)
@@ -105,7 +125,8 @@ def main():
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
 
     iters = N_POLICY_STEPS * ACTION_PACK * args.steps
-    value = world * iters / elapsed
+    value = (1 if strong else world) * iters / elapsed      # iterations over a 48-image batch per second, whole job
+    den.context(dev).status()                                # half-split range guard: raises if any call overflowed
     final_psnr_gain = float(torch.stack(rewards).sum(0).mean().item())
 
     out = {
@@ -117,24 +138,29 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32 values as f16 hi+lo pairs (22-bit significand); 3 f16 MFMAs per product, f32 accumulate",
         "data": "synthetic",
         "config": {
-            "workload": f"CS-MRI ADMM {H}x{W} env_batch={B}/GPU radial x{args.ratio} sigma_n=15, "
+            "workload": f"CS-MRI ADMM {H}x{W} env_batch=" + (f"{n_global} global ({B} on rank 0)" if strong else f"{B}/GPU") +
+                        f" radial x{args.ratio} sigma_n=15, "
                         f"{N_POLICY_STEPS} solver calls x {ACTION_PACK} inner iters + PSNR reward, no early stop",
             "global_batch": n_global,
             "iters_per_step": N_POLICY_STEPS * ACTION_PACK,
             "parallelism": f"batch-shard x{world}, all_gather(reward) per env step" if world > 1 else "single GPU",
         },
         "images_per_s": n_global * args.steps / elapsed,
-        "image_iters_per_s": value * B,
+        "image_iters_per_s": value * args.batch,
         "psnr_gain_db_random_init_denoiser": final_psnr_gain,
     }
 
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline(den, dev, B, H, W)
+    if rank == 0 and world == 1 and not args.no_batch_table:
+        out["batch_table"] = batch_table(solver, dev, H, W, args.ratio)
+    if rank == 0 and world == 1 and not args.no_fp32_mode:
+        out["fp32_mode"] = fp32_mode(params, data, actions, dev, B, H, W)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity_rel_l2_vs_cpu"] = cpu_baseline(params, solver, dev, args, value)
         out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
@@ -183,11 +209,73 @@ def roofline(den, dev, B, H, W, reps=3):
     }
 
 
+def batch_table(solver, dev, H, W, ratio, sizes=(6, 12, 24, 48), T=ACTION_PACK, reps=3):
+    """One ADMMSolver_CSMRI call (T inner iterations) at the per-rank batch sizes of an 8 / 4 / 2 / 1-way strong split
+    of env_batch 48: ms per iteration, image-iterations/s and per-image efficiency relative to B=48 (= the predicted
+    strong-scaling efficiency at 48/B ranks, reward all_gather aside)."""
+    rows = []
+    for b in sizes:
+        d = synth.make_csmri_batch(b, H, W, ratio=ratio, sigma_n=15.0, seed=77)
+        a = synth.make_actions(b, N_POLICY_STEPS, ACTION_PACK)[0]
+        g = lambda v: t(v).to(dev)
+        v0 = solver.reset({"x0": g(d["x0"])})
+        aux = (g(d["y0"]), g(d["mask"]))
+        par = (g(a["sigma_d"][:, :T]), g(a["mu"][:, :T]))
+        solver((v0, aux), par)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            solver((v0, aux), par)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / (reps * T)
+        rows.append({"B": b, "ms_per_iter": ms, "image_iters_per_s": b / (ms * 1e-3)})
+    ref = rows[-1]["image_iters_per_s"]
+    for r in rows:
+        r["per_image_efficiency_vs_B48"] = r["image_iters_per_s"] / ref
+    return rows
+
+
+def fp32_mode(params, data, actions, dev, B, H, W):
+    """The exact-fp32 MFMA convolution family (conv_mode 0, csrc/conv3x3.hip) on the same episode, one timed episode
+    after one warm-up, and its own roofline against the 157.3 TF/s fp32-MFMA peak."""
+    den = UNetDenoiser2D(state_dict=params, conv_mode=0)
+    env = CSMRIEnv(None, ADMMSolver_CSMRI(den), max_episode_step=N_POLICY_STEPS)
+
+    def episode():
+        env.reset(data)
+        for a in actions:
+            env.step(a)
+    episode()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    episode()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ctx = den.context(dev)
+    x = torch.rand(B, 1, H, W, device=dev)
+    sigma = torch.full((B,), 25 / 255.0, device=dev)
+    conv_ms = conv_fl = 0.0
+    for _ in range(2):
+        for name, ms, fl in ops.unet_profile(ctx, x, sigma):
+            if name == "conv3x3":
+                conv_ms += ms
+                conv_fl += fl
+    tf = conv_fl / (conv_ms * 1e-3) / 1e12
+    return {"iters_per_s": N_POLICY_STEPS * ACTION_PACK / dt, "ms_per_step": 1e3 * dt, "conv_ms_per_forward": conv_ms / 2,
+            "achieved_tflops": tf, "peak_tflops": PEAK_FP32_MFMA_TFLOPS, "frac_of_157.3": tf / PEAK_FP32_MFMA_TFLOPS,
+            "kernel": "conv3x3_mfma_kernel (v_mfma_f32_32x32x2_f32, exact fp32)"}
+
+
 def pmc_traffic(B, H, W):
-    """HBM bytes of the conv launches of one denoiser forward, from the committed rocprofv3 PMC passes
-    (profiles/r1_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, per MI355X_MICROARCH.md).  Same aggregation as
-    `achieved` (all conv launches of one forward).  None when no PMC pass exists for this geometry."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    """HBM bytes of the conv launches of one denoiser forward, from the newest committed rocprofv3 PMC passes
+    (profiles/r*_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, per MI355X_MICROARCH.md; counters cannot be collected
+    inside a timed run).  Same aggregation as `achieved` (all conv launches of one forward).  None when no PMC pass
+    exists for this geometry."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not cands:
+        return None
+    path = cands[-1]
     try:
         t = json.load(open(path))
     except OSError:
@@ -240,6 +328,32 @@ def cpu_baseline(params, solver, dev, args, gpu_value):
         t0 = time.perf_counter()
         ref = O.csmri_admm(oden, v0, t(d["y0"]), t(d["mask"]), sig, mu)
         dt = time.perf_counter() - t0
+        # a single-thread figure (1 item x 1 iteration) ...
+        torch.set_num_threads(1)
+        t1 = time.perf_counter()
+        O.csmri_admm(oden, v0[:1], t(d["y0"][:1]), t(d["mask"][:1]), sig[:1, :1], mu[:1, :1])
+        dt_1thread = time.perf_counter() - t1
+        # ... and BASELINE config #1 in full: B = 1, 128 x 128, 6 x 5 = 30 inner iterations
+        torch.set_num_threads(threads)
+        d1 = synth.make_csmri_batch(1, 128, 128, ratio=args.ratio, sigma_n=15.0, seed=99)
+        acts1 = synth.make_actions(1, N_POLICY_STEPS, ACTION_PACK)
+        v1 = O.admm_reset(t(d1["x0"]))
+        t1 = time.perf_counter()
+        for a1 in acts1:
+            v1 = O.csmri_admm(oden, v1, t(d1["y0"]), t(d1["mask"]), t(a1["sigma_d"]), t(a1["mu"]))
+        dt_cfg1 = time.perf_counter() - t1
+    g1 = lambda a_: t(a_).to(dev)
+    gv1 = solver.reset({"x0": g1(d1["x0"])})
+    for a1 in acts1:                                               # warm-up (workspace for 128 x 128)
+        gv1 = solver((gv1, (g1(d1["y0"]), g1(d1["mask"]))), (g1(a1["sigma_d"]), g1(a1["mu"])))
+    gv1 = solver.reset({"x0": g1(d1["x0"])})
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for a1 in acts1:
+        gv1 = solver((gv1, (g1(d1["y0"]), g1(d1["mask"]))), (g1(a1["sigma_d"]), g1(a1["mu"])))
+    torch.cuda.synchronize()
+    dt_cfg1_gpu = time.perf_counter() - t1
+    rel_cfg1 = float((gv1.cpu() - v1).norm() / v1.norm())
     gv0 = solver.reset({"x0": t(d["x0"]).to(dev)})
     got = solver((gv0, (t(d["y0"]).to(dev), t(d["mask"]).to(dev))), (sig.to(dev), mu.to(dev))).cpu()
     rel = float((got - ref).norm() / ref.norm())
@@ -253,6 +367,10 @@ def cpu_baseline(params, solver, dev, args, gpu_value):
         "sample": f"{Bc} items x {Tc} inner iterations of CS-MRI ADMM {H}x{W} ({dt:.1f} s of CPU wall), "
                   f"scaled to env_batch={args.batch}",
         "image_iters_per_s": image_iters_per_s,
+        "one_thread": {"image_iters_per_s": 1.0 / dt_1thread, "sample": f"1 item x 1 iteration {H}x{W}, 1 thread"},
+        "config1_full": {"workload": "BASELINE configs[0]: CS-MRI ADMM 128x128, B=1, 6 x 5 = 30 iterations",
+                         "cpu_s": dt_cfg1, "cpu_iters_per_s": 30.0 / dt_cfg1, "cpu_threads": threads,
+                         "gpu_s": dt_cfg1_gpu, "gpu_iters_per_s": 30.0 / dt_cfg1_gpu, "rel_l2_gpu_vs_cpu": rel_cfg1},
     }
     return base, rel
 

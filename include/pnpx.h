@@ -34,7 +34,8 @@ enum pnpx_status {
   PNPX_ERR_SHAPE = 2,       /* unsupported geometry (e.g. FFT length > 2048, image side < 16)    */
   PNPX_ERR_NO_WEIGHTS = 3,  /* denoiser used before pnpx_unet_load                               */
   PNPX_ERR_ALLOC = 4,       /* device allocation failed                                          */
-  PNPX_ERR_HIP = 5          /* a HIP runtime call failed; see pnpx_last_error()                  */
+  PNPX_ERR_HIP = 5,         /* a HIP runtime call failed; see pnpx_last_error()                  */
+  PNPX_ERR_RANGE = 6        /* half-split range guard tripped (pnpx_ctx_status)                  */
 };
 
 const char* pnpx_version(void);
@@ -46,9 +47,23 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx);
 /* Pre-size the internal workspaces for batches up to B of H x W images (optional; otherwise they
  * grow on first use, which synchronises the device once). */
 int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
-/* Tuning / diagnostics.  "conv_mode": 1 (default) = half-split f16 MFMA convolutions (fp32-class accuracy, 3 MFMAs
- * per product, csrc/conv_hs.hip); 0 = plain fp32 MFMA convolutions (csrc/conv3x3.hip).  Both meet the 1e-4 bar. */
+/* Options (the library reads no environment variables).
+ *  "conv_mode": 1 (default) = half-split f16 MFMA convolutions (fp32-class accuracy, 3 MFMAs per product,
+ *      csrc/conv_hs.hip); 0 = plain fp32 MFMA convolutions (csrc/conv3x3.hip).  Both meet the 1e-4 bar.
+ *  "range_guard": the half-split kernels carry activations as f16 hi+lo pairs of 16*v, i.e. |v| < 4095.  Their
+ *      epilogues set a sticky flag when a stored value leaves that range or is NaN.
+ *      1 (default): the flag is looked at (no synchronisation) at the top of the next call; once seen, the context
+ *         switches to conv_mode 0 for good and pnpx_ctx_status() returns PNPX_ERR_RANGE (the call that tripped it
+ *         returned invalid numbers).  Setting the option again re-arms the guard.
+ *      2 (strict): every denoiser / solver entry synchronises its stream before returning and, if the flag was set,
+ *         repeats itself in conv_mode 0 -- the caller always receives valid output, at the price of a sync per call.
+ *      0: off.
+ *  "subbatch" (images per level-0 sub-batch, 0 = whole batch), "fuse_pool", "fuse_outc" (0/1): diagnostics. */
 int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value);
+int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value);
+/* PNPX_OK, or PNPX_ERR_RANGE once the range guard has tripped.  Does not synchronise: call it after a point where
+ * the stream is known to have drained (e.g. after reading a result back). */
+int pnpx_ctx_status(pnpx_ctx* ctx);
 /* Bytes of device memory currently held by the context (weights + workspaces). */
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx);
 
@@ -116,6 +131,31 @@ int pnpx_spi_inverse(pnpx_ctx* ctx, const float* ztilde, const float* K1, const 
 /* torch_psnr (tfpnp/env/base.py:237-242): output, gt [B,1,H,W] -> psnr [B]. */
 int pnpx_psnr(pnpx_ctx* ctx, const float* output, const float* gt, float* psnr, int B, int n_per_item,
               void* stream);
+
+/* ---- episode orchestration: the caller contract of PnPEnv.step (tfpnp/env/base.py:157-191) -------- */
+/* Live-row gather `x[self.idx_left, ...]` (base.py:162-166) of n_tensors state tensors in ONE launch:
+ * dst_t[r] = src_t[idx[r]] for r < n_rows, rows of row_bytes[t] bytes.  src_host / dst_host / row_bytes_host are HOST
+ * arrays (of device pointers / sizes); idx is a device int64 array. */
+int pnpx_rows_gather(pnpx_ctx* ctx, int n_tensors, const void* const* src_host, void* const* dst_host,
+                     const size_t* row_bytes_host, const int64_t* idx, int n_rows, void* stream);
+/* Write-back `state[...][self.idx_left, ...] = value` (base.py:171-172): dst_t[idx[r]] = src_t[r]. */
+int pnpx_rows_scatter(pnpx_ctx* ctx, int n_tensors, const void* const* src_host, void* const* dst_host,
+                      const size_t* row_bytes_host, const int64_t* idx, int n_rows, void* stream);
+/* `self.idx_left = self.idx_left[idx_stop == 0]; all_done = len(self.idx_left) == 0` (base.py:180-182) as a
+ * device-side stream compaction: idx_out[0..n_live) = the idx_left[i] with idx_stop[i] == 0 (int64, in order).
+ * *n_live_host receives the count: this call SYNCHRONISES `stream` -- it is the one host read of an env step
+ * (`all_done` is a Python bool in the reference's contract). */
+int pnpx_live_compact(pnpx_ctx* ctx, const int64_t* idx_left, const int64_t* idx_stop, int n, int64_t* idx_out,
+                      int* n_live_host, void* stream);
+/* Policy observation (get_policy_ob: tasks/csmri/env.py:14-23, tasks/pr/env.py:14-21, tasks/ct/env.py:13-20,
+ * tasks/spi/env.py:12-19): channel-concatenation of n_entries (<= 12) state tensors, each viewed as
+ *   kind 0: fp32 [B,c,H,W] as is;  1: complex2real of [B,c,H,W,2] (transforms.py:16-17);
+ *   kind 2: complex2channel of [B,c,H,W,2] (re, im of channel j -> channels 2j, 2j+1; transforms.py:20-26);
+ *   kind 3: uint8 / bool [B,c,H,W] cast to float
+ * into out [n_rows, sum(channels), H, W].  Row r reads source row idx[r] (idx == NULL: row r). */
+int pnpx_policy_ob_pack(pnpx_ctx* ctx, int n_entries, const void* const* src_host, const int* kind_host,
+                        const int* channels_host, const int64_t* idx, int n_rows, int H, int W, float* out,
+                        void* stream);
 
 /* ---- solver loops: T inner iterations per call ---------------------------------------------------- */
 /* Hyper-parameter arrays are [B, param_stride] row-major (the policy's [B, action_pack] tensors,

@@ -39,12 +39,11 @@ def test_subbatching_is_bit_identical(unet_params):
     x, s = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
     den = UNetDenoiser2D(state_dict=unet_params)
     outs = []
-    try:
-        for sb in ["0", "1", "3", "24"]:
-            os.environ["PNPX_SUBBATCH"] = sb
-            outs.append(den(x, s).clone())
-    finally:
-        os.environ.pop("PNPX_SUBBATCH", None)
+    ctx = den.context(dev())
+    for sb in [0, 1, 3, 24]:
+        ctx.set_option("subbatch", sb)
+        assert ctx.get_option("subbatch") == sb
+        outs.append(den(x, s).clone())
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
 
@@ -98,3 +97,72 @@ def test_csmri_episode_drift_not_worse_than_fp32(unet_params):
         e = rel(sol.get_output(v).double().cpu(), ref64)
         print(f"conv_mode {mode}: rel-L2 vs fp64 = {e:.3e}   (CPU fp32 oracle vs fp64 = {e_cpu32:.3e})")
         assert e < 1e-4 and e < 2.0 * e_cpu32 + 1e-5
+
+
+def _hot_params(unet_params, scale=3e3):
+    """The synthetic UNet with its first convolution scaled up so that activations leave the f16 hi/lo range (|v| >= 4095)."""
+    p = {k: np.array(v, copy=True) for k, v in unet_params.items()}
+    for k in ("inc.conv.conv-0.conv2d.weight", "inc.conv.conv-0.conv2d.bias"):
+        p[k] = (p[k] * scale).astype(np.float32)
+    return p
+
+
+def test_range_guard_strict_returns_exact_result(unet_params):
+    """range_guard = 2: a call whose activations exceed the half-split range is repeated in exact fp32 before it
+    returns -- correct output, never inf/NaN -- and the context stays in conv_mode 0 afterwards."""
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    x, s = denoiser_inputs(3, 64, 64, 11)
+    x, s = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
+    hot = _hot_params(unet_params)
+    ref_den = UNetDenoiser2D(state_dict=hot, conv_mode=0)
+    ref, ref_pre = ref_den.forward_preclamp(x, s)
+    assert torch.isfinite(ref_pre).all() and float(ref_pre.abs().max()) > 100.0   # the network really is "hot"
+    den = UNetDenoiser2D(state_dict=hot, conv_mode=1)
+    ctx = den.context(dev())
+    ctx.set_option("range_guard", 2)
+    out, pre = den.forward_preclamp(x, s)
+    assert torch.isfinite(pre).all() and torch.equal(pre, ref_pre) and torch.equal(out, ref)
+    assert ctx.get_option("conv_mode") == 0
+    ctx.status()   # nothing invalid escaped: no error pending
+    # a well-scaled network never trips the guard and stays on the fast path
+    ok = UNetDenoiser2D(state_dict=unet_params, conv_mode=1)
+    ok.context(dev()).set_option("range_guard", 2)
+    a = ok(x, s)
+    assert ok.context(dev()).get_option("conv_mode") == 1 and torch.isfinite(a).all()
+
+
+def test_range_guard_default_reports_clean_error(unet_params):
+    """range_guard = 1 (default, no synchronisation): the tripping call cannot be repaired, but the error is surfaced by
+    Context.status() at the next synchronisation point, and every later call runs the exact fp32 kernels."""
+    from tfpnp_amd._lib import PnpxError
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    x, s = denoiser_inputs(3, 64, 64, 12)
+    x, s = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
+    hot = _hot_params(unet_params)
+    ref = UNetDenoiser2D(state_dict=hot, conv_mode=0)(x, s)
+    den = UNetDenoiser2D(state_dict=hot, conv_mode=1)
+    ctx = den.context(dev())
+    assert ctx.get_option("range_guard") == 1
+    den(x, s)
+    torch.cuda.synchronize()
+    with pytest.raises(PnpxError, match="range guard"):
+        ctx.status()
+    assert ctx.get_option("conv_mode") == 0
+    out = den(x, s)                     # latched to the exact kernels: correct from here on
+    assert torch.equal(out, ref) and torch.isfinite(out).all()
+    with pytest.raises(PnpxError):      # the error stays visible until the guard is re-armed
+        ctx.status()
+    ctx.set_option("range_guard", 1)
+    ctx.status()
+    # the solver entries are guarded the same way
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
+    d = synth.make_csmri_batch(2, 64, 64, ratio=4, seed=5)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    acts = synth.make_actions(2)[0]
+    sols = {}
+    for mode, guard in ((0, 1), (1, 2)):
+        sol = ADMMSolver_CSMRI(UNetDenoiser2D(state_dict=hot, conv_mode=mode))
+        sol.denoiser.context(dev()).set_option("range_guard", guard)
+        v = sol.reset({"x0": g(d["x0"])})
+        sols[mode] = sol((v, (g(d["y0"]), g(d["mask"]))), (g(acts["sigma_d"]), g(acts["mu"])))
+    assert torch.isfinite(sols[1]).all() and torch.equal(sols[0], sols[1])

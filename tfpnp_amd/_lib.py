@@ -32,6 +32,8 @@ _SIGNATURES = {
     "pnpx_ctx_destroy": (C.c_int, [c_void_p]),
     "pnpx_ctx_reserve": (C.c_int, [c_void_p, C.c_int, C.c_int, C.c_int]),
     "pnpx_ctx_set_option": (C.c_int, [c_void_p, C.c_char_p, C.c_int]),
+    "pnpx_ctx_get_option": (C.c_int, [c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "pnpx_ctx_status": (C.c_int, [c_void_p]),
     "pnpx_ctx_bytes": (C.c_size_t, [c_void_p]),
     "pnpx_unet_num_params": (C.c_size_t, []),
     "pnpx_unet_load": (C.c_int, [c_void_p, c_void_p, C.c_size_t]),
@@ -47,6 +49,13 @@ _SIGNATURES = {
     "pnpx_cdp_backward": (C.c_int, [c_void_p, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, c_void_p]),
     "pnpx_spi_inverse": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, c_void_p]),
     "pnpx_psnr": (C.c_int, [c_void_p, _P, _P, _P, C.c_int, C.c_int, c_void_p]),
+    "pnpx_rows_gather": (C.c_int, [c_void_p, C.c_int, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(C.c_size_t), _P,
+                                   C.c_int, c_void_p]),
+    "pnpx_rows_scatter": (C.c_int, [c_void_p, C.c_int, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(C.c_size_t), _P,
+                                    C.c_int, c_void_p]),
+    "pnpx_live_compact": (C.c_int, [c_void_p, _P, _P, C.c_int, _P, C.POINTER(C.c_int), c_void_p]),
+    "pnpx_policy_ob_pack": (C.c_int, [c_void_p, C.c_int, C.POINTER(c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), _P,
+                                      C.c_int, C.c_int, C.c_int, _P, c_void_p]),
     "pnpx_csmri_admm": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, _P] + [C.c_int] * 5 + [c_void_p]),
     "pnpx_csmri_hqs": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, _P] + [C.c_int] * 5 + [c_void_p]),
     "pnpx_csmri_pg": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, _P] + [C.c_int] * 5 + [c_void_p]),
@@ -75,7 +84,12 @@ def lib():
                         "(run `make -C tfpnp_amd/csrc` or __graft_entry__.build()). There is no CPU fallback.")
                 l = C.CDLL(LIB_PATH)
                 for name, (res, args) in _SIGNATURES.items():
-                    fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol
+                    try:
+                        fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol
+                    except AttributeError:
+                        if "PNPX_LIB" in os.environ:   # A/B run against an older build of the ABI (tools/ only)
+                            continue
+                        raise
                     fn.restype = res
                     fn.argtypes = args
                 _lib = l

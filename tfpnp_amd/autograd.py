@@ -5,82 +5,35 @@ solver.forward under autograd and back-propagates the critic's value / the PSNR 
 (sigma_d, mu, tau) outputs (tfpnp/trainer/mddpg/trainer.py:171-192).  The fused native solver loops are
 inference-only; when gradients are required the solvers in tfpnp_amd/tasks fall back to the reference's own
 iteration written with these differentiable building blocks:
-  * denoise(x, sigma)      native forward, native VJP (pnpx_unet_denoise_backward: fp32 re-computation + transposed
-                           MFMA convolutions)
+  * denoise(x, sigma)      native forward, native VJP (pnpx_unet_denoise_backward: re-computation + transposed
+                           MFMA convolutions), both dispatcher-registered ops (torch.ops.pnpx.*, torch_ops.py)
   * fft2 / ifft2 / plain FFTs   native; the transforms are unitary, so the VJP is the inverse transform
   * radon forward / backprojection   native; each is the other's VJP (the unmatched pair torch_radon also uses)
 and ordinary PyTorch pointwise autograd for the O(N) glue (masks, blends, dual updates).
 """
 import torch
 
-from . import ops
+from . import torch_ops as T
 
 
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
-class _Denoise(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, sigma, native_ctx):
-        ctx.native = native_ctx
-        ctx.save_for_backward(x, sigma)
-        return ops.unet_denoise(native_ctx, x, sigma)
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        x, sigma = ctx.saved_tensors
-        gx, gs = ops.unet_denoise_backward(ctx.native, x, sigma.reshape(-1), grad_out)
-        return gx, gs.view_as(sigma), None
-
-
 def denoise(native_ctx, x, sigma):
-    return _Denoise.apply(x, sigma, native_ctx)
-
-
-class _FFT2(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, inverse, centered):
-        ctx.inverse, ctx.centered = inverse, centered
-        return ops.fft2(x, inverse=inverse, centered=centered)
-
-    @staticmethod
-    def backward(ctx, g):   # orthonormal transform (+ index permutations): adjoint == inverse
-        return ops.fft2(g, inverse=not ctx.inverse, centered=ctx.centered), None, None
+    return T.call("unet_denoise", x, sigma, native_ctx.cid)          # VJP registered with the dispatcher
 
 
 def fft2(x, inverse=False, centered=True):
-    return _FFT2.apply(x, inverse, centered)
-
-
-class _RadonForward(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, img, n_view):
-        ctx.R = img.shape[-1]
-        return ops.radon_forward(img, n_view)
-
-    @staticmethod
-    def backward(ctx, g):
-        return ops.radon_backprojection(g, ctx.R), None
-
-
-class _RadonBackprojection(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, sino, R):
-        ctx.V = sino.shape[2]
-        return ops.radon_backprojection(sino, R)
-
-    @staticmethod
-    def backward(ctx, g):
-        return ops.radon_forward(g, ctx.V), None
+    return T.call("fft2", x, bool(inverse), bool(centered))          # unitary: the VJP is the inverse transform
 
 
 def radon_forward(img, n_view):
-    return _RadonForward.apply(img, n_view)
+    return T.call("radon_forward", img, int(n_view))                 # VJP = backprojection
 
 
 def radon_backprojection(sino, R):
-    return _RadonBackprojection.apply(sino, R)
+    return T.call("radon_backprojection", sino, int(R))              # VJP = forward projection
 
 
 # ---- complex helpers (pure layout / pointwise, autograd by PyTorch) -- tfpnp/utils/transforms.py:12-17,260-274

@@ -53,6 +53,25 @@ static void unet_layers(LayerSpec out[27]) {
     for (int j = 0; j < 3; ++j) out[3 * b + j] = LayerSpec{j == 0 ? blocks[b][0] : blocks[b][1], blocks[b][1]};
 }
 
+void range_guard_enter(pnpx_ctx* ctx) {
+  if (!ctx->opt_range_guard || !ctx->range_flag_host) return;
+  if (*static_cast<volatile unsigned*>(ctx->range_flag_host) != 0 && !ctx->range_tripped) {
+    ctx->range_tripped = true;        // an EARLIER call overflowed: its output was invalid (pnpx_ctx_status reports it)
+    ctx->conv_mode = CONV_F32;        // every later call is exact
+  }
+}
+
+int range_guard_strict(pnpx_ctx* ctx, hipStream_t s, bool* rerun) {
+  *rerun = false;
+  PNPX_HIP(hipStreamSynchronize(s));
+  if (*static_cast<volatile unsigned*>(ctx->range_flag_host) != 0 && !ctx->range_tripped) {
+    ctx->conv_mode = CONV_F32;        // this call is repeated in exact fp32 before it returns: nothing invalid escapes
+    *ctx->range_flag_host = 0;
+    *rerun = true;
+  }
+  return PNPX_OK;
+}
+
 }  // namespace pnpx
 
 using namespace pnpx;
@@ -84,6 +103,23 @@ int pnpx_ctx_create(int device, pnpx_ctx** out) {
   PNPX_HIP(hipSetDevice(device));
   pnpx_ctx* c = new pnpx_ctx();
   c->device = device;
+  // range-guard word: pinned, host-mapped, written by the device only in the (rare) overflow branch
+  void* h = nullptr;
+  hipError_t e = hipHostMalloc(&h, 64, hipHostMallocMapped);
+  if (e != hipSuccess) {
+    delete c;
+    return hip_fail(e, "hipHostMalloc(range flag)", __FILE__, __LINE__);
+  }
+  c->range_flag_host = static_cast<unsigned*>(h);
+  *c->range_flag_host = 0;
+  void* d = nullptr;
+  e = hipHostGetDevicePointer(&d, h, 0);
+  if (e != hipSuccess) {
+    (void)hipHostFree(h);
+    delete c;
+    return hip_fail(e, "hipHostGetDevicePointer(range flag)", __FILE__, __LINE__);
+  }
+  c->range_flag_dev = static_cast<unsigned*>(d);
   *out = c;
   return PNPX_OK;
 }
@@ -100,6 +136,7 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx) {
   for (auto& t : ctx->twiddle)
     if (t.second) (void)hipFree(t.second);
   for (auto e : ctx->events) (void)hipEventDestroy(e);
+  if (ctx->range_flag_host) (void)hipHostFree(ctx->range_flag_host);
   delete ctx;
   return PNPX_OK;
 }
@@ -135,12 +172,63 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W) {
 
 int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
   LOCK_CTX(ctx);
-  if (key && !std::strcmp(key, "conv_mode") && (value == CONV_F32 || value == CONV_HS)) {
+  auto is = [&](const char* k) { return key && !std::strcmp(key, k); };
+  if (is("conv_mode") && (value == CONV_F32 || value == CONV_HS)) {
     ctx->conv_mode = value;
+    return PNPX_OK;
+  }
+  if (is("subbatch") && value >= 0) {
+    ctx->opt_subbatch = value;
+    return PNPX_OK;
+  }
+  if (is("fuse_pool") && (value == 0 || value == 1)) {
+    ctx->opt_fuse_pool = value;
+    return PNPX_OK;
+  }
+  if (is("fuse_outc") && (value == 0 || value == 1)) {
+    ctx->opt_fuse_outc = value;
+    return PNPX_OK;
+  }
+  if (is("range_guard") && value >= 0 && value <= 2) {   // also re-arms a tripped guard
+    PNPX_HIP(hipDeviceSynchronize());
+    ctx->opt_range_guard = value;
+    ctx->range_tripped = false;
+    *ctx->range_flag_host = 0;
     return PNPX_OK;
   }
   set_error("pnpx_ctx_set_option: unknown option '%s' or bad value %d", key ? key : "(null)", value);
   return PNPX_ERR_ARG;
+}
+
+int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
+  LOCK_CTX(ctx);
+  auto is = [&](const char* k) { return key && !std::strcmp(key, k); };
+  if (!value) {
+    set_error("pnpx_ctx_get_option: null value pointer");
+    return PNPX_ERR_ARG;
+  }
+  if (is("conv_mode")) *value = ctx->conv_mode;
+  else if (is("subbatch")) *value = ctx->opt_subbatch;
+  else if (is("fuse_pool")) *value = ctx->opt_fuse_pool;
+  else if (is("fuse_outc")) *value = ctx->opt_fuse_outc;
+  else if (is("range_guard")) *value = ctx->opt_range_guard;
+  else {
+    set_error("pnpx_ctx_get_option: unknown option '%s'", key ? key : "(null)");
+    return PNPX_ERR_ARG;
+  }
+  return PNPX_OK;
+}
+
+int pnpx_ctx_status(pnpx_ctx* ctx) {
+  LOCK_CTX(ctx);
+  range_guard_enter(ctx);
+  if (ctx->range_tripped) {
+    set_error("half-split range guard tripped: an activation of an earlier call left the f16 hi/lo range (|v| >= 4095 or "
+              "NaN); that call's output is invalid.  The context now runs conv_mode 0 (exact fp32 MFMA); re-arm with "
+              "pnpx_ctx_set_option(ctx, \"range_guard\", 1)");
+    return PNPX_ERR_RANGE;
+  }
+  return PNPX_OK;
 }
 
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
@@ -292,21 +380,25 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
 int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, float* out_preclamp, int B,
                       int H, int W, void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   if (!x || !sigma || !out) {
     set_error("pnpx_unet_denoise: null pointer");
     return PNPX_ERR_ARG;
   }
   return unet_denoise(ctx, x, sigma, 1, out, out_preclamp, B, H, W, static_cast<hipStream_t>(stream), nullptr);
+  });
 }
 
 int pnpx_unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, const float* grad_out, float* grad_x,
                                float* grad_sigma, int B, int H, int W, void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   if (!x || !sigma || !grad_out || !grad_x || !grad_sigma) {
     set_error("pnpx_unet_denoise_backward: null pointer");
     return PNPX_ERR_ARG;
   }
   return unet_denoise_backward(ctx, x, sigma, 1, grad_out, grad_x, grad_sigma, B, H, W, static_cast<hipStream_t>(stream));
+  });
 }
 
 int pnpx_unet_profile(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, int B, int H, int W,

@@ -115,6 +115,15 @@ struct pnpx_ctx {
   pnpx::ConvLayer conv[27];
   pnpx::ConvLayerHsDev conv_hs[27];
   int conv_mode = pnpx::CONV_HS;   // which conv kernel family the denoiser runs (pnpx_ctx_set_option)
+  // --- options (pnpx_ctx_set_option; no environment variables are read on any launch path)
+  int opt_subbatch = 24;           // images per level-0 sub-batch of the half-split forward (0 = whole batch)
+  int opt_fuse_pool = 1;           // fused 2x2 max-pool epilogue
+  int opt_fuse_outc = 1;           // fused 1x1 out-conv + residual + clamp epilogue
+  int opt_range_guard = 1;         // 0 off, 1 sticky flag + latch to conv_mode 0, 2 strict (sync + transparent re-run)
+  // --- half-split range guard: host-mapped word the conv_hs epilogues set when a stored value leaves the f16 range
+  unsigned* range_flag_host = nullptr;   // pinned host allocation
+  unsigned* range_flag_dev = nullptr;    // its device address
+  bool range_tripped = false;            // latched by the host once the flag was seen set (cleared by set_option)
   pnpx::ConvLayer conv_bwd[27];    // adjoint (input-gradient) convolutions, fp32 kernel family
   pnpx::ConvLayerHsDev conv_hs_bwd[27];  // ... and packed for the half-split kernel family
   float* zero_bias = nullptr;      // [768] zeros (bias operand of the adjoint convolutions)
@@ -141,6 +150,24 @@ int ctx_reserve_unet(pnpx_ctx* ctx, int B, int H, int W);   // main arena, ctx->
 int reserve_arena(pnpx_ctx* ctx, UNetArena& ar, int mode, int B, int H, int W, size_t extra_bytes);
 int ctx_scratch(pnpx_ctx* ctx, size_t bytes, void** out);
 int ctx_twiddle(pnpx_ctx* ctx, int N, const float2** out);
+// Half-split range guard (api.hip).  range_guard_enter: called at the top of every entry that runs the denoiser; if the
+// flag of an earlier call is set, latches the context to conv_mode 0.  range_guard_strict: option value 2 -- synchronise
+// `s`, and if the flag was set by THIS call return true after switching to conv_mode 0 so the caller re-runs the call.
+void range_guard_enter(pnpx_ctx* ctx);
+int range_guard_strict(pnpx_ctx* ctx, hipStream_t s, bool* rerun);
+// Wraps the body of a C-ABI entry that runs the denoiser (entries are functional: inputs are never modified, so a body
+// can simply be executed again).
+template <class F>
+int guarded(pnpx_ctx* ctx, hipStream_t s, F&& body) {
+  range_guard_enter(ctx);
+  int st = body();
+  if (st == PNPX_OK && ctx->opt_range_guard == 2 && ctx->conv_mode == CONV_HS) {
+    bool rerun = false;
+    PNPX_TRY(range_guard_strict(ctx, s, &rerun));
+    if (rerun) st = body();
+  }
+  return st;
+}
 
 struct ProfileSink {      // optional per-launch event recording for pnpx_unet_profile
   std::vector<hipEvent_t>* events = nullptr;

@@ -15,6 +15,18 @@ struct ConvLayerHs {
   float inv_scale = 1.f;      // 1 / (weight_scale * HS_ASCALE)
 };
 
+// n / d for small n by one multiply-high (exact for n * d < 2^32; checked at launch): the persistent tile walk
+// decodes its work items with these instead of hardware-less integer division sequences.
+struct HsFastDiv {
+  unsigned m, d;
+};
+inline HsFastDiv hs_fastdiv(unsigned d) {
+  HsFastDiv f;
+  f.d = d;
+  f.m = d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u;
+  return f;
+}
+
 struct ConvHsArgs {
   const char* in0;   // HS8 tensor, G0 groups of 8 channels
   const char* in1;   // second source (channel concat), G1 groups
@@ -31,12 +43,16 @@ struct ConvHsArgs {
   int G0, G1;
   int H, W, Hp, Wp;
   int tilesX, tilesY, nct, B;
+  HsFastDiv div_nct, div_tx, div_ty;
   float inv_scale, slope;
   // backward pass (input-gradient convolution): LeakyReLU' taken from the sign of a saved HS8 activation with the
   // geometry of `out` instead of from the result itself
   const char* dmask;
   // residual add before the activation (policy ResNet blocks): HS8 tensor with the geometry of `out`
   const char* res;
+  float neg_one;           // -1.0f (kept in a scalar register: selects the fused f16 fma-mix forms in the hi/lo split)
+  unsigned* range_flag;    // sticky half-split range guard (host-mapped word) or null
+  unsigned long long* trace;   // HS_TRACE builds: s_memtime stamps of workgroup 0 / wave 0 (null otherwise)
 };
 
 int conv_hs_mt(int cout);
@@ -49,8 +65,9 @@ struct ConvHsFuse {       // optional fused work
   float* out_img = nullptr;
   float* out_pre = nullptr;
   const char* dmask = nullptr;  // input-gradient mode: out = acc * (dmask > 0 ? 1 : slope), no bias expected (pass zeros)
-  float slope = 0.2f;           // 1.0 = linear epilogue, 0.0 = ReLU
+  float slope = 0.2f;           // in [0, 1]: 1.0 = linear epilogue, 0.0 = ReLU
   const char* res = nullptr;    // out = act(conv + bias + res)
+  unsigned* range_flag = nullptr;   // set to 1 by the kernel when a stored value leaves the f16 range (|v| >= 4095) or is NaN
 };
 // true when launch_conv_hs will honour ConvHsFuse::pool_out for this geometry
 bool conv_hs_can_pool(int H, int W);

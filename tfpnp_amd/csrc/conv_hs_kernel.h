@@ -1,0 +1,622 @@
+// Device code of the half-split ("HS") 3x3 convolution: kernel template + per-instance launcher.
+// Included by the translation units that instantiate it (conv_hs.hip: forward epilogues; conv_hs_bwd.hip: the
+// input-gradient epilogue; conv_hs_res.hip: the residual-block epilogue of the policy network).  See conv_hs.hip
+// for the numerical scheme and the data layouts.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <type_traits>
+
+#include "common.h"
+#include "conv_hs.h"
+
+namespace pnpx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16b(const char* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
+}
+
+// Epilogue flavours (compile-time: each instance carries only the registers / scalars its own epilogue needs)
+enum HsEpi {
+  EPI_ACT = 0,    // out = act(conv + bias) [+ fused 2x2 max-pool output]
+  EPI_OUTC = 1,   // network tail: clamp(x + outc(act(conv + bias)) + b) written as an fp32 image (MT == 32)
+  EPI_DMASK = 2,  // input-gradient convolution: out = conv * (saved activation > 0 ? 1 : slope)
+  EPI_RES = 3     // out = act(conv + bias + res)
+};
+
+#ifndef HS_DMA_TAPS
+#define HS_DMA_TAPS 9
+#endif
+constexpr int HS_BIAS_BYTES = 4096;   // LDS copy of the layer's (pre-scaled) bias vector, cout <= 1024
+
+template <int MT, int NBW, int MBW, int NW>
+struct HsGeom {
+  static constexpr int MBH = 32 / MBW;
+  static constexpr int NBLK = NW * NBW;
+  static constexpr int TW = MBW;
+  static constexpr int TH = NBLK * MBH;
+  static constexpr int LW = TW + 2;
+  static constexpr int LH = TH + 2;
+  static constexpr int PLANE = LW * LH;                 // pixels per LDS plane
+  static constexpr int IN_LOADS = 4 * PLANE;            // 16-byte lane loads per chunk (2 groups x hi/lo)
+  static constexpr int IN_INSTR = (IN_LOADS + 63) / 64; // wave-level DMA instructions (1 KiB each)
+  static constexpr int NI = (IN_INSTR + NW - 1) / NW;   // DMA slots per wave
+  static constexpr int IN_BYTES = IN_INSTR * 1024;
+  static constexpr int W_BYTES = 9 * 2 * 2 * MT * 16;   // [tap][hi,lo][kg][MT] x 16 B (multiple of 1 KiB)
+  static constexpr int W_INSTR = W_BYTES / 1024;
+  static constexpr int NWJ = (W_INSTR + NW - 1) / NW;
+  static constexpr int STAGE = IN_BYTES + W_BYTES;
+  static constexpr int BIAS_OFF = 2 * STAGE;
+  static constexpr int LDS_USED = 2 * STAGE + HS_BIAS_BYTES;
+  // One workgroup per CU BY CONSTRUCTION: the request is padded past half of the 160 KiB so that two workgroups can
+  // never be co-resident (see DESIGN.md "co-residency"); the persistent grid is <= 256 workgroups.
+  static constexpr int LDS_BYTES = LDS_USED > 82 * 1024 ? LDS_USED : 82 * 1024;
+  static constexpr int MTB = MT / 32;
+  static constexpr int NS = NI + NWJ;
+  static constexpr int NST = MTB * NBW * 4;             // 16-byte record stores per wave and tile
+  static constexpr int NST_POOL = MTB * (NBW / 2) * 4;  // ... of the fused pool output
+  static_assert(LDS_USED <= 160 * 1024, "tile does not fit the LDS");
+  static_assert(NST + NST_POOL <= 63, "vmcnt is a 6-bit counter");
+};
+
+// lo halves of a hi/lo pair: f16(v0 - hi.lo16) | f16(v1 - hi.hi16) << 16, straight from the packed hi register
+// (v - hi is exact in fp32, so this is the single rounding of the reference split).  The trailing s_nop covers the
+// VALU-write -> v_permlane32_swap read hazard, which the compiler cannot see through an asm statement.
+__device__ __forceinline__ unsigned hs_lo_pair(unsigned hi_pk, float neg_one, float v0, float v1) {
+  unsigned lo_pk;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "s_nop 1"
+      : "=&v"(lo_pk)
+      : "v"(hi_pk), "s"(neg_one), "v"(v0), "v"(v1));
+  return lo_pk;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Persistent kernel: a workgroup walks its tiles (XCD-aware order, below) and runs ONE software pipeline over the
+// flattened (tile, K-chunk) steps: the DMA of step s+1 (possibly the next tile's first chunk) is issued while
+// step s is multiplied, so the load latency is exposed once per workgroup, not once per tile.  The record stores of
+// a finished tile are never waited for: the wait in front of a step's barrier is a COUNTED vmcnt that covers only
+// the LDS-DMA of that step (issued before the stores; the counter retires in order), so the stores drain while the
+// next tile is multiplied.
+template <int MT, int NBW, int MBW, int NW, int EPI>
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) {
+  using G = HsGeom<MT, NBW, MBW, NW>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int HpWp = a.Hp * a.Wp;
+  const int nch = (a.G0 + a.G1) / 2;
+  // XCD-aware tile walk.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own
+  // L2.  The nct cout-tiles of one pixel region read the same input halo, so they are given to workgroups of the
+  // SAME XCD that run at the same time (consecutive "slots"): step k of workgroup (xcd, slot) handles
+  //   j = slot + nslot*k,  pixel region p = 8*(j / nct) + xcd,  cout tile ct = j % nct.
+  // nct divides nslot, so a workgroup keeps one cout tile (its weight slice stays hot) for its whole life.
+  // With few pixel regions (small batches / deep levels) that grouping would leave whole XCDs idle and funnel every
+  // weight byte through one XCD (measured at B=1, 8x8 level: 386 us with the 8 cout tiles on one XCD, 53 us spread
+  // over eight), so below 32 regions the work items are simply dealt out to consecutive workgroups (= XCDs).
+  const int nregions = a.tilesX * a.tilesY * a.B;
+  const int nx = (gridDim.x % 8 == 0 && nregions >= 32) ? 8 : 1;
+  const int xcd = blockIdx.x % nx, nslot = gridDim.x / nx;
+
+  // the layer's bias vector, pre-scaled by HS_ASCALE, stays in LDS for the life of the workgroup (a global load in
+  // the epilogue would make the compiler drain the in-flight LDS-DMA queue in front of it)
+  if constexpr (EPI != EPI_DMASK) {
+    float* lbias = reinterpret_cast<float*>(lds + G::BIAS_OFF);
+    for (int i = tid; i < a.nct * MT; i += NW * 64) lbias[i] = a.bias[i] * HS_ASCALE;
+    __syncthreads();
+  }
+
+  // per-thread byte offsets of the halo gather (identical for every chunk and tile)
+  int ioff[G::NI];
+#pragma unroll
+  for (int k = 0; k < G::NI; ++k) {
+    const int idx = (wave + NW * k) * 64 + lane;
+    const int q = idx / G::PLANE;               // plane: group = q >> 1, half = q & 1
+    const int r = idx - q * G::PLANE;
+    const int hy = r / G::LW;
+    const int hx = r - hy * G::LW;
+    ioff[k] = (idx < G::IN_LOADS) ? (((q >> 1) * HpWp + hy * a.Wp + hx) * 32 + (q & 1) * 16) : 0;
+  }
+
+  struct Tile {
+    int ct, b, x0, y0;
+  };
+  auto fdiv = [](unsigned n, const HsFastDiv& f) { return f.d > 1 ? __umulhi(n, f.m) : n; };
+  auto valid = [&](int j) { return nx * (int)fdiv(j, a.div_nct) + xcd < nregions; };
+  auto decode = [&](int j) {
+    Tile T;
+    const unsigned q = fdiv(j, a.div_nct);
+    T.ct = j - (int)q * a.nct;
+    const unsigned t = nx * q + xcd;
+    const unsigned t1 = fdiv(t, a.div_tx);
+    const int tx = t - t1 * a.tilesX;
+    const unsigned t2 = fdiv(t1, a.div_ty);
+    const int ty = t1 - t2 * a.tilesY;
+    T.b = t2;
+    T.x0 = tx * G::TW;
+    T.y0 = ty * G::TH;
+    return T;
+  };
+  auto chunk_src = [&](const Tile& T, int chunk) -> const char* {
+    const int g0 = chunk * 2;
+    const char* src = (g0 < a.G0) ? a.in0 + ((size_t)T.b * a.G0 + g0) * HpWp * 32
+                                  : a.in1 + ((size_t)T.b * a.G1 + (g0 - a.G0)) * HpWp * 32;
+    return src + ((size_t)T.y0 * a.Wp + T.x0) * 32;
+  };
+  auto chunk_w = [&](const Tile& T, int chunk) -> const char* {
+    return a.wpk + ((size_t)T.ct * nch + chunk) * G::W_BYTES;
+  };
+  auto issue_slot = [&](int slot, const char* src, const char* wsrc, char* lstage) {
+    // the (wave-uniform) guards are compile-time true except on the last slot of each kind
+    if (slot < G::NI) {
+      const int instr = wave + NW * slot;
+      if (NW * slot + NW - 1 < G::IN_INSTR || instr < G::IN_INSTR) glds16b(src + ioff[slot], lstage + instr * 1024);
+    } else {
+      const int j = wave + NW * (slot - G::NI);
+      if (NW * (slot - G::NI) + NW - 1 < G::W_INSTR || j < G::W_INSTR)
+        glds16b(wsrc + j * 1024 + lane * 16, lstage + G::IN_BYTES + j * 1024);
+    }
+  };
+
+  f32x16 acc[G::MTB][NBW];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < G::MTB; ++m)
+#pragma unroll
+      for (int n = 0; n < NBW; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  };
+  zero_acc();
+
+  const int l31 = lane & 31, kg = lane >> 5;
+  const int py = l31 / MBW, px = l31 - py * MBW;
+  // LDS byte offsets of this lane's operand fragments (tap / tile / hi-lo shifts are compile-time immediates)
+  const int b_lane = (kg * 2 * G::PLANE + (wave * NBW * G::MBH + py) * G::LW + px) * 16;
+  const int a_lane = G::IN_BYTES + (kg * MT + l31) * 16;
+
+  // one K-chunk of multiply; MORE: also issue the next step's DMA slots.  Explicit software pipeline over the
+  // 9 taps: the fragments of tap t+1 are read from LDS before the MFMAs of tap t are issued, and the DMA slots of
+  // this tap sit BEHIND those reads (the compiler keeps ds_reads in order with LDS-DMA, so a DMA at the top of a
+  // tap would pin the next reads right in front of their first use).
+  struct Frags {
+    h8 ah[G::MTB], al[G::MTB], bh[NBW], bl[NBW];
+  };
+  auto load_frags = [&](Frags& f, const char* la, const char* lb, int tap) {
+    const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+    for (int m = 0; m < G::MTB; ++m) {
+      f.ah[m] = *reinterpret_cast<const h8*>(la + ((tap * 2 + 0) * 2 * MT + m * 32) * 16);
+      f.al[m] = *reinterpret_cast<const h8*>(la + ((tap * 2 + 1) * 2 * MT + m * 32) * 16);
+    }
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+      f.bh[n] = *reinterpret_cast<const h8*>(lb + ((n * G::MBH + dy) * G::LW + dx) * 16);
+      f.bl[n] = *reinterpret_cast<const h8*>(lb + (G::PLANE + (n * G::MBH + dy) * G::LW + dx) * 16);
+    }
+  };
+  // KIND: 0 = nothing follows, 1 = the next step's halo + weights come by DMA
+  auto body = [&](auto kind_tag, int stage, const char* nsrc, const char* nw) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    constexpr bool MORE = (KIND == 1);
+    char* nstage = lds + (stage ^ 1) * G::STAGE;
+    const char* lb = lds + stage * G::STAGE + b_lane;
+    const char* la = lds + stage * G::STAGE + a_lane;
+    Frags fr[2];
+    load_frags(fr[0], la, lb, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const Frags& f = fr[tap & 1];
+      if (tap + 1 < 9) load_frags(fr[(tap + 1) & 1], la, lb, tap + 1);
+      if constexpr (NBW == 1) __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads up front
+#pragma unroll
+      for (int m = 0; m < G::MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bh[n], acc[m][n], 0, 0, 0);
+      if constexpr (MORE) {
+        // the next step's DMA slots are spread over the first HS_DMA_TAPS taps of this step
+        if (tap < HS_DMA_TAPS) {
+#pragma unroll
+          for (int sl = tap; sl < G::NS; sl += HS_DMA_TAPS) issue_slot(sl, nsrc, nw, nstage);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < G::MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < G::MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[m], f.bh[n], acc[m][n], 0, 0, 0);
+      // schedule of this tap: the next tap's fragment reads are drip-fed between this tap's MFMAs (one ds_read per
+      // MFMA) instead of being issued as one burst that lets the matrix pipe run dry
+      if constexpr (NBW >= 2) {
+        constexpr int NRD = 2 * G::MTB + 2 * NBW;   // ds_read_b128 per tap
+        constexpr int NMF = 3 * G::MTB * NBW;
+        if (tap + 1 < 9) {
+#pragma unroll
+          for (int i = 0; i < NRD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+          }
+          if (MORE && tap < HS_DMA_TAPS)
+            __builtin_amdgcn_sched_group_barrier(0x020, (G::NS + HS_DMA_TAPS - 1) / HS_DMA_TAPS, 0);   // this tap's DMA slots
+          __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+        }
+      }
+    }
+  };
+
+  const int Gout = a.nct * (MT / 8);
+  const float c16 = a.inv_scale * HS_ASCALE;   // accumulator -> HS_ASCALE * value (a power of two)
+  const float neg_one = a.neg_one;             // -1.0f in a scalar register
+  h2 range_chk = {(_Float16)0.f, (_Float16)0.f};
+  // pack 16 activated values (rows of one 32x32 accumulator, already scaled by HS_ASCALE) into 32-byte HS8 records:
+  // after the permlane swaps lanes 0-31 hold all 8 channels of the even group of each pair, lanes 32-63 of the odd.
+  // `rsrc` is a buffer descriptor of one image's tensor slice; masked lanes pass an out-of-range offset (the store is
+  // dropped by the bounds check), so every wave issues exactly the same number of stores (see the counted vmcnt).
+  auto store_records = [&](const float (&v)[16], __amdgpu_buffer_rsrc_t rsrc, int pix_rec, int g_first,
+                           int group_stride_rec, bool ok) {
+    unsigned hp[4][2], lp[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float v0 = v[q * 4 + e * 2], v1 = v[q * 4 + e * 2 + 1];
+        const h2 hh = {(_Float16)v0, (_Float16)v1};
+        range_chk = hh * (h2){(_Float16)0.f, (_Float16)0.f} + range_chk;   // inf * 0 = NaN: sticky per lane
+        hp[q][e] = __builtin_bit_cast(unsigned, hh);
+        lp[q][e] = hs_lo_pair(hp[q][e], neg_one, v0, v1);
+      }
+#pragma unroll
+    for (int qp = 0; qp < 2; ++qp) {
+      unsigned rec[8];  // hi[0..3] dwords, lo[0..3] dwords of one record
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        auto sh = __builtin_amdgcn_permlane32_swap(hp[2 * qp][e], hp[2 * qp + 1][e], false, false);
+        auto sl = __builtin_amdgcn_permlane32_swap(lp[2 * qp][e], lp[2 * qp + 1][e], false, false);
+        rec[e] = sh[0];
+        rec[2 + e] = sh[1];
+        rec[4 + e] = sl[0];
+        rec[6 + e] = sl[1];
+      }
+      const int off = ok ? ((g_first + 2 * qp + kg) * group_stride_rec + pix_rec) * 32 : (int)0x80000000;
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4){rec[0], rec[1], rec[2], rec[3]}, rsrc, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4){rec[4], rec[5], rec[6], rec[7]}, rsrc, off, 16, 0);
+    }
+  };
+
+  auto epilogue = [&](const Tile& T) {
+    const size_t img_rec = (size_t)T.b * Gout * HpWp;
+    const int img_bytes = Gout * HpWp * 32;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc(a.out + img_rec * 32, 0, img_bytes, 0x00020000);
+    // fused MaxPool2d(2) output (models/unet.py:82-85): [B][Gout][H/2+2][W/2+2] records
+    const int Hpo = a.H / 2 + 2, Wpo = a.W / 2 + 2;
+    const bool do_pool = (EPI == EPI_ACT) && (MBW == 32) && (NBW >= 2) && (a.pool_out != nullptr);
+    [[maybe_unused]] float odot[NBW];   // fused 1x1 out-conv partial sums (EPI_OUTC)
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) odot[n] = 0.f;
+#pragma unroll
+    for (int m = 0; m < G::MTB; ++m) {
+      float bias[16];
+      if constexpr (EPI != EPI_DMASK) {
+        const char* lb = lds + G::BIAS_OFF + (T.ct * MT + m * 32 + 4 * kg) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(lb + 32 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bias[q * 4 + j] = bq[j];
+        }
+      }
+      float v[NBW][16];
+      if constexpr (EPI == EPI_DMASK) {
+        // input-gradient convolution: the LeakyReLU derivative comes from the saved forward activation (same record
+        // position as the output record; this lane's 4 channels of group q are hi[4*kg .. 4*kg+3])
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+          const int y = min(T.y0 + (wave * NBW + n) * G::MBH + py, a.H - 1), x = min(T.x0 + px, a.W - 1);
+          const size_t rec = img_rec + (size_t)(y + 1) * a.Wp + (x + 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            unsigned hh[4] = {0x3c00u, 0x3c00u, 0x3c00u, 0x3c00u};   // no mask: everything "positive" (linear epilogue)
+            if (a.dmask) {
+              const uint2 w = *reinterpret_cast<const uint2*>(
+                  a.dmask + (rec + (size_t)(T.ct * (MT / 8) + m * 4 + q) * HpWp) * 32 + 8 * kg);
+              hh[0] = w.x & 0xffffu;
+              hh[1] = w.x >> 16;
+              hh[2] = w.y & 0xffffu;
+              hh[3] = w.y >> 16;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool pos = (hh[j] & 0x8000u) == 0 && (hh[j] & 0x7fffu) != 0;
+              const float t = acc[m][n][q * 4 + j] * c16;
+              v[n][q * 4 + j] = pos ? t : t * a.slope;
+            }
+          }
+        }
+      } else if constexpr (EPI == EPI_RES) {
+        // residual block tail: act(conv + bias + res); res is an HS8 tensor laid out like the output
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+          const int y = min(T.y0 + (wave * NBW + n) * G::MBH + py, a.H - 1), x = min(T.x0 + px, a.W - 1);
+          const size_t rec = img_rec + (size_t)(y + 1) * a.Wp + (x + 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            h4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};
+            if (a.res) {
+              const char* rp = a.res + (rec + (size_t)(T.ct * (MT / 8) + m * 4 + q) * HpWp) * 32 + 8 * kg;
+              rh = *reinterpret_cast<const h4*>(rp);
+              rl = *reinterpret_cast<const h4*>(rp + 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float t = __builtin_fmaf(acc[m][n][q * 4 + j], c16, bias[q * 4 + j]) + ((float)rh[j] + (float)rl[j]);
+              v[n][q * 4 + j] = __builtin_fmaxf(t, t * a.slope);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float t = __builtin_fmaf(acc[m][n][r], c16, bias[r]);
+            v[n][r] = __builtin_fmaxf(t, t * a.slope);   // = t > 0 ? t : slope * t  for 0 <= slope <= 1
+          }
+      }
+      if constexpr (EPI == EPI_OUTC) {
+        // out = clamp(x + outc(v) ...): accumulate this lane's 16 channels
+        float w16[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w16[r] = a.outc_w[(r & 3) + 8 * (r >> 2) + 4 * kg];
+#pragma unroll
+        for (int n = 0; n < NBW; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) odot[n] = fmaf(w16[r], v[n][r], odot[n]);
+      } else {
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+          const int y = T.y0 + (wave * NBW + n) * G::MBH + py;
+          const int x = T.x0 + px;
+          store_records(v[n], orsrc, (y + 1) * a.Wp + (x + 1), T.ct * (MT / 8) + m * 4, HpWp, (y < a.H) && (x < a.W));
+        }
+      }
+      if constexpr (EPI == EPI_ACT && MBW == 32 && NBW >= 2) {
+        if (do_pool) {
+          const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+              a.pool_out + (size_t)T.b * Gout * Hpo * Wpo * 32, 0, Gout * Hpo * Wpo * 32, 0x00020000);
+#pragma unroll
+          for (int n = 0; n < NBW; n += 2) {
+            float pm[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float t = __builtin_fmaxf(v[n][r], v[n + 1][r]);    // vertical pair: rows y, y+1
+              const float o = __builtin_bit_cast(                      // horizontal pair: lanes x, x^1 (DPP quad_perm 1,0,3,2)
+                  float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));
+              pm[r] = __builtin_fmaxf(t, o);
+            }
+            const int y = T.y0 + (wave * NBW + n), x = T.x0 + px;       // y even, both rows inside or both outside
+            const bool ok = (y + 1 < a.H) && (x + 1 < a.W) && ((px & 1) == 0);
+            store_records(pm, prsrc, (y / 2 + 1) * Wpo + (x / 2 + 1), T.ct * (MT / 8) + m * 4, Hpo * Wpo, ok);
+          }
+        }
+      }
+    }
+    if constexpr (EPI == EPI_OUTC) {
+      // finish the fused 1x1 conv + residual + clamp (models/unet.py:63-66, denoiser/base.py:32)
+#pragma unroll
+      for (int n = 0; n < NBW; ++n) {
+        const float tot = odot[n] + __shfl_xor(odot[n], 32, 64);     // the other 16 channels live in lane ^ 32
+        const int y = T.y0 + (wave * NBW + n) * G::MBH + py;
+        const int x = T.x0 + px;
+        if (kg == 0 && y < a.H && x < a.W) {
+          const size_t o = ((size_t)T.b * a.H + y) * a.W + x;
+          const float r = a.x_in[o] + (tot * (1.f / HS_ASCALE) + a.outc_b[0]);
+          if (a.out_pre) a.out_pre[o] = r;
+          a.out_img[o] = fminf(fmaxf(r, 0.f), 1.f);
+        }
+      }
+    }
+  };
+
+#ifdef HS_TRACE
+  int tk = 0;
+  const bool tr_on = a.trace && blockIdx.x == 8 && wave == 0;
+  auto mark = [&](int tag) {
+    if (tr_on && tk < 4000) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (lane == 0) a.trace[tk] = (t << 4) | (unsigned)tag;
+      ++tk;
+    }
+  };
+#else
+  auto mark = [](int) {};
+#endif
+  int tile = blockIdx.x / nx;   // j of this workgroup's first step
+  if (!valid(tile)) return;
+  Tile cur = decode(tile);
+  int ch = 0, stage = 0;
+  {
+    const char* src = chunk_src(cur, 0);
+    const char* w = chunk_w(cur, 0);
+#pragma unroll
+    for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, w, lds);
+  }
+  bool stores_behind = false;   // the last VMEM operations of this wave are the record stores of a finished tile
+  const bool pool_on = (EPI == EPI_ACT) && (MBW == 32) && (NBW >= 2) && (a.pool_out != nullptr);
+  while (true) {
+    int ntile = tile, nchk = ch + 1;
+    bool has_next = true;
+    Tile nxt = cur;
+    if (nchk == nch) {   // tile boundary: the only place the walk is decoded
+      nchk = 0;
+      ntile = tile + nslot;
+      has_next = valid(ntile);
+      if (has_next) nxt = decode(ntile);
+    }
+    // this step's operands have landed (every wave waits for its own DMA, then the barrier publishes them); stores
+    // of the tile finished in the previous step stay in flight
+    mark(1);
+    if (EPI != EPI_OUTC && stores_behind) {
+      if (pool_on)
+        wait_vmcnt<G::NST + G::NST_POOL>();
+      else
+        wait_vmcnt<G::NST>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    mark(2);
+    __builtin_amdgcn_s_barrier();
+    mark(3);
+    if (!has_next) {
+      body(std::integral_constant<int, 0>{}, stage, nullptr, nullptr);
+    } else {
+      body(std::integral_constant<int, 1>{}, stage, chunk_src(nxt, nchk), chunk_w(nxt, nchk));
+    }
+    mark(4);
+    stores_behind = false;
+    if (ch == nch - 1) {
+      epilogue(cur);
+      zero_acc();
+      stores_behind = true;
+      mark(5);
+    }
+    if (!has_next) break;
+    tile = ntile;
+    ch = nchk;
+    cur = nxt;
+    stage ^= 1;
+  }
+  // half-split range guard: a stored hi half overflowed f16 (|value| >= 4095) or was NaN
+  if constexpr (EPI != EPI_OUTC) {
+    if (a.range_flag) {
+      const bool bad = (range_chk[0] != range_chk[0]) || (range_chk[1] != range_chk[1]);
+      if (bad) __hip_atomic_fetch_or(a.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// hipFuncSetAttribute once per (instance, device); thread-safe
+inline int ensure_dyn_lds(const void* func, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, bool> done;
+  int dev = 0;
+  PNPX_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  auto key = std::make_pair(func, dev);
+  if (done.count(key)) return PNPX_OK;
+  PNPX_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done[key] = true;
+  return PNPX_OK;
+}
+
+template <int MT, int NBW, int MBW, int NW, int EPI>
+static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
+  using G = HsGeom<MT, NBW, MBW, NW>;
+  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI>), G::LDS_BYTES));
+  ConvHsArgs a = a0;
+  a.tilesX = (a.W + G::TW - 1) / G::TW;
+  a.tilesY = (a.H + G::TH - 1) / G::TH;
+  a.B = B;
+  const long long ntiles = (long long)a.nct * a.tilesX * a.tilesY * B;
+  a.div_nct = hs_fastdiv(a.nct);
+  a.div_tx = hs_fastdiv(a.tilesX);
+  a.div_ty = hs_fastdiv(a.tilesY);
+  {
+    const long long dmax = std::max<long long>(a.nct, std::max(a.tilesX, a.tilesY));
+    if ((ntiles + 8 * 256) * dmax >= (1LL << 32)) {
+      set_error("conv_hs: %lld tiles exceed the range of the tile-walk decoder", ntiles);
+      return PNPX_ERR_SHAPE;
+    }
+  }
+  // persistent: one workgroup per CU (the LDS request makes a second one impossible), each walks ntiles/grid tiles
+  long long grid = 256;
+  if (grid > ntiles) grid = ntiles;
+  if (grid >= 8) grid -= grid % 8;          // whole XCD groups (the kernel falls back to a plain walk otherwise)
+  if (a.nct > 1 && (grid / 8) % a.nct != 0 && grid >= 8 * a.nct) grid -= grid % (8 * a.nct);
+#ifdef HS_TRACE
+  static unsigned long long* tbuf = nullptr;
+  const char* tfile = getenv("PNPX_HS_TRACE");
+  if (tfile) {
+    if (!tbuf) PNPX_HIP(hipMalloc(&tbuf, 4096 * 8));
+    PNPX_HIP(hipMemsetAsync(tbuf, 0, 4096 * 8, s));
+    a.trace = tbuf;
+  }
+#endif
+  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI>), dim3((unsigned)grid), dim3(NW * 64), G::LDS_BYTES, s, a);
+  PNPX_LAUNCH_CHECK();
+#ifdef HS_TRACE
+  if (tfile) {
+    static std::vector<unsigned long long> host(4096);
+    PNPX_HIP(hipStreamSynchronize(s));
+    PNPX_HIP(hipMemcpy(host.data(), tbuf, 4096 * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(tfile, "a")) {
+      fprintf(f, "# conv_hs<%d,%d,%d,%d,e%d> W=%d H=%d B=%d G=%d nct=%d grid=%lld\n", MT, NBW, MBW, NW, EPI, a.W, a.H, B,
+              a.G0 + a.G1, a.nct, grid);
+      unsigned long long prev = 0;
+      for (int i = 0; i < 4096 && host[i]; ++i) {
+        const unsigned long long t = host[i] >> 4;
+        fprintf(f, "%d:%llu ", (int)(host[i] & 15), prev ? t - prev : 0ull);
+        prev = t;
+      }
+      fprintf(f, "\n");
+      fclose(f);
+    }
+  }
+#endif
+  return PNPX_OK;
+}
+
+struct HsChoice {
+  int nbw, nw;
+};
+
+template <int MT, int MBW, int EPI>
+static int launch_hs_mbw(const ConvHsArgs& a, int B, HsChoice c, hipStream_t s) {
+  if (c.nw == 8) {
+    if (c.nbw >= 2) return launch_hs_cfg<MT, 2, MBW, 8, EPI>(a, B, s);
+    return launch_hs_cfg<MT, 1, MBW, 8, EPI>(a, B, s);
+  }
+  if (c.nbw == 4) return launch_hs_cfg<MT, 4, MBW, 4, EPI>(a, B, s);
+  if (c.nbw == 2) return launch_hs_cfg<MT, 2, MBW, 4, EPI>(a, B, s);
+  return launch_hs_cfg<MT, 1, MBW, 4, EPI>(a, B, s);
+}
+
+HsChoice hs_choose(int mt, const ConvHsArgs& a, int B);   // conv_hs.hip
+
+template <int MT, int EPI>
+static int launch_hs_mt(const ConvHsArgs& a, int B, hipStream_t s) {
+  const int mbw = a.W >= 32 ? 32 : (a.W >= 16 ? 16 : 8);
+  const HsChoice c = hs_choose(MT, a, B);
+  if (mbw == 32) return launch_hs_mbw<MT, 32, EPI>(a, B, c, s);
+  if (mbw == 16) return launch_hs_mbw<MT, 16, EPI>(a, B, c, s);
+  return launch_hs_mbw<MT, 8, EPI>(a, B, c, s);
+}
+
+// entry points of the other translation units
+int launch_conv_hs_dmask(const ConvHsArgs& a, int mt, int B, hipStream_t s);   // conv_hs_bwd.hip
+int launch_conv_hs_res(const ConvHsArgs& a, int mt, int B, hipStream_t s);     // conv_hs_res.hip
+
+}  // namespace pnpx

@@ -237,6 +237,7 @@ extern "C" int pnpx_csmri_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_
                                const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
                                int H, int W, int T, void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int HW = H * W;
@@ -267,12 +268,14 @@ extern "C" int pnpx_csmri_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_
     PNPX_TRY((launch_rows<true>(P, kld, StoreAdmm{zo, uo, xo, ui, xr, d, i == T - 1}, s)));
   }
   return PNPX_OK;
+  });
 }
 
 extern "C" int pnpx_csmri_hqs(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                               const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
                               int H, int W, int T, void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int HW = H * W;
@@ -302,12 +305,14 @@ extern "C" int pnpx_csmri_hqs(pnpx_ctx* ctx, const float* vars_in, float* vars_o
     PNPX_TRY((launch_rows<true>(P, kld, StoreHqs{zo, xo, xr, d, i == T - 1}, s)));
   }
   return PNPX_OK;
+  });
 }
 
 extern "C" int pnpx_csmri_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                              const uint8_t* mask, const float* sigma_d, const float* tau, int param_stride, int B,
                              int H, int W, int T, void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int HW = H * W;
@@ -338,12 +343,14 @@ extern "C" int pnpx_csmri_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_ou
   hipLaunchKernelGGL(real_to_slot_kernel, g1((size_t)HW * B), dim3(256), 0, s, S.xr, vout, is, HW, B);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
+  });
 }
 
 extern "C" int pnpx_csmri_apg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                               const uint8_t* mask, const float* sigma_d, const float* tau, const float* beta,
                               int param_stride, int B, int H, int W, int T, void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
   if (!beta || !tau) {
     set_error("csmri_apg: null tau/beta");
@@ -375,12 +382,14 @@ extern "C" int pnpx_csmri_apg(pnpx_ctx* ctx, const float* vars_in, float* vars_o
     PNPX_LAUNCH_CHECK();
   }
   return PNPX_OK;
+  });
 }
 
 extern "C" int pnpx_csmri_redadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                                   const uint8_t* mask, const float* sigma_d, const float* mu, const float* lamda,
                                   int param_stride, int B, int H, int W, int T, void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
   if (!mu || !lamda) {
     set_error("csmri_redadmm: null mu/lamda");
@@ -413,4 +422,5 @@ extern "C" int pnpx_csmri_redadmm(pnpx_ctx* ctx, const float* vars_in, float* va
     PNPX_TRY((launch_rows<true>(P, kld, StoreAdmmCx{zo, uo, uc, xc}, s)));
   }
   return PNPX_OK;
+  });
 }

@@ -508,6 +508,7 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
     ConvHsFuse f;
     f.slope = 0.f;                          // ReLU
     f.res = res ? hsc(*res) : nullptr;
+    f.range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
     return launch_conv_hs(Lh, hsc(in), in.C / 8, nullptr, 0, hsc(out), B, h, w, f, s);
   };
   const float* xin = ptr(P.stem);

@@ -394,6 +394,7 @@ int pnpx_pr_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
                   const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int S, int H, int W,
                   int T, void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   REQUIRE(vars_in && vars_out && y0 && mask && sigma_d && mu && tau && B > 0 && S > 0 && T >= 0 && param_stride >= T,
           "pnpx_pr_iadmm: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -430,6 +431,7 @@ int pnpx_pr_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
     PNPX_LAUNCH_CHECK();
   }
   return PNPX_OK;
+  });
 }
 
 // ------------------------------------------------------------------------------------------- SPI
@@ -446,6 +448,7 @@ int pnpx_spi_inverse(pnpx_ctx* ctx, const float* ztilde, const float* K1, const 
 int pnpx_spi_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* x0, const float* Kmap,
                   const float* sigma_d, const float* mu, int param_stride, int B, int H, int W, int T, void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   REQUIRE(vars_in && vars_out && x0 && Kmap && sigma_d && mu && B > 0 && T >= 0 && param_stride >= T,
           "pnpx_spi_admm: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -472,6 +475,7 @@ int pnpx_spi_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
     PNPX_LAUNCH_CHECK();
   }
   return PNPX_OK;
+  });
 }
 
 // ------------------------------------------------------------------------------------------- PSNR
@@ -542,6 +546,7 @@ int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
                   const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int R, int T,
                   void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   REQUIRE(vars_in && vars_out && y0 && sigma_d && mu && tau && B > 0 && R > 0 && n_view > 0 && T >= 0 &&
               param_stride >= T && opnorm > 0.f,
           "pnpx_ct_iadmm: bad argument");
@@ -580,11 +585,13 @@ int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
     PNPX_LAUNCH_CHECK();
   }
   return PNPX_OK;
+  });
 }
 
 int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
                const float* sigma_d, const float* tau, int param_stride, int B, int R, int T, void* stream) {
   LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
   REQUIRE(vars_in && vars_out && y0 && sigma_d && tau && B > 0 && R > 0 && n_view > 0 && T >= 0 &&
               param_stride >= T && opnorm > 0.f,
           "pnpx_ct_pg: bad argument");
@@ -618,6 +625,7 @@ int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float
     PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, vars_out, nullptr, B, R, R, s, nullptr));
   }
   return PNPX_OK;
+  });
 }
 
 }  // extern "C"

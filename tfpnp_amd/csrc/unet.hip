@@ -248,12 +248,12 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
   auto bpi = [&](const Act& d) { return act_bytes_per_image(CONV_HS, d.C, d.H, d.W); };
   auto at = [&](const Act& d, int b0) { return A + d.off + (size_t)b0 * bpi(d); };
   auto rat = [&](const Act& d, int b0) { return reinterpret_cast<HsRec*>(at(d, b0)); };
-  const bool no_pool_fuse = getenv("PNPX_NO_POOL_FUSE") != nullptr, no_outc_fuse = keep_all || getenv("PNPX_NO_OUTC_FUSE") != nullptr;
+  const bool no_pool_fuse = !ctx->opt_fuse_pool, no_outc_fuse = keep_all || !ctx->opt_fuse_outc;
+  unsigned* const range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
   // (A variant that interpolated the bilinear x2 upsample inside the conv loader was built and parity-tested in r1; it cost
   // ~190 VALU ops per 32-byte record in the MFMA waves, was slower than "separate upsample kernel + DMA loader" (6.48 vs
   // 6.31 ms per forward) and was removed again -- it also cost every instance registers.)
-  int sub_default = 24;
-  if (const char* e = getenv("PNPX_SUBBATCH")) sub_default = atoi(e);
+  const int sub_default = ctx->opt_subbatch;
   auto sub_of = [&](int level) {   // images per sub-batch at this level
     if (sub_default <= 0 || level > 1) return B;
     // level-1 tensors are 2x smaller per image: twice the images per sub-batch
@@ -278,8 +278,10 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
     Lh.w = D.w;
     Lh.b = L.b;
     Lh.inv_scale = D.inv_scale;
+    ConvHsFuse fz = fuse;
+    fz.range_flag = range_flag;
     PNPX_TRY(launch_conv_hs(Lh, at(i0, b0), i0.C / 8, i1 ? at(*i1, b0) : nullptr, i1 ? i1->C / 8 : 0, at(o, b0), nb, o.H,
-                            o.W, fuse, s));
+                            o.W, fz, s));
     return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * nb);
   };
   auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o, int b0, int nb,

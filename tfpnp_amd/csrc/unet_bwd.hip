@@ -476,6 +476,7 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
       ConvHsFuse f;
       f.dmask = saved ? FA + saved->off : nullptr;
       f.slope = saved ? 0.2f : 1.0f;
+      f.range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
       return launch_conv_hs(Lh, GA + gin.off, gin.C / 8, nullptr, 0, GA + gout.off, B, gout.H, gout.W, f, s);
     };
     for (int l = 0; l <= 3; ++l) {

@@ -21,26 +21,36 @@ from ..utils import transforms
 
 
 # ------------------------------------------------------------------------------------------- noise models
+def _per_item(values, like):
+    """[N] host values -> device tensor broadcastable over `like` ([N,1,...])."""
+    t = torch.as_tensor(np.asarray(values, dtype=np.float32), device=like.device)
+    return t.view(like.shape[0], *([1] * (like.dim() - 1)))
+
+
 class GaussianModelD:
-    """tfpnp/utils/noise.py:20-33 -- additive N(0, (sigma/255)^2), sigma drawn per call from a discrete set."""
+    """tfpnp/utils/noise.py:20-33 -- additive N(0, (sigma/255)^2).  The reference draws sigma inside
+    Dataset.__getitem__, i.e. ONE PER ITEM; so does the batched form here (sigma returned as [N])."""
 
     def __init__(self, sigmas):
         self.sigmas = sigmas
 
     def __call__(self, x, idx=None, generator=None):
-        sigma = (self.sigmas[idx] if idx is not None else np.random.choice(self.sigmas)) / 255.
-        return x + torch.randn(x.shape, device=x.device, generator=generator) * sigma, sigma
+        N = x.shape[0]
+        sig = (np.full(N, self.sigmas[idx]) if idx is not None else np.random.choice(self.sigmas, size=N)) / 255.
+        sigma = _per_item(sig, x)
+        return x + torch.randn(x.shape, device=x.device, generator=generator) * sigma, sigma.reshape(N)
 
 
 class GaussianModelC:
-    """tfpnp/utils/noise.py:5-17 -- sigma ~ U(low, high) / 255."""
+    """tfpnp/utils/noise.py:5-17 -- sigma ~ U(low, high) / 255, one draw per item."""
 
     def __init__(self, low_sigma=0, high_sigma=55):
         self.low_sigma, self.high_sigma = low_sigma, high_sigma
 
     def __call__(self, x, generator=None):
-        sigma = np.random.uniform(self.low_sigma, self.high_sigma) / 255.
-        return x + torch.randn(x.shape, device=x.device, generator=generator) * sigma, sigma
+        N = x.shape[0]
+        sigma = _per_item(np.random.uniform(self.low_sigma, self.high_sigma, size=N) / 255., x)
+        return x + torch.randn(x.shape, device=x.device, generator=generator) * sigma, sigma.reshape(N)
 
 
 class GaussianModelP:
@@ -58,13 +68,14 @@ class GaussianModelP:
 
 
 class PoissonModel:
-    """tfpnp/utils/noise.py:61-84 -- intensity noise alpha/255 * |z| * N(0,1) on z^2, per-item residual std."""
+    """tfpnp/utils/noise.py:61-84 -- intensity noise alpha/255 * |z| * N(0,1) on z^2, per-item alpha and residual std."""
 
     def __init__(self, alphas):
         self.alphas = alphas
 
     def __call__(self, z, idx=None, generator=None):
-        alpha = self.alphas[idx] if idx is not None else np.random.choice(self.alphas)
+        N = z.shape[0]   # one alpha per item, as Dataset.__getitem__ draws it
+        alpha = _per_item(np.full(N, self.alphas[idx]) if idx is not None else np.random.choice(self.alphas, size=N), z)
         noise = alpha / 255 * z.abs() * torch.randn(z.shape, device=z.device, generator=generator)
         y = torch.sqrt(torch.clamp(z ** 2 + noise, min=0))
         sigma = (y - z.abs()).reshape(z.shape[0], -1).std(dim=1)

@@ -107,6 +107,16 @@ class ShardedEnv:
         self.n_global = self.n_local = 0
         self.lo = self.hi = 0
         self._local_done = False
+        # device of the collectives' buffers: fixed at construction so that a rank WITHOUT local items still joins the
+        # gathers with tensors the backend accepts (RCCL wants this rank's GPU; gloo takes the CPU)
+        backend = dist.get_backend(group) if dist.is_initialized() else 'gloo'
+        env_dev = getattr(env, 'device', None)
+        if env_dev is not None and torch.device(env_dev).type == 'cuda':
+            self.coll_device = torch.device(env_dev)
+        elif backend == 'nccl':
+            self.coll_device = torch.device('cuda', torch.cuda.current_device())
+        else:
+            self.coll_device = torch.device('cpu')
 
     def __getattr__(self, name):          # get_policy_ob, get_images, solver, max_episode_step, ...
         return getattr(self.env, name)
@@ -128,7 +138,7 @@ class ShardedEnv:
     def step(self, action):
         """-> (local observation of the still-live items, global reward [B_global,1], all ranks done?, info)"""
         ref = self.env.state['gt'] if self.n_local else None
-        device = ref.device if ref is not None else torch.device('cpu')
+        device = ref.device if ref is not None else self.coll_device
         done_full = torch.ones(self.n_local, dtype=torch.float32, device=device)
         ob = None
         if not self._local_done:

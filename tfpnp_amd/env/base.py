@@ -1,10 +1,15 @@
-"""PnPEnv -- the caller of the hot path, mirror of tfpnp/env/base.py:43-242 (same constructor, `reset` / `step` /
-`forward` / `get_images` signatures and return values) so the reference's trainer / evaluator loops drive it unchanged.
+"""PnPEnv -- the caller of the hot path: same constructor, `reset` / `step` / `forward` / `get_images` signatures and
+return values as tfpnp/env/base.py:43-242, so rollout and evaluation loops written against the reference
+(eval/evaluator.py, the rollout half of trainer/mddpg/trainer.py) drive it unchanged.  Scope: inference / evaluation
+episodes and the differentiable one-step model `forward` (gradients wrt actions through the native VJPs,
+tfpnp_amd/autograd.py).  A trainable actor / critic and the MDDPG trainer are NOT part of this package.
 
-What happens per `step` (base.py:157-191): gather the live rows `idx_left`, run the native solver under no_grad, write
-state / output back, delta-PSNR reward over the whole batch (native pnpx_psnr), build the observation of the rows that
-were live, shrink `idx_left` by `idx_stop`, build the observation of the rows still live.  `forward` (base.py:193-206) is
-the differentiable one-step model used by the actor / critic update (native VJPs, see tfpnp_amd/autograd.py).
+One `step` (base.py:157-191), orchestrated on the device (csrc/env.hip):
+  live-row gather of solver state + aux inputs (ONE launch)  ->  native solver loop  ->  write-back of state and output
+  (ONE launch)  ->  delta-PSNR reward over the whole batch (native)  ->  observation of the rows that were live (ONE
+  gather launch)  ->  device-side compaction of the live set by `idx_stop`, whose survivor count is the step's single
+  host read (`all_done` is a Python bool in the contract)  ->  observation of the rows still live.
+No boolean-mask indexing, no `len(idx_left)` sync, no aten gather / index_put kernels.
 
 The four task environments of the reference (tasks/*/env.py) differ only in which state entries make up the
 observation and how they are packed for the policy; here that is data (class attributes), not four copies of the code.
@@ -17,31 +22,37 @@ from ..data.batch import Batch
 from ..utils import transforms
 
 
-class _Psnr(torch.autograd.Function):
-    """Native PSNR forward; analytic VJP: d psnr_b / d out = -(20 / ln 10) * (clamp(out) - gt) / (N * mse_b) inside (0,1)."""
+# ---- row bookkeeping.  Device tensors go through the native ops; CPU tensors (host-logic tests with stub solvers and
+# the gloo process group -- the native solvers themselves refuse CPU tensors) use plain indexing.
+def _take_rows(tensors, rows, n):
+    if rows.is_cuda:
+        return ops.rows_gather(tensors, rows, n)
+    sel = rows[:n]
+    return [t[sel] for t in tensors]
 
-    @staticmethod
-    def forward(ctx, output, gt):
-        ctx.save_for_backward(output, gt)
-        return ops.psnr(output, gt)
 
-    @staticmethod
-    def backward(ctx, g):
-        output, gt = ctx.saved_tensors
-        B = output.shape[0]
-        o = output.reshape(B, -1)
-        diff = o.clamp(0, 1) - gt.reshape(B, -1)
-        sse = (diff * diff).sum(dim=1, keepdim=True)
-        inside = (o > 0) & (o < 1)
-        go = (-20.0 / 2.302585092994046) * g.reshape(B, 1) * diff / sse * inside
-        return go.view_as(output), None
+def _put_rows(values, targets, rows, n):
+    if rows.is_cuda:
+        ops.rows_scatter(values, targets, rows, n)
+        return
+    sel = rows[:n]
+    for v, t in zip(values, targets):
+        t[sel] = v
+
+
+def _surviving_rows(rows, idx_stop, n):
+    """(rows that continue, their count as a Python int) -- the step's one host read."""
+    idx_stop = idx_stop.reshape(-1).to(torch.int64)
+    if rows.is_cuda:
+        return ops.live_compact(rows, idx_stop, n)
+    keep = rows[:n][idx_stop[:n] == 0]
+    return keep, int(keep.numel())
 
 
 def torch_psnr(output, gt):
-    """tfpnp/env/base.py:237-242 -> [B,1]"""
-    if torch.is_grad_enabled() and output.requires_grad:
-        return _Psnr.apply(output, gt)
-    return ops.psnr(output, gt)
+    """tfpnp/env/base.py:237-242 -> [B,1].  One dispatcher op (torch.ops.pnpx.psnr) with an analytic VJP."""
+    from .. import torch_ops as T
+    return T.call("psnr", output, gt)
 
 
 def torch2img255(img):
@@ -68,21 +79,23 @@ class PnPEnv:
         self.max_episode_step = max_episode_step
         self.cur_step = 0
         self.state = None
-        self.idx_left = None
+        self._rows = None        # int64 [B]: the first _n_live entries are the batch rows still being iterated
+        self._n_live = 0
         self.last_metric = 0
         self.metric_fn = torch_psnr
 
+    @property
+    def idx_left(self):
+        """Rows still live (the reference's attribute of the same name): a view, no copy, no sync."""
+        return self._rows[:self._n_live]
+
     # ------------------------------------------------------------------ observation plumbing (tasks/*/env.py)
     def get_policy_ob(self, ob):
-        parts = []
-        for key, kind in self.policy_layout:
-            v = ob[key]
-            if kind == 'real':
-                v = transforms.complex2real(v)
-            elif kind == 'channel':
-                v = transforms.complex2channel(v)
-            parts.append(v)
-        return torch.cat(parts, 1)
+        parts = [(ob[key], kind) for key, kind in self.policy_layout]
+        if parts and parts[0][0].is_cuda:
+            return ops.policy_ob_pack(parts)          # one launch: views + channel concat fused
+        views = {'real': transforms.complex2real, 'channel': transforms.complex2channel, 'raw': lambda v: v}
+        return torch.cat([views[kind](v) for v, kind in parts], 1)
 
     def get_eval_ob(self, ob):
         return self.get_policy_ob(ob)
@@ -104,78 +117,75 @@ class PnPEnv:
         return nxt
 
     def _observation(self):
-        il = self.idx_left
-        ob = Batch(gt=self.state['gt'][il, ...], variables=self.state['solver'][il, ...], T=self.state['T'][il, ...])
-        for k in self.ob_keys:
-            v = self.state[k][il, ...]
-            ob[k] = v.float() if k in self.float_keys else v
+        """Batch of the live rows: gt, variables, T and the task's ob_keys (bool entries listed in float_keys as float)."""
+        names = ('gt', 'solver', 'T') + tuple(self.ob_keys)
+        got = _take_rows([self.state[k] for k in names], self._rows, self._n_live)
+        ob = Batch()
+        for k, v in zip(names, got):
+            ob['variables' if k == 'solver' else k] = v.float() if k in self.float_keys else v
         return ob
 
     # ------------------------------------------------------------------ basic API (tfpnp/env/base.py:121-206)
+    def _next_batch(self):
+        try:
+            return next(self.data_iterator)
+        except StopIteration:
+            self.data_iterator = iter(self.data_loader)
+            return next(self.data_iterator)
+
     def reset(self, data=None):
         self.cur_step = 0
-        if data is None:
-            try:
-                data = next(self.data_iterator)
-            except StopIteration:
-                self.data_iterator = iter(self.data_loader)
-                data = next(self.data_iterator)
+        data = dict(self._next_batch() if data is None else data)
         if self.data_transform is not None:
-            data = self.data_transform(data)
-        data = {k: (v.to(self.device) if isinstance(v, torch.Tensor) and self.device.type != 'cpu' else v)
-                for k, v in dict(data).items()}
+            data = dict(self.data_transform(data))
+        if self.device.type != 'cpu':
+            data = {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
         data['solver'] = self.solver.reset(data)
         if 'output' in data:
             data['output'] = data['output'].clone()
-        B, _, H, W = data['gt'].shape
-        dev = data['gt'].device
-        data['T'] = torch.full((B, 1, H, W), self.cur_step / self.max_episode_step, dtype=torch.float32, device=dev)
-        self.state = data
-        self.idx_left = torch.arange(0, B, device=dev)
+        gt = data['gt']
+        B, _, H, W = gt.shape
+        data['T'] = torch.zeros((B, 1, H, W), dtype=torch.float32, device=gt.device)
+        self.state = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+        self._rows = torch.arange(B, device=gt.device)
+        self._n_live = B
         self.last_metric = self._compute_metric()
         return self._observation()
 
     def step(self, action):
         self.cur_step += 1
-        il = self.idx_left
+        st, rows, n = self.state, self._rows, self._n_live
         with torch.no_grad():
-            aux = tuple(a[il, ...] for a in self.solver.filter_aux_inputs(self.state))
-            inputs = (self.state['solver'][il, ...], aux)
-            parameters = self.solver.filter_hyperparameter(action)
-            solver_state = self.solver(inputs, parameters)
-        self.state['T'] = torch.full_like(self.state['T'], self.cur_step / self.max_episode_step)
-        self.state['output'][il, ...] = self.solver.get_output(solver_state)
-        self.state['solver'][il, ...] = solver_state
-        reward = self._compute_reward()
-        ob = self._observation()
-        idx_stop = action['idx_stop']
-        self.idx_left = il[idx_stop == 0]
-        all_done = len(self.idx_left) == 0
-        done = idx_stop.detach()
-        if self.cur_step == self.max_episode_step:
-            all_done = True
-            done = torch.ones_like(idx_stop)
-        ob_masked = self._observation()
+            live = _take_rows([st['solver'], *self.solver.filter_aux_inputs(st)], rows, n)
+            solver_state = self.solver((live[0], tuple(live[1:])), self.solver.filter_hyperparameter(action))
+            st['T'].fill_(self.cur_step / self.max_episode_step)
+            _put_rows([self.solver.get_output(solver_state), solver_state], [st['output'], st['solver']], rows, n)
+            reward = self._compute_reward()
+            ob = self._observation()                      # rows that were live during this step
+            idx_stop = action['idx_stop']
+            self._rows, self._n_live = _surviving_rows(rows, idx_stop, n)
+            done = idx_stop.detach()
+            all_done = self._n_live == 0
+            if self.cur_step == self.max_episode_step:
+                all_done, done = True, torch.ones_like(idx_stop)
+            ob_masked = self._observation()               # rows still live
         return ob, ob_masked, reward, all_done, {'done': done}
 
     def forward(self, ob, action):
         """Differentiable one-step model (base.py:193-206): gradients flow into `action` / `ob` tensors that require
         them.  -> (next observation, delta-PSNR reward [B,1])"""
-        output = self._get_attribute(ob, 'output')
         gt = self._get_attribute(ob, 'gt')
-        inputs = self._get_attribute(ob, 'solver_input')
-        parameters = self.solver.filter_hyperparameter(action)
-        solver_state = self.solver(inputs, parameters)
-        output2 = self.solver.get_output(solver_state)
-        reward = self.metric_fn(output2, gt) - self.metric_fn(output, gt)
-        return self._build_next_ob(ob, solver_state), reward
+        before = self.metric_fn(self._get_attribute(ob, 'output'), gt)
+        solver_state = self.solver(self._get_attribute(ob, 'solver_input'), self.solver.filter_hyperparameter(action))
+        after = self.metric_fn(self.solver.get_output(solver_state), gt)
+        return self._build_next_ob(ob, solver_state), after - before
 
     def get_images(self, ob, pre_process=torch2img255):
         return tuple(pre_process(self._get_attribute(ob, k)) for k in ('input', 'output', 'gt'))
 
     def to(self, device):
         if not isinstance(device, torch.device):
-            raise TypeError('device must be torch.device, but got {}'.format(type(device)))
+            raise TypeError(f'PnPEnv.to expects a torch.device, got {type(device).__name__}')
         self.device = device
         return self
 
@@ -184,6 +194,5 @@ class PnPEnv:
 
     def _compute_reward(self):
         metric = self._compute_metric()
-        reward = metric - self.last_metric
-        self.last_metric = metric
+        reward, self.last_metric = metric - self.last_metric, metric
         return reward

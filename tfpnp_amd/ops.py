@@ -4,13 +4,27 @@ PyTorch is plumbing here (device memory, streams); every op below is one libpnpx
 current HIP stream.  All ops require contiguous fp32 tensors on a ROCm device; anything else raises.
 """
 import ctypes as C
+import itertools
 import threading
+import weakref
 
 import numpy as np
 import torch
 
 from . import _lib
 from ._lib import PnpxError, check
+
+
+_ctx_ids = itertools.count(1)
+_ctx_by_id = weakref.WeakValueDictionary()
+
+
+def context_by_id(cid):
+    """The live Context with integer handle `cid` (how contexts travel through torch.ops.pnpx.* schemas)."""
+    try:
+        return _ctx_by_id[int(cid)]
+    except KeyError:
+        raise PnpxError(f"no live native context with id {cid}") from None
 
 
 class Context:
@@ -26,6 +40,8 @@ class Context:
         self._h = h
         self._has_weights = False
         self._policy = None
+        self.cid = next(_ctx_ids)          # integer handle for the dispatcher-registered ops (torch_ops.py)
+        _ctx_by_id[self.cid] = self
 
     @property
     def handle(self):
@@ -69,6 +85,17 @@ class Context:
     def set_option(self, key, value):
         """e.g. set_option('conv_mode', 0) selects the plain-fp32 MFMA convolutions (default 1 = half-split f16)."""
         check(_lib.lib().pnpx_ctx_set_option(self.handle, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int(0)
+        check(_lib.lib().pnpx_ctx_get_option(self.handle, key.encode(), C.byref(v)))
+        return int(v.value)
+
+    def status(self):
+        """Raises PnpxError once the half-split range guard has tripped (an earlier call's output was invalid; the
+        context has switched itself to conv_mode 0).  Does not synchronise: call it after the stream has drained,
+        e.g. right after reading a result back.  Re-arm with set_option('range_guard', 1)."""
+        check(_lib.lib().pnpx_ctx_status(self.handle))
 
     def reserve(self, B, H, W):
         check(_lib.lib().pnpx_ctx_reserve(self.handle, B, H, W))
@@ -403,10 +430,19 @@ def radon_backprojection(sino, R, ctx=None):
     return out
 
 
+def _ct_sino(y0, B, R, n_view):
+    """The native CT loops index the sinogram with a (n_view, det) stride: a mismatching tensor must not get through."""
+    y0 = _f32(y0, "y0")
+    want = (B, 1, int(n_view), radon_det_count(R))
+    if tuple(y0.shape) != want:
+        raise PnpxError(f"y0: sinogram of shape {tuple(y0.shape)} does not match (B, 1, n_view, det) = {want}")
+    return y0
+
+
 def ct_iadmm(ctx, variables, y0, n_view, opnorm, sigma_d, mu, tau, iter_num=None):
     v = _vars(variables, 3, False)
     B, _, R, _ = v.shape
-    y0 = _f32(y0, "y0")
+    y0 = _ct_sino(y0, B, R, n_view)
     ps, T = _params(B, sigma_d, mu, tau)
     T = T if iter_num is None else iter_num
     out = torch.empty_like(v)
@@ -421,7 +457,7 @@ def ct_iadmm(ctx, variables, y0, n_view, opnorm, sigma_d, mu, tau, iter_num=None
 def ct_pg(ctx, variables, y0, n_view, opnorm, sigma_d, tau, iter_num=None):
     v = _vars(variables, 1, False)
     B, _, R, _ = v.shape
-    y0 = _f32(y0, "y0")
+    y0 = _ct_sino(y0, B, R, n_view)
     ps, T = _params(B, sigma_d, tau)
     T = T if iter_num is None else iter_num
     out = torch.empty_like(v)
@@ -430,4 +466,121 @@ def ct_pg(ctx, variables, y0, n_view, opnorm, sigma_d, tau, iter_num=None):
     with torch.cuda.device(v.device):
         check(_lib.lib().pnpx_ct_pg(ctx.handle, _p(v), _p(out), _p(y0), int(n_view), float(opnorm),
                                     *[_p(p) for p in ps], ps[0].shape[1], B, R, T, _stream(v)))
+    return out
+
+
+# ------------------------------------------------------------------------------------- episode orchestration (env.hip)
+def _dense(t, name):
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise PnpxError(f"{name}: expected a tensor on a ROCm device (there is no CPU path)")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _idx64(idx, name):
+    if not isinstance(idx, torch.Tensor) or idx.dtype != torch.int64 or idx.device.type != "cuda":
+        raise PnpxError(f"{name}: expected an int64 tensor on a ROCm device")
+    return idx if idx.is_contiguous() else idx.contiguous()
+
+
+def _rows_call(fn, srcs, dsts, small, idx, n_rows, dev):
+    n = len(srcs)
+    S = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    D = (C.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    RB = (C.c_size_t * n)(*[(t.numel() // max(t.shape[0], 1)) * t.element_size() for t in small])
+    ctx = default_context(dev)
+    with torch.cuda.device(dev):
+        check(fn(ctx.handle, n, S, D, RB, _p(idx), int(n_rows), _stream(idx)))
+
+
+def rows_gather(tensors, idx, n_rows):
+    """[t[idx[:n_rows]] for t in tensors] in ONE launch (tfpnp/env/base.py:162-166).  idx: device int64 (capacity >=
+    n_rows); dtypes are preserved (fp32 state, bool masks)."""
+    idx = _idx64(idx, "idx")
+    srcs = [_dense(t, "tensor") for t in tensors]
+    outs = [torch.empty((n_rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in srcs]
+    if n_rows > 0 and srcs:
+        _rows_call(_lib.lib().pnpx_rows_gather, srcs, outs, outs, idx, n_rows, idx.device)
+    return outs
+
+
+def rows_scatter(values, targets, idx, n_rows):
+    """targets[k][idx[:n_rows]] = values[k] for every k, in ONE launch (tfpnp/env/base.py:171-172).  In place."""
+    idx = _idx64(idx, "idx")
+    vals = []
+    for v, t in zip(values, targets):
+        if not t.is_contiguous() or t.device.type != "cuda":
+            raise PnpxError("rows_scatter: targets must be contiguous device tensors")
+        v = _dense(v, "value")
+        if v.dtype != t.dtype or tuple(v.shape[1:]) != tuple(t.shape[1:]) or v.shape[0] < n_rows:
+            raise PnpxError(f"rows_scatter: value {tuple(v.shape)}/{v.dtype} does not fit target {tuple(t.shape)}/{t.dtype}")
+        vals.append(v)
+    if n_rows > 0 and vals:
+        _rows_call(_lib.lib().pnpx_rows_scatter, vals, list(targets), vals, idx, n_rows, idx.device)
+
+
+def live_compact(idx_left, idx_stop, n):
+    """(idx_left[:n][idx_stop == 0] in a buffer of capacity n, number of survivors as a Python int).
+    Synchronises the current stream: the one host read of an env step (tfpnp/env/base.py:180-182)."""
+    idx_left = _idx64(idx_left, "idx_left")
+    idx_stop = _idx64(idx_stop, "idx_stop")
+    if idx_stop.numel() < n or idx_left.numel() < n:
+        raise PnpxError("live_compact: idx_left / idx_stop shorter than n")
+    out = torch.empty((max(n, 1),), dtype=torch.int64, device=idx_left.device)
+    cnt = C.c_int(0)
+    ctx = default_context(idx_left.device)
+    with torch.cuda.device(idx_left.device):
+        check(_lib.lib().pnpx_live_compact(ctx.handle, _p(idx_left), _p(idx_stop), int(n), _p(out), C.byref(cnt),
+                                           _stream(idx_left)))
+    return out, int(cnt.value)
+
+
+_PACK_KINDS = {"raw": 0, "real": 1, "channel": 2, "u8": 3}
+
+
+def policy_ob_pack(entries, idx=None, n_rows=None):
+    """Fused get_policy_ob (tasks/*/env.py): entries = [(tensor, 'raw' | 'real' | 'channel'), ...] in channel order;
+    'raw' fp32/bool [B,c,H,W], 'real' / 'channel' complex [B,c,H,W,2].  idx/n_rows: gather rows idx[:n_rows] on the fly."""
+    srcs, kinds, chans = [], [], []
+    H = W = None
+    for t, kind in entries:
+        t = _dense(t, "observation entry")
+        if kind == "raw":
+            if t.dim() != 4:
+                raise PnpxError(f"policy_ob_pack: raw entry must be [B,c,H,W], got {tuple(t.shape)}")
+            if t.dtype in (torch.bool, torch.uint8):
+                k = "u8"
+            elif t.dtype == torch.float32:
+                k = "raw"
+            else:
+                raise PnpxError(f"policy_ob_pack: unsupported dtype {t.dtype}")
+        elif kind in ("real", "channel"):
+            if t.dim() != 5 or t.shape[-1] != 2 or t.dtype != torch.float32:
+                raise PnpxError(f"policy_ob_pack: {kind} entry must be fp32 [B,c,H,W,2], got {tuple(t.shape)}")
+            k = kind
+        else:
+            raise PnpxError(f"policy_ob_pack: unknown kind {kind}")
+        if H is None:
+            H, W = t.shape[2], t.shape[3]
+        elif (t.shape[2], t.shape[3]) != (H, W):
+            raise PnpxError("policy_ob_pack: entries disagree on H, W")
+        srcs.append(t)
+        kinds.append(_PACK_KINDS[k])
+        chans.append(t.shape[1])
+    n = len(srcs)
+    if n == 0:
+        raise PnpxError("policy_ob_pack: no entries")
+    rows = srcs[0].shape[0] if n_rows is None else int(n_rows)
+    C_out = sum(c * (2 if k == 2 else 1) for c, k in zip(chans, kinds))
+    out = torch.empty((rows, C_out, H, W), dtype=torch.float32, device=srcs[0].device)
+    if rows == 0:
+        return out
+    if idx is not None:
+        idx = _idx64(idx, "idx")
+    S = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    K = (C.c_int * n)(*kinds)
+    CH = (C.c_int * n)(*chans)
+    ctx = default_context(out.device)
+    with torch.cuda.device(out.device):
+        check(_lib.lib().pnpx_policy_ob_pack(ctx.handle, n, S, K, CH, _p(idx) if idx is not None else None, rows, H, W,
+                                             _p(out), _stream(out)))
     return out

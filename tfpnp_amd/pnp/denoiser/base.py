@@ -9,6 +9,7 @@ import os
 import torch
 
 from ... import ops
+from ... import torch_ops as T
 from ..._lib import PnpxError
 
 CURRENT_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -49,11 +50,9 @@ class UNetDenoiser2D(torch.nn.Module):
 
     def forward(self, x, sigma):
         # x: [B,1,H,W]; sigma: [B]      (denoiser/base.py:23-32)
-        from ... import autograd as A
-        if A.needs_grad(x, sigma):      # training path: native forward + native VJP wrt x and sigma
-            return A.denoise(self.context(x.device), x, sigma)
-        return ops.unet_denoise(self.context(x.device), x, sigma)
+        # one dispatcher op; its registered autograd formula is the native VJP wrt x and sigma (training path)
+        return T.call("unet_denoise", x, sigma, self.context(x.device).cid)
 
     def forward_preclamp(self, x, sigma):
         """(clamped, pre-clamp) outputs -- the pre-clamp UNet output is what the parity tests compare."""
-        return ops.unet_denoise(self.context(x.device), x, sigma, return_preclamp=True)
+        return T.call("unet_denoise_preclamp", x, sigma, self.context(x.device).cid)

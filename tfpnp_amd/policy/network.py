@@ -15,6 +15,7 @@ import torch.nn as nn
 from torch.distributions import Categorical
 
 from .. import ops
+from .. import torch_ops as T
 
 
 class ResNetActorBase(nn.Module):
@@ -48,7 +49,7 @@ class ResNetActorBase(nn.Module):
         return self._ctx[key]
 
     def forward(self, state, idx_stop, train, hidden):
-        action_probs, action_deterministic = ops.policy_forward(self.context(state.device), state)
+        action_probs, action_deterministic = T.call("policy_forward", state, self.context(state.device).cid)
         dist_categorical = Categorical(action_probs)
         dist_entropy = dist_categorical.entropy().unsqueeze(1)
         if idx_stop is None:

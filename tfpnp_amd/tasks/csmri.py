@@ -7,7 +7,7 @@ iter_num inner iterations (denoiser prox + masked-FFT data prox + dual update) o
 import torch
 
 from .. import autograd as A
-from .. import ops
+from .. import torch_ops as T
 from ..env.base import PnPEnv
 from ..pnp.solver.base import ADMMSolver, HQSSolver, PGSolver, APGSolver, REDADMMSolver, AMPSolver
 from ..utils import transforms
@@ -40,7 +40,7 @@ class ADMMSolver_CSMRI(CSMRIMixin, ADMMSolver):
         sigma_d, mu = parameters
         if A.needs_grad(variables, sigma_d, mu):
             return self._forward_autograd(variables, y0, mask, sigma_d, mu, iter_num)
-        return ops.csmri_admm(self._ctx(variables), variables, y0, mask, sigma_d, mu, iter_num)
+        return T.call("csmri_admm", variables, y0, mask, sigma_d, mu, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
     def _forward_autograd(self, variables, y0, mask, sigma_d, mu, iter_num):
         """Training path (PnPEnv.forward under autograd): the reference's loop, tasks/csmri/solver.py:43-55."""
@@ -67,7 +67,7 @@ class HQSSolver_CSMRI(CSMRIMixin, HQSSolver):
                 x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
                 z = A.fft2(_blend(A.fft2(x), y0, m, _v5(mu[:, i], B)), inverse=True)
             return torch.cat([x, z], dim=1)
-        return ops.csmri_hqs(self._ctx(variables), variables, y0, mask, sigma_d, mu, iter_num)
+        return T.call("csmri_hqs", variables, y0, mask, sigma_d, mu, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
 
 class PGSolver_CSMRI(CSMRIMixin, PGSolver):
@@ -83,7 +83,7 @@ class PGSolver_CSMRI(CSMRIMixin, PGSolver):
                 z = x - _v5(tau[:, i], B) * A.fft2(temp, inverse=True)
                 x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
             return x
-        return ops.csmri_pg(self._ctx(variables), variables, y0, mask, sigma_d, tau, iter_num)
+        return T.call("csmri_pg", variables, y0, mask, sigma_d, tau, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
 
 class APGSolver_CSMRI(CSMRIMixin, APGSolver):
@@ -102,7 +102,7 @@ class APGSolver_CSMRI(CSMRIMixin, APGSolver):
                 x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
                 s = x + _v5(beta[:, i], B) * (x - x_prev)
             return torch.cat([x, s], dim=1)
-        return ops.csmri_apg(self._ctx(variables), variables, y0, mask, sigma_d, tau, beta, iter_num)
+        return T.call("csmri_apg", variables, y0, mask, sigma_d, tau, beta, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
 
 class REDADMMSolver_CSMRI(CSMRIMixin, REDADMMSolver):
@@ -121,7 +121,7 @@ class REDADMMSolver_CSMRI(CSMRIMixin, REDADMMSolver):
                 z = A.fft2(_blend(A.fft2(x + u), y0, m, _mu), inverse=True)
                 u = u + x - z
             return torch.cat([x, z, u], dim=1)
-        return ops.csmri_redadmm(self._ctx(variables), variables, y0, mask, sigma_d, mu, lamda, iter_num)
+        return T.call("csmri_redadmm", variables, y0, mask, sigma_d, mu, lamda, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
 
 class AMPSolver_CSMRI(CSMRIMixin, AMPSolver):

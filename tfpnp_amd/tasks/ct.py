@@ -2,7 +2,7 @@
 import torch
 
 from .. import autograd as A
-from .. import ops
+from .. import torch_ops as T
 from ..env.base import PnPEnv
 from ..pnp.solver.base import IADMMSolver, PGSolver
 from ..utils.transforms import RadonGenerator
@@ -25,7 +25,10 @@ class IADMMSolver_CT(CTMixin, IADMMSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, view) = inputs
         sigma_d, mu, tau = parameters
-        n_view = int(view[0, 0, 0, 0].item() * 120)     # host sync, as in the reference (:26)
+        # The reference recovers the view count from the observation map, int(view[0,0,0,0] * 120) (:26): a host sync,
+        # and the float32 round trip truncates many counts by one (50 -> 49, 100 -> 99), which torch_radon then rejects
+        # with a shape error.  The sinogram itself carries the count, exactly and without a sync.
+        n_view = int(y0.shape[2])
         radon = self.radon_generator(variables.shape[-1], n_view, device=variables.device)
         if A.needs_grad(variables, sigma_d, mu, tau):
             x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
@@ -37,7 +40,8 @@ class IADMMSolver_CT(CTMixin, IADMMSolver):
                 z = z - _tau * (g + _mu * (z - (x + u)))
                 u = u + x - z
             return torch.cat([x, z, u], dim=1)
-        return ops.ct_iadmm(self._ctx(variables), variables, y0, n_view, radon.opnorm, sigma_d, mu, tau, iter_num)
+        return T.call("ct_iadmm", variables, y0, n_view, float(radon.opnorm), sigma_d, mu, tau, -1 if iter_num is None else iter_num,
+                      self._ctx(variables).cid)
 
 
 class PGSolver_CT(CTMixin, PGSolver):
@@ -50,7 +54,7 @@ class PGSolver_CT(CTMixin, PGSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, view) = inputs
         sigma_d, tau = parameters
-        n_view = int(view[0, 0, 0, 0].item() * 120)
+        n_view = int(y0.shape[2])                        # see IADMMSolver_CT.forward
         radon = self.radon_generator(variables.shape[-1], n_view, device=variables.device)
         if A.needs_grad(variables, sigma_d, tau):
             x, B, R = variables, variables.shape[0], variables.shape[-1]
@@ -58,7 +62,7 @@ class PGSolver_CT(CTMixin, PGSolver):
                 g = A.radon_backprojection(A.radon_forward(x, n_view) - y0, R) / radon.opnorm ** 2
                 x = self.prox_mapping(x - tau[:, i].reshape(B, 1, 1, 1) * g, sigma_d[:, i])
             return x
-        return ops.ct_pg(self._ctx(variables), variables, y0, n_view, radon.opnorm, sigma_d, tau, iter_num)
+        return T.call("ct_pg", variables, y0, n_view, float(radon.opnorm), sigma_d, tau, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
 
 _solver_map = {'iadmm': IADMMSolver_CT, 'pg': PGSolver_CT}

@@ -2,7 +2,7 @@
 import torch
 
 from .. import autograd as A
-from .. import ops
+from .. import torch_ops as T
 from ..env.base import PnPEnv
 from ..pnp.solver.base import IADMMSolver, PGSolver
 from ..utils.transforms import complex2real, real2complex
@@ -43,7 +43,7 @@ class IADMMSolver_PR(PRMixin, IADMMSolver):
                 z = z - _tau * (g + _mu * (z - (x + u)))
                 u = u + x - z
             return torch.cat([x, z, u], dim=1)
-        return ops.pr_iadmm(self._ctx(variables), variables, y0, mask, sigma_d, mu, tau, iter_num)
+        return T.call("pr_iadmm", variables, y0, mask, sigma_d, mu, tau, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
 
 class PGSolver_PR(PRMixin, PGSolver):

@@ -2,7 +2,7 @@
 import torch
 
 from .. import autograd as A
-from .. import ops
+from .. import torch_ops as T
 from ..env.base import PnPEnv
 from ..pnp.solver.base import ADMMSolver
 
@@ -30,12 +30,12 @@ class ADMMSolver_SPI(SPIMixin, ADMMSolver):
                 zt = x + u
                 # spi_inverse (transforms.py:404-439): the bisection result carries no gradient in the reference
                 # either (bmin/bmax/bave are built by masked assignment of constants); only the K1 == 0 branch does.
-                bis = ops.spi_inverse(zt.detach(), K1, Kv, _mu.detach())
+                bis = T.call("spi_inverse", zt.detach(), K1, Kv, _mu.detach())
                 z = torch.clamp(torch.where(K1 == 0, zt - (Kv ** 2 - K1) / _mu, bis), 0.0, 1.0)
                 u = u + x - z
                 x = self.prox_mapping(z - u, sigma_d[:, i])
             return torch.cat([x, z, u], dim=1)
-        return ops.spi_admm(self._ctx(variables), variables, x0, K, sigma_d, mu, iter_num)
+        return T.call("spi_admm", variables, x0, K, sigma_d, mu, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
 
 _solver_map = {'admm_spi': ADMMSolver_SPI}

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .. import torch_ops as T
 
 
 def real2complex(x):
@@ -28,13 +29,13 @@ def complex2channel(x):
 def fft2(data):
     """Centered orthonormal 2-D FFT over dims (-3,-2) of [...,H,W,2].  transforms.py:68-84"""
     assert data.size(-1) == 2
-    return ops.fft2(data, inverse=False, centered=True)
+    return T.call("fft2", data, False, True)
 
 
 def ifft2(data):
     """transforms.py:87-103"""
     assert data.size(-1) == 2
-    return ops.fft2(data, inverse=True, centered=True)
+    return T.call("fft2", data, True, True)
 
 
 def complex_abs(data):
@@ -58,18 +59,18 @@ def conjugate(x):
 def cdp_forward(data, mask):
     """transforms.py:282-301"""
     assert mask.size(-1) == 2
-    return ops.cdp_forward(data, mask)
+    return T.call("cdp_forward", data, mask)
 
 
 def cdp_backward(data, mask):
     """transforms.py:304-320"""
     assert mask.size(-1) == 2
-    return ops.cdp_backward(data, mask)
+    return T.call("cdp_backward", data, mask)
 
 
 def spi_inverse(ztilde, K1, K, mu):
     """transforms.py:404-439"""
-    return ops.spi_inverse(ztilde, K1, K, mu)
+    return T.call("spi_inverse", ztilde, K1, K, mu)
 
 
 # ------------------------------------------------------------------------------------------------ CT
@@ -96,10 +97,10 @@ class Radon_norm:
         self.opnorm = opnorm
 
     def forward(self, x):
-        return ops.radon_forward(x, self.view)
+        return T.call("radon_forward", x, int(self.view))
 
     def backprojection(self, sinogram):
-        return ops.radon_backprojection(sinogram, self.resolution)
+        return T.call("radon_backprojection", sinogram, int(self.resolution))
 
     backward = backprojection
 
@@ -120,9 +121,9 @@ class Radon_norm:
         L = max(64, 1 << int(np.ceil(np.log2(2 * D))))
         x = torch.zeros(B * C * V, 1, L, 2, device=sinogram.device, dtype=torch.float32)
         x[:, 0, :D, 0] = sinogram.reshape(-1, D)
-        spec = ops.fft2(x, inverse=False, centered=False)
+        spec = T.call("fft2", x, False, False)
         filt = torch.from_numpy(ramp_filter(L)).to(sinogram.device)
-        out = ops.fft2(spec * filt.view(1, 1, L, 1), inverse=True, centered=False)
+        out = T.call("fft2", spec * filt.view(1, 1, L, 1), True, False)
         return (out[:, 0, :D, 0] * (np.pi / (2 * V))).reshape(B, C, V, D).contiguous()
 
     def filter_backprojection(self, sinogram):

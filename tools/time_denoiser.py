@@ -1,4 +1,4 @@
-"""Wall time of the denoiser forward (B=48, 256^2) for several PNPX_SUBBATCH values."""
+"""Wall time of the denoiser forward (B=48, 256^2) for several values of the "subbatch" context option."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,10 +10,11 @@ dev = torch.device("cuda:0")
 den = UNetDenoiser2D(state_dict=synth.make_unet_params(0), conv_mode=1)
 x = torch.rand(B, 1, H, H, device=dev)
 s = torch.full((B,), 0.1, device=dev)
-os.environ["PNPX_SUBBATCH"] = "0"
+ctx = den.context(dev)
+ctx.set_option("subbatch", 0)
 ref = den(x, s).clone()
 for sb in ["0", "2", "4", "6", "8", "12", "16", "24"]:
-    os.environ["PNPX_SUBBATCH"] = sb
+    ctx.set_option("subbatch", int(sb))
     y = den(x, s); torch.cuda.synchronize()
     ok = torch.equal(y, ref)
     t0 = time.perf_counter()
