@@ -55,3 +55,48 @@ ROLLOUT_CONTINUE_BIAS = 3.0   # added to the "continue" logit of the rollout act
 def policy_obs(B, C, H, W, seed):
     """Synthetic policy observation in [0,1] (float32 [B,C,H,W])."""
     return np.random.RandomState(seed).uniform(0, 1, (B, C, H, W)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------- CT: analytic phantoms
+class ellipse_phantom:
+    """Random ellipse phantoms with EXACT line integrals (the chord of an ellipse has a closed form): the best available
+    pin for the Radon pair, whose reference implementation (torch_radon) cannot be built here.
+    Coordinates are centred pixel units: x = column - (R/2 - 0.5), y = row - (R/2 - 0.5)."""
+
+    @staticmethod
+    def make(seed, n=6, R=256):
+        rs = np.random.RandomState(seed)
+        ells = []
+        for _ in range(n):
+            a, b = rs.uniform(0.05, 0.2, 2) * R          # r + max(a, b) <= 0.45 R: every ellipse lies inside the image
+            r = rs.uniform(0, 0.25) * R
+            ph = rs.uniform(0, 2 * np.pi)
+            ells.append(dict(cx=r * np.cos(ph), cy=r * np.sin(ph), a=a, b=b, phi=rs.uniform(0, np.pi),
+                             rho=rs.uniform(0.2, 1.0)))
+        return ells
+
+    @staticmethod
+    def raster(ells, R, ss=4):
+        """Area-sampled (ss x ss sub-pixels) image [R,R] float32."""
+        sub = (np.arange(R * ss) + 0.5) / ss - 0.5 - (R / 2 - 0.5)
+        X, Y = np.meshgrid(sub, sub)
+        img = np.zeros((R * ss, R * ss), np.float64)
+        for e in ells:
+            c, s = np.cos(e["phi"]), np.sin(e["phi"])
+            u = (X - e["cx"]) * c + (Y - e["cy"]) * s
+            v = -(X - e["cx"]) * s + (Y - e["cy"]) * c
+            img += e["rho"] * ((u / e["a"]) ** 2 + (v / e["b"]) ** 2 <= 1.0)
+        return img.reshape(R, ss, R, ss).mean(axis=(1, 3)).astype(np.float32)
+
+
+def ellipse_sinogram(ells, angles, det):
+    """Exact parallel-beam sinogram [V, det] of the phantom in the geometry of tfpnp/utils/transforms.py:487-491 (unit
+    detector spacing, s = k - det/2 + 0.5): chord length 2ab*sqrt(r^2 - t^2)/r^2, r^2 = a^2 cos^2 + b^2 sin^2."""
+    s = np.arange(det, dtype=np.float64) - det / 2 + 0.5
+    out = np.zeros((len(angles), det), np.float64)
+    for v, th in enumerate(np.asarray(angles, np.float64)):
+        for e in ells:
+            r2 = (e["a"] * np.cos(th - e["phi"])) ** 2 + (e["b"] * np.sin(th - e["phi"])) ** 2
+            tt = s - (e["cx"] * np.cos(th) + e["cy"] * np.sin(th))
+            out[v] += e["rho"] * 2 * e["a"] * e["b"] * np.sqrt(np.maximum(r2 - tt ** 2, 0.0)) / r2
+    return out.astype(np.float32)

@@ -68,7 +68,7 @@ HsChoice hs_choose(int mt, const ConvHsArgs& a, int B) {
       c.nbw = rows / 4;
     }
   }
-  if (mt == 32) c.nbw = 4;
+  if (mt == 32 && a.w_mt == 32) c.nbw = 4;
   // two waves per SIMD (same tile, half the blocks per wave) once every workgroup has at least two tiles to walk
   if (c.nbw >= 2 && blocks(4 * c.nbw) >= 512 && !(a.pool_out && c.nbw < 4)) c = HsChoice{c.nbw / 2, 8};
 #ifdef PNPX_TUNING
@@ -115,6 +115,7 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.Hp = H + 2;
   a.Wp = W + 2;
   a.nct = L.cout / L.mt;
+  a.w_mt = L.mt;
   a.inv_scale = L.inv_scale;
   a.slope = fuse.slope;
   a.dmask = fuse.dmask;
@@ -122,16 +123,34 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.neg_one = -1.0f;
   a.range_flag = fuse.range_flag;
   a.trace = nullptr;
+  a.abl = 0;
+#ifdef PNPX_TUNING
+  if (const char* e = getenv("PNPX_HS_ABL")) a.abl = atoi(e);
+#endif
   a.tilesX = a.tilesY = 0;
   a.B = B;
   if (L.mt != 64 && L.mt != 32) {
     set_error("conv_hs: no kernel for mt=%d", L.mt);
     return PNPX_ERR_SHAPE;
   }
-  if (a.dmask) return launch_conv_hs_dmask(a, L.mt, B, s);
-  if (a.res) return launch_conv_hs_res(a, L.mt, B, s);
+  // Half tiles: when the 64-cout tiling leaves more than half of the 256 CUs without a tile (small batches, deep
+  // levels), run the 32-cout instance over the same 64-cout weight packing: twice the tiles, identical K order (bit-
+  // identical results), weight slice gathered by the DMA.
+  int mt_run = L.mt;
+  if (L.mt == 64) {
+    const HsChoice c64 = hs_choose(64, a, B);
+    const int mbw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
+    const int th = c64.nw * c64.nbw * (32 / mbw);
+    const long long tiles64 = (long long)a.nct * ((W + mbw - 1) / mbw) * ((H + th - 1) / th) * B;
+    if (tiles64 <= 128) {
+      mt_run = 32;
+      a.nct = L.cout / 32;
+    }
+  }
+  if (a.dmask) return launch_conv_hs_dmask(a, mt_run, B, s);
+  if (a.res) return launch_conv_hs_res(a, mt_run, B, s);
   if (a.outc_w) return launch_hs_mt<32, EPI_OUTC>(a, B, s);
-  if (L.mt == 64) return launch_hs_mt<64, EPI_ACT>(a, B, s);
+  if (mt_run == 64) return launch_hs_mt<64, EPI_ACT>(a, B, s);
   return launch_hs_mt<32, EPI_ACT>(a, B, s);
 }
 

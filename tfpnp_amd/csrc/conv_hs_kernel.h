@@ -160,7 +160,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
                                   : a.in1 + ((size_t)T.b * a.G1 + (g0 - a.G0)) * HpWp * 32;
     return src + ((size_t)T.y0 * a.Wp + T.x0) * 32;
   };
+  // Weight slices are packed [cout / w_mt][chunk][tap][hi,lo][kg][w_mt] x 16 B.  A 32-cout instance may run over a
+  // 64-cout packing ("half tiles": twice the tiles for batches that do not fill the chip, same K order -> same bits):
+  // its slice is then every other 512-byte run of the 64-cout slice, gathered by the DMA's per-lane source address.
+  const bool half_tiles = (MT == 32) && (a.w_mt == 64);
   auto chunk_w = [&](const Tile& T, int chunk) -> const char* {
+    if (half_tiles) return a.wpk + ((size_t)(T.ct >> 1) * nch + chunk) * (2 * G::W_BYTES) + (T.ct & 1) * 512;
     return a.wpk + ((size_t)T.ct * nch + chunk) * G::W_BYTES;
   };
   auto issue_slot = [&](int slot, const char* src, const char* wsrc, char* lstage) {
@@ -171,7 +176,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
     } else {
       const int j = wave + NW * (slot - G::NI);
       if (NW * (slot - G::NI) + NW - 1 < G::W_INSTR || j < G::W_INSTR)
-        glds16b(wsrc + j * 1024 + lane * 16, lstage + G::IN_BYTES + j * 1024);
+        // 16-byte piece i = j*64 + lane of the slice: row r = i / 32 (tap, half, kg), cout m = i % 32
+        glds16b(wsrc + (half_tiles ? (j * 2 + (lane >> 5)) * 1024 + (lane & 31) * 16 : j * 1024 + lane * 16),
+                lstage + G::IN_BYTES + j * 1024);
     }
   };
 
@@ -301,6 +308,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
         rec[6 + e] = sl[1];
       }
       const int off = ok ? ((g_first + 2 * qp + kg) * group_stride_rec + pix_rec) * 32 : (int)0x80000000;
+#ifdef PNPX_TUNING   // ablation (invalid results): conversion work kept alive, stores dropped
+      if (a.abl & 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(rec[i]));
+        asm volatile("" ::"v"(off));
+        continue;
+      }
+#endif
       __builtin_amdgcn_raw_buffer_store_b128((u32x4){rec[0], rec[1], rec[2], rec[3]}, rsrc, off, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128((u32x4){rec[4], rec[5], rec[6], rec[7]}, rsrc, off, 16, 0);
     }
@@ -498,9 +513,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
     mark(4);
     stores_behind = false;
     if (ch == nch - 1) {
-      epilogue(cur);
+#ifdef PNPX_TUNING      // ablation (invalid results): accumulators kept alive, no epilogue at all
+      if (a.abl & 2) {
+#pragma unroll
+        for (int m = 0; m < G::MTB; ++m)
+#pragma unroll
+          for (int n = 0; n < NBW; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[m][n][r]));
+      } else
+#endif
+      {
+        epilogue(cur);
+        stores_behind = true;
+      }
       zero_acc();
-      stores_behind = true;
       mark(5);
     }
     if (!has_next) break;

@@ -131,27 +131,43 @@ __global__ __launch_bounds__(256) void maxpool2_hs_kernel(const HsRec* __restric
   dst[(bg * (Ho + 2) + (yo + 1)) * (Wo + 2) + xo + 1] = hs_pack(o);
 }
 
-__global__ __launch_bounds__(256) void upsample2x_hs_kernel(const HsRec* __restrict__ src, HsRec* __restrict__ dst,
-                                                            size_t n_out, int h, int w, int Ht, int Wt, float sy,
-                                                            float sx) {
+// Bilinear x2 (align_corners) on HS8 records through LDS.  A workgroup produces a TX x TY tile of output records of one
+// channel group (TX * TY = 256, one record per thread); the (TY/2 + 2) x (TX/2 + 2) source records it interpolates from
+// are staged once in LDS with dense, coalesced 32-byte loads, so every source record is fetched once per tile instead
+// of once per output pixel through the L1 (4 x), and the index arithmetic is per tile, not per pixel.  Same
+// association as ATen's kernel: (1-ly) * ((1-lx) * v00 + lx * v01) + ly * ((1-lx) * v10 + lx * v11).
+template <int TX>
+__global__ __launch_bounds__(256) void upsample2x_hs_kernel(const HsRec* __restrict__ src, HsRec* __restrict__ dst, int h,
+                                                            int w, int Ht, int Wt, float sy, float sx) {
+  constexpr int TY = 256 / TX;
+  constexpr int SW = TX / 2 + 2, SH = TY / 2 + 2;
+  __shared__ uint4 tile[SH * SW * 2];
   const int H = 2 * h, W = 2 * w;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_out) return;
-  const int x = (int)(i % W);
-  const size_t t = i / W;
-  const int y = (int)(t % H);
-  const size_t bg = t / H;
+  const int X0 = blockIdx.x * TX, Y0 = blockIdx.y * TY;
+  const size_t bg = blockIdx.z;
+  const int c_lo = (int)(sx * X0), r_lo = (int)(sy * Y0);
+  const uint4* s = reinterpret_cast<const uint4*>(src + bg * (size_t)(h + 2) * (w + 2) + 1);
+  for (int k = threadIdx.x; k < SH * SW * 2; k += 256) {     // 16-byte pieces: consecutive lanes = consecutive bytes
+    const int rec = k >> 1, piece = k & 1;
+    const int rr = rec / SW, cc = rec - rr * SW;
+    const int yy = min(r_lo + rr, h - 1), xx = min(c_lo + cc, w - 1);
+    tile[k] = s[((size_t)(yy + 1) * (w + 2) + xx) * 2 + piece];
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int x = X0 + tx, y = Y0 + ty;
+  if (x >= W || y >= H) return;
   const float fy = sy * y, fx = sx * x;
   const int y0 = (int)fy, x0 = (int)fx;
   const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
   const float ly = fy - y0, lx = fx - x0;
   const float hy = 1.f - ly, hx = 1.f - lx;
-  const HsRec* s = src + bg * (h + 2) * (w + 2) + 1;
+  const HsRec* t = reinterpret_cast<const HsRec*>(tile);
   float v00[8], v01[8], v10[8], v11[8], o[8];
-  hs_unpack(s[(size_t)(y0 + 1) * (w + 2) + x0], v00);
-  hs_unpack(s[(size_t)(y0 + 1) * (w + 2) + x1], v01);
-  hs_unpack(s[(size_t)(y1 + 1) * (w + 2) + x0], v10);
-  hs_unpack(s[(size_t)(y1 + 1) * (w + 2) + x1], v11);
+  hs_unpack(t[(y0 - r_lo) * SW + (x0 - c_lo)], v00);
+  hs_unpack(t[(y0 - r_lo) * SW + (x1 - c_lo)], v01);
+  hs_unpack(t[(y1 - r_lo) * SW + (x0 - c_lo)], v10);
+  hs_unpack(t[(y1 - r_lo) * SW + (x1 - c_lo)], v11);
 #pragma unroll
   for (int k = 0; k < 8; ++k) o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
   dst[(bg * (Ht + 2) + (y + 1)) * (Wt + 2) + x + 1] = hs_pack(o);
@@ -324,9 +340,18 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
       const int nb = (B - b0 < sb) ? (B - b0) : sb;
       ConvHsFuse f;
       {
-        const size_t n_up = (size_t)nb * (below->C / 8) * (2 * h) * (2 * w);
-        hipLaunchKernelGGL(upsample2x_hs_kernel, g1d(n_up), dim3(256), 0, s, rat(*below, b0), rat(P.u[l], b0), n_up, h, w,
-                           P.u[l].H, P.u[l].W, sy, sx);
+        const unsigned nbg = (unsigned)(nb * (below->C / 8));
+        const int Wo = 2 * w, Ho = 2 * h;
+        if (Wo > 128) {
+          hipLaunchKernelGGL(upsample2x_hs_kernel<256>, dim3((Wo + 255) / 256, Ho, nbg), dim3(256), 0, s, rat(*below, b0),
+                             rat(P.u[l], b0), h, w, P.u[l].H, P.u[l].W, sy, sx);
+        } else if (Wo > 32) {
+          hipLaunchKernelGGL(upsample2x_hs_kernel<64>, dim3((Wo + 63) / 64, (Ho + 3) / 4, nbg), dim3(256), 0, s,
+                             rat(*below, b0), rat(P.u[l], b0), h, w, P.u[l].H, P.u[l].W, sy, sx);
+        } else {
+          hipLaunchKernelGGL(upsample2x_hs_kernel<32>, dim3((Wo + 31) / 32, (Ho + 7) / 8, nbg), dim3(256), 0, s,
+                             rat(*below, b0), rat(P.u[l], b0), h, w, P.u[l].H, P.u[l].W, sy, sx);
+        }
         PNPX_LAUNCH_CHECK();
         PNPX_TRY(rec.mark("upsample2x", 0));
       }

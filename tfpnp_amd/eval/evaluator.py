@@ -20,69 +20,58 @@ def psnr_qrnn3d(X, Y, data_range=255):
     return float(np.mean(vals))
 
 
-def eval_single(env, data, policy, max_episode_step, metric=psnr_qrnn3d):
-    """One sample (batch of 1) driven by the policy until it stops or max_episode_step is reached."""
-    observation = env.reset(data=data)
-    hidden = policy.init_state(observation.shape[0])
-    _, output_init, gt = env.get_images(observation)
-    psnr_init = metric(output_init[0], gt[0])
-    episode_steps = 0
-    psnr_seq = [psnr_init]
-    action_seqs = {}
-    ob = observation
-    time_stamp = time.time()
-    while episode_steps < max_episode_step:
-        action, _, _, hidden = policy(env.get_policy_ob(ob), idx_stop=None, train=False, hidden=hidden)
-        ob, _, _, done, _ = env.step(action)
-        episode_steps += 1
-        _, output, gt = env.get_images(ob)
-        psnr_seq.append(float(metric(output[0], gt[0])))
-        action.pop('idx_stop')
-        for k, v in action.items():
-            action_seqs.setdefault(k, [])
-            for i in range(v.shape[0]):
-                action_seqs[k] += list(v[i].detach().cpu().numpy())
-        if done:
-            break
-    if ob.gt.is_cuda:
-        torch.cuda.synchronize(ob.gt.device)
-    run_time = time.time() - time_stamp
-    input, output, gt = env.get_images(ob)
-    psnr_finished = metric(output[0], gt[0])
-    info = (episode_steps, psnr_seq, action_seqs, run_time)
-    imgs = (input[0], output_init[0], output[0], gt[0])
-    return psnr_init, psnr_finished, info, imgs
-
-
-def eval_batch(env, data, policy, max_episode_step, metric=psnr_qrnn3d):
-    """Like eval_single for a batch of B > 1 samples at once (the reference evaluates one sample per call because its
-    bookkeeping indexes [0]; the native path is ~10x more efficient per image at env_batch 48 than at 1).  Items stop
-    individually (`idx_stop`), exactly as in training rollouts.  Returns per-item lists
-    (psnr_init, psnr_finished, episode_steps) and the wall time of the whole batch."""
+def _rollout(env, data, policy, max_episode_step, metric, trace):
+    """Policy-driven episode over a batch of any size with per-item bookkeeping.  Items stop individually (`idx_stop`),
+    exactly as in training rollouts.  trace=True additionally records each item's PSNR after every step and its
+    action sequence (one device read-back per step, as the reference's eval_single does)."""
+    from ..env.base import torch2img255
     ob = env.reset(data=data)
     B = ob.shape[0]
     hidden = policy.init_state(B)
-    _, out0, gt = env.get_images(ob)
-    psnr_init = [metric(out0[b], gt[b]) for b in range(B)]
-    steps = [0] * B
+    first = env.get_images(ob)                                     # (input, output, gt), 0..255 arrays
+    rec = [{'psnr': [metric(first[1][b], first[2][b])], 'steps': 0, 'actions': {}} for b in range(B)]
     live = list(range(B))
-    time_stamp = time.time()
+    t0 = time.time()
     for _ in range(max_episode_step):
         action, _, _, hidden = policy(env.get_policy_ob(ob), idx_stop=None, train=False, hidden=hidden)
-        for b in live:
-            steps[b] += 1
         stop = action['idx_stop'].detach().cpu().numpy()
-        _, ob, _, all_done, _ = env.step(action)
+        ob_stepped, ob, _, all_done, _ = env.step(action)
+        if trace:
+            _, out, gt = env.get_images(ob_stepped)
+            values = {k: v.detach().cpu().numpy() for k, v in action.items() if k != 'idx_stop'}
+        for row, b in enumerate(live):
+            rec[b]['steps'] += 1
+            if trace:
+                rec[b]['psnr'].append(float(metric(out[row], gt[row])))
+                for k, v in values.items():
+                    rec[b]['actions'].setdefault(k, []).extend(v[row].tolist())
         live = [b for b, s_ in zip(live, stop) if s_ == 0]
         if all_done:
             break
     if env.state['gt'].is_cuda:
         torch.cuda.synchronize(env.state['gt'].device)
-    run_time = time.time() - time_stamp
-    from ..env.base import torch2img255
-    out, gt = torch2img255(env.state['output']), torch2img255(env.state['gt'])
-    psnr_finished = [metric(out[b], gt[b]) for b in range(B)]
-    return psnr_init, psnr_finished, steps, run_time
+    run_time = time.time() - t0
+    final = tuple(torch2img255(env.state[k]) for k in (env.input_key, 'output', 'gt'))
+    for b in range(B):
+        rec[b]['psnr_final'] = metric(final[1][b], final[2][b])
+    return rec, first, final, run_time
+
+
+def eval_single(env, data, policy, max_episode_step, metric=psnr_qrnn3d):
+    """The reference's per-sample evaluation (eval/evaluator.py:75-118) = the B = 1 case of the batched rollout; same
+    return layout: psnr_init, psnr_finished, (steps, psnr trace, action sequences, wall time), (input, output_init,
+    output, gt)."""
+    rec, first, final, run_time = _rollout(env, data, policy, max_episode_step, metric, trace=True)
+    r = rec[0]
+    return (r['psnr'][0], r['psnr_final'], (r['steps'], r['psnr'], r['actions'], run_time),
+            (final[0][0], first[1][0], final[1][0], final[2][0]))
+
+
+def eval_batch(env, data, policy, max_episode_step, metric=psnr_qrnn3d):
+    """A whole loader batch at once (the native path is ~10x more efficient per image at env_batch 48 than at 1).
+    Returns per-item lists (psnr_init, psnr_finished, episode_steps) and the wall time of the batch."""
+    rec, _, _, run_time = _rollout(env, data, policy, max_episode_step, metric, trace=False)
+    return [r['psnr'][0] for r in rec], [r['psnr_final'] for r in rec], [r['steps'] for r in rec], run_time
 
 
 class Evaluator:

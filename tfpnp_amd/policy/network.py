@@ -12,7 +12,6 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
-from torch.distributions import Categorical
 
 from .. import ops
 from .. import torch_ops as T
@@ -49,25 +48,24 @@ class ResNetActorBase(nn.Module):
         return self._ctx[key]
 
     def forward(self, state, idx_stop, train, hidden):
-        action_probs, action_deterministic = T.call("policy_forward", state, self.context(state.device).cid)
-        dist_categorical = Categorical(action_probs)
-        dist_entropy = dist_categorical.entropy().unsqueeze(1)
-        if idx_stop is None:
-            idx_stop = dist_categorical.sample() if train else torch.argmax(action_probs, dim=1)
-        action_categorical_logprob = dist_categorical.log_prob(idx_stop).unsqueeze(1)
-        action = self.action_mapping(action_deterministic)
+        """-> (action dict incl. 'idx_stop', log-prob of idx_stop [B,1], entropy of the stop head [B,1], hidden)"""
+        p_stop, det = T.call("policy_forward", state, self.context(state.device).cid)   # [B,2] softmax, [B,n_det] sigmoid
+        logp = torch.log(p_stop.clamp_min(torch.finfo(p_stop.dtype).eps))     # Categorical's own clamp
+        entropy = -torch.special.xlogy(p_stop, p_stop).sum(dim=1, keepdim=True)
+        if idx_stop is None:      # stochastic while training, greedy otherwise (network.py:149-156)
+            idx_stop = torch.multinomial(p_stop, 1).squeeze(1) if train else p_stop.argmax(dim=1)
+        action = self.action_mapping(det)
         action['idx_stop'] = idx_stop
-        return action, action_categorical_logprob, dist_entropy, hidden
+        return action, logp.gather(1, idx_stop.view(-1, 1)), entropy, hidden
 
     def action_mapping(self, action_deterministic):
-        chunk_size = int(action_deterministic.shape[1] // self.num_actions)
-        action_values = torch.split(action_deterministic, chunk_size, dim=1)
-        action = OrderedDict()
-        for i, key in enumerate(self.action_range):
-            action[key] = action_values[i] * self.action_range[key]['scale'] + self.action_range[key]['shift']
-        return action
+        """Sigmoid outputs [B, num_actions * bundle] -> {name: [B, bundle] in the action's range} (network.py:163-175)."""
+        per_action = action_deterministic.shape[1] // self.num_actions
+        return OrderedDict(
+            (name, action_deterministic[:, i * per_action:(i + 1) * per_action] * rng['scale'] + rng['shift'])
+            for i, (name, rng) in enumerate(self.action_range.items()))
 
-    def init_state(self, B):
+    def init_state(self, B):      # no recurrent state (the reference returns a dummy as well)
         return torch.zeros(B)
 
 

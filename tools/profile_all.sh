@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-2 profile collection on the GPU box (gpurun): kernel traces + separate --pmc passes (never combined with trace
+# domains other than --kernel-trace).  Raw rocpd databases land under gpurun_out/prof_r2/; the summaries are copied to
+# profiles/ by hand after inspection.
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/prof_r2
+rm -rf $O; mkdir -p $O
+R="rocprofv3 --kernel-trace"
+# 1. the bench command itself (kernel trace + stats)
+$R --stats -d $O/bench -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-table --no-fp32-mode > $O/bench.log 2>&1
+# 2. one denoiser forward: SQ / GRBM, FETCH, WRITE passes
+D="python tools/run_denoiser.py 48 256 1"
+$R --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d $O/den_sq -o p -- $D > $O/den_sq.log 2>&1
+$R --pmc FETCH_SIZE -d $O/den_fetch -o p -- $D > $O/den_fetch.log 2>&1
+$R --pmc WRITE_SIZE -d $O/den_write -o p -- $D > $O/den_write.log 2>&1
+# 3. the prox / update kernels of all four tasks at the BASELINE sizes
+T="python tools/bench_tasks.py"
+$R --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $O/task_sq -o p -- $T > $O/task_sq.log 2>&1
+$R --pmc FETCH_SIZE -d $O/task_fetch -o p -- $T > $O/task_fetch.log 2>&1
+$R --pmc WRITE_SIZE -d $O/task_write -o p -- $T > $O/task_write.log 2>&1
+find $O -name "*.db" | xargs ls -la
+tail -2 $O/bench.log | cut -c1-300

@@ -21,6 +21,9 @@ x = torch.rand(B, 1, H, H, generator=g).to(dev)
 s = torch.full((B,), 0.1, device=dev)
 ctx = den.context(dev)
 y = den(x, s)
+abl = [a for a in sys.argv[1:] if a.startswith("--abl=")]
+if abl:   # tuning builds: ablation bits take effect AFTER a real forward has filled the arena with real activations
+    os.environ["PNPX_HS_ABL"] = abl[0].split("=")[1]
 ops.unet_profile(ctx, x, s)
 acc = None
 R = 5
