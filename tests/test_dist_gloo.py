@@ -139,3 +139,56 @@ def test_sharded_env_episode_world2():
     assert done2 == [False, True, False, True, True]
     rew3, done3, _ = log[2]
     assert rew3[1] == 0.0 and rew3[0] > 0 and done3 == [True] * 5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bench.py --scaling strong: ONE global env batch of 48 (the reference's DataParallel scatter, tasks/csmri/main.py:79-80)
+# split contiguously over the ranks; per step every rank contributes the rewards of ITS items to one all_gather.
+def _strong_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from tfpnp_amd import dist as D
+    D.init_from_env(backend="gloo")
+    n_global, steps = 48, 6
+    lo, hi = D.shard_bounds(n_global, world, rank)
+    rs = np.random.RandomState(0)                        # every rank builds the same global batch, keeps its rows
+    gt = torch.from_numpy(rs.rand(n_global, 1, 4, 4).astype(np.float32))
+    x = torch.zeros_like(gt)[lo:hi]
+    log = []
+    for s in range(steps):
+        before = -((x - gt[lo:hi]) ** 2).reshape(hi - lo, -1).mean(1, keepdim=True)
+        x = x + 0.5 * (gt[lo:hi] - x)
+        after = -((x - gt[lo:hi]) ** 2).reshape(hi - lo, -1).mean(1, keepdim=True)
+        log.append(D.all_gather_rows(after - before, n_global).view(-1))
+    q.put((rank, (lo, hi), torch.stack(log).numpy()))
+    dist.destroy_process_group()
+
+
+def test_strong_split_of_one_env_batch_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (b, log) for r, b, log in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == (0, 24) and res[1][0] == (24, 48)            # 48 / 2 contiguous items per rank
+    assert np.array_equal(res[0][1], res[1][1])                      # both ranks hold the global reward table
+    # ... and it equals the single-process run of the whole batch
+    rs = np.random.RandomState(0)
+    gt = torch.from_numpy(rs.rand(48, 1, 4, 4).astype(np.float32))
+    x = torch.zeros_like(gt)
+    for s in range(6):
+        before = -((x - gt) ** 2).reshape(48, -1).mean(1)
+        x = x + 0.5 * (gt - x)
+        after = -((x - gt) ** 2).reshape(48, -1).mean(1)
+        assert np.allclose(res[0][1][s], (after - before).numpy(), rtol=1e-6, atol=1e-7)
+    from tfpnp_amd import dist as D
+    for g in (1, 2, 4, 8, 5):                                        # shard sizes of the strong split, incl. uneven
+        bounds = [D.shard_bounds(48, g, r) for r in range(g)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == 48 and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+        assert max(h - l for l, h in bounds) - min(h - l for l, h in bounds) <= 1

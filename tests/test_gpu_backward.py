@@ -155,6 +155,28 @@ def test_denoiser_vjp_is_linear_and_batch_independent(den):
     assert torch.equal(den(g(x), g(s)), ref)
 
 
+def solver_kink_margin(run):
+    """Smallest distance of any LeakyReLU / max-pool / clamp decision from its kink over a whole fp64 oracle solver run
+    (every denoiser call of every inner iteration)."""
+    from oracle import pnp_oracle as O
+    probe, keep_f, keep_d = _KinkProbe(), O.F, O.denoise
+    clamp_margin = [float("inf")]
+
+    def denoise_probe(x, sigma, params):
+        N, _, H, W = x.shape
+        pre = O.unet_forward(torch.cat([x, torch.ones(N, 1, H, W, dtype=x.dtype) * sigma.view(N, 1, 1, 1)], 1), params)
+        clamp_margin[0] = min(clamp_margin[0], float(pre.abs().min()), float((pre - 1).abs().min()))
+        return torch.clamp(pre, 0, 1)
+
+    O.F, O.denoise = probe, denoise_probe
+    try:
+        with torch.no_grad():
+            run()
+    finally:
+        O.F, O.denoise = keep_f, keep_d
+    return min(probe.margin, clamp_margin[0])
+
+
 def _check(names, got, want64, want32, floor=2e-2):   # floor: see test_denoiser_vjp_vs_oracle_autograd
     for n, a, b64, b32 in zip(names, got, want64, want32):
         e, y = rel(a, b64), rel(b32, b64)
@@ -166,36 +188,59 @@ def _check(names, got, want64, want32, floor=2e-2):   # floor: see test_denoiser
                                        ("pg", ("sigma_d", "tau")), ("apg", ("sigma_d", "tau", "beta")),
                                        ("redadmm", ("sigma_d", "mu", "lamda"))])
 def test_csmri_solver_gradients(den, oden32, oden64, name, keys):
-    """PnPEnv.forward under autograd (tfpnp/env/base.py:193-206): d loss / d (state, policy actions)."""
+    """PnPEnv.forward under autograd (tfpnp/env/base.py:193-206): d loss / d (state, policy actions).
+
+    The derivative of a T-iteration solve jumps whenever ANY LeakyReLU / pooling / clamp decision of ANY denoiser call
+    flips, and one flip in the 2x2 bottleneck of a 32x32 image moves these gradients by several per cent (measured on one
+    input: 1e-3 with the MFMA first convolution, 5e-2 with the exact-fp32 one, the CPU fp32 oracle itself 1e-3 from
+    fp64).  So (a) the tight comparison is made on seeded inputs whose whole fp64 trajectory keeps a safety margin from
+    every kink (found within a few tries at B=1, 16x16, T=2); (b) arbitrary inputs (B=2, 32x32, T=3) check the forward
+    values tightly and the gradients against a structural-error bound (a wrong VJP is O(1))."""
     from oracle import pnp_oracle as O
     from tfpnp_amd.tasks import csmri
-    B, H, W, T = 2, 32, 32, 3
-    d = synth.make_csmri_batch(B, H, W, seed=71)
-    a = csmri_actions(B, T, 72, keys)
-    if "beta" in a:
-        a["beta"] = (0.3 * a["beta"]).astype(np.float32)
     sol = {"admm": csmri.ADMMSolver_CSMRI, "hqs": csmri.HQSSolver_CSMRI, "pg": csmri.PGSolver_CSMRI,
            "apg": csmri.APGSolver_CSMRI, "redadmm": csmri.REDADMMSolver_CSMRI}[name](den)
-    v0 = sol.reset({"x0": g(d["x0"])}).cpu().numpy()
-    wts = np.random.RandomState(73).standard_normal(v0.shape).astype(np.float32)
     ofn = getattr(O, "csmri_" + name)
-    acts = [a[k] for k in keys]
 
-    def run_oracle(oden, dtype):
-        y0, m = t(d["y0"]).to(dtype), t(d["mask"])
-        return oracle_grads(lambda v, *p: ofn(oden, v, y0, m, *p), [v0] + acts, wts, dtype)
+    def case(B, H, W, T, k):
+        d = synth.make_csmri_batch(B, H, W, seed=71 + 100 * k)
+        a = csmri_actions(B, T, 72 + 100 * k, keys)
+        if "beta" in a:
+            a["beta"] = (0.3 * a["beta"]).astype(np.float32)
+        return d, [a[key] for key in keys], sol.reset({"x0": g(d["x0"])}).cpu().numpy()
 
-    out64, g64 = run_oracle(oden64, torch.float64)
-    _, g32 = run_oracle(oden32, torch.float32)
-    leaves = [g(v0, True)] + [g(p, True) for p in acts]
-    out = sol((leaves[0], (g(d["y0"]), g(d["mask"]))), tuple(leaves[1:]))
-    assert rel(out, out64) < 1e-4
-    # same values as the fused inference loop
-    with torch.no_grad():
-        fused = sol((g(v0), (g(d["y0"]), g(d["mask"]))), tuple(g(p) for p in acts))
-    assert rel(out, fused) < 1e-5
-    (out * g(wts)).sum().backward()
-    _check(["variables"] + list(keys), [l.grad for l in leaves], g64, g32)
+    def compare(d, acts, v0, floor):
+        wts = np.random.RandomState(73).standard_normal(v0.shape).astype(np.float32)
+
+        def run_oracle(oden, dtype):
+            y0, m = t(d["y0"]).to(dtype), t(d["mask"])
+            return oracle_grads(lambda v, *p: ofn(oden, v, y0, m, *p), [v0] + acts, wts, dtype)
+
+        out64, g64 = run_oracle(oden64, torch.float64)
+        _, g32 = run_oracle(oden32, torch.float32)
+        leaves = [g(v0, True)] + [g(p, True) for p in acts]
+        out = sol((leaves[0], (g(d["y0"]), g(d["mask"]))), tuple(leaves[1:]))
+        assert rel(out, out64) < 1e-4
+        with torch.no_grad():      # same values as the fused inference loop
+            fused = sol((g(v0), (g(d["y0"]), g(d["mask"]))), tuple(g(p) for p in acts))
+        assert rel(out, fused) < 1e-5
+        (out * g(wts)).sum().backward()
+        _check(["variables"] + list(keys), [l.grad for l in leaves], g64, g32, floor=floor)
+
+    # (a) kink-free, tight
+    for k in range(60):
+        d, acts, v0 = case(1, 16, 16, 2, k)
+        margin = solver_kink_margin(lambda: ofn(oden64, t(v0).double(), t(d["y0"]).double(), t(d["mask"]),
+                                               *[t(p).double() for p in acts]))
+        if margin > 1e-5:
+            break
+    else:
+        raise AssertionError("no kink-free CS-MRI case found")
+    print(f"  {name}: kink-free case at try {k} (margin {margin:.1e})")
+    compare(d, acts, v0, floor=1e-4)
+    # (b) arbitrary inputs
+    d, acts, v0 = case(2, 32, 32, 3, 0)
+    compare(d, acts, v0, floor=0.25)
 
 
 def test_pr_solver_gradients(den, oden32, oden64):

@@ -189,6 +189,10 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_fuse_outc = value;
     return PNPX_OK;
   }
+  if (is("fuse_first") && (value == 0 || value == 1)) {
+    ctx->opt_fuse_first = value;
+    return PNPX_OK;
+  }
   if (is("range_guard") && value >= 0 && value <= 2) {   // also re-arms a tripped guard
     PNPX_HIP(hipDeviceSynchronize());
     ctx->opt_range_guard = value;
@@ -211,6 +215,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("subbatch")) *value = ctx->opt_subbatch;
   else if (is("fuse_pool")) *value = ctx->opt_fuse_pool;
   else if (is("fuse_outc")) *value = ctx->opt_fuse_outc;
+  else if (is("fuse_first")) *value = ctx->opt_fuse_first;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
   else {
     set_error("pnpx_ctx_get_option: unknown option '%s'", key ? key : "(null)");
@@ -338,6 +343,9 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
     }
   }
   align();
+  const size_t oc0 = host.size();          // first convolution, native [32][2][3][3] layout
+  host.insert(host.end(), params_host, params_host + 32 * 2 * 9);
+  align();
   const size_t ozero = host.size();
   host.resize(host.size() + 768, 0.f);
   align();
@@ -368,6 +376,7 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
     ctx->conv_bwd[i].b = nullptr;
     ctx->conv_hs_bwd[i].w = reinterpret_cast<char*>(d + thoff[i]);
   }
+  ctx->conv0_w = d + oc0;
   ctx->zero_bias = d + ozero;
   ctx->outc_w = d + ow;
   ctx->outc_b = d + ob;

@@ -119,6 +119,7 @@ struct pnpx_ctx {
   int opt_subbatch = 24;           // images per level-0 sub-batch of the half-split forward (0 = whole batch)
   int opt_fuse_pool = 1;           // fused 2x2 max-pool epilogue
   int opt_fuse_outc = 1;           // fused 1x1 out-conv + residual + clamp epilogue
+  int opt_fuse_first = 1;          // VALU first convolution straight from the fp32 image (no padded-input tensor)
   int opt_range_guard = 1;         // 0 off, 1 sticky flag + latch to conv_mode 0, 2 strict (sync + transparent re-run)
   // --- half-split range guard: host-mapped word the conv_hs epilogues set when a stored value leaves the f16 range
   unsigned* range_flag_host = nullptr;   // pinned host allocation
@@ -127,6 +128,7 @@ struct pnpx_ctx {
   pnpx::ConvLayer conv_bwd[27];    // adjoint (input-gradient) convolutions, fp32 kernel family
   pnpx::ConvLayerHsDev conv_hs_bwd[27];  // ... and packed for the half-split kernel family
   float* zero_bias = nullptr;      // [768] zeros (bias operand of the adjoint convolutions)
+  float* conv0_w = nullptr;  // [32][2][9] fp32: the first convolution in its native layout (VALU kernel, unet.hip)
   float* outc_w = nullptr;   // [32]
   float* outc_b = nullptr;   // [1]
   pnpx::DeviceBuf weights;   // single allocation holding all of the above

@@ -580,6 +580,16 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
   }
   // persistent: one workgroup per CU (the LDS request makes a second one impossible), each walks ntiles/grid tiles
   long long grid = 256;
+  int lds_req = G::LDS_BYTES;
+#ifdef PNPX_TUNING   // co-residency experiments (tools/micro/coresident_check.py): PNPX_HS_PERCU=2 drops the LDS padding
+  if (const char* e = getenv("PNPX_HS_PERCU")) {
+    const int per_cu = atoi(e);
+    if (per_cu > 1 && per_cu * G::LDS_USED <= 160 * 1024) {
+      grid = 256LL * per_cu;
+      lds_req = G::LDS_USED;
+    }
+  }
+#endif
   if (grid > ntiles) grid = ntiles;
   if (grid >= 8) grid -= grid % 8;          // whole XCD groups (the kernel falls back to a plain walk otherwise)
   if (a.nct > 1 && (grid / 8) % a.nct != 0 && grid >= 8 * a.nct) grid -= grid % (8 * a.nct);
@@ -592,7 +602,7 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
     a.trace = tbuf;
   }
 #endif
-  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI>), dim3((unsigned)grid), dim3(NW * 64), G::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI>), dim3((unsigned)grid), dim3(NW * 64), lds_req, s, a);
   PNPX_LAUNCH_CHECK();
 #ifdef HS_TRACE
   if (tfile) {

@@ -111,6 +111,43 @@ __global__ __launch_bounds__(256) void prep_input_hs_kernel(const float* __restr
   dst[(b * 2 * (H + 2) + (y + 1)) * (W + 2) + xx + 1] = hs_pack(v);   // group 0 of 2; group 1 stays zero
 }
 
+// First convolution of the network, fused with the input preparation (denoiser/base.py:27-30 + inc.conv-0,
+// models/unet.py:8-18): out[c] = LeakyReLU(b[c] + sum_taps w[c][0][t] * x[t] + w[c][1][t] * sigma * [t inside the image]).
+// K is only 18, so padding it to the 16-channel chunks of the MFMA kernel wastes 8x the multiplies and a 100 MB
+// padded-input round trip; here each thread evaluates 8 output channels of one pixel as exact fp32 FMA chains straight
+// from the fp32 image (weights are wave-uniform: scalar loads) and stores one HS8 record.  HBM-write bound.
+__global__ __launch_bounds__(256) void conv_first_hs_kernel(const float* __restrict__ x, const float* __restrict__ sigma,
+                                                            int sigma_stride, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, HsRec* __restrict__ dst, int H,
+                                                            int W, float slope) {
+  const int g = blockIdx.y, b = blockIdx.z;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= H * W) return;
+  const int y = p / W, xx = p - y * W;
+  const float sg = sigma[(size_t)b * sigma_stride];
+  const float* xb = x + (size_t)b * H * W;
+  float xi[9], si[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xc = xx + t % 3 - 1;
+    const bool in = (yy >= 0) && (yy < H) && (xc >= 0) && (xc < W);
+    xi[t] = in ? xb[(size_t)yy * W + xc] : 0.f;
+    si[t] = in ? sg : 0.f;
+  }
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float* wc = w + (size_t)(g * 8 + c) * 18;
+    float acc = bias[g * 8 + c];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc = fmaf(wc[t], xi[t], acc);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc = fmaf(wc[9 + t], si[t], acc);
+    v[c] = fmaxf(acc, acc * slope) * HS_ASCALE;
+  }
+  dst[((size_t)(b * 4 + g) * (H + 2) + (y + 1)) * (W + 2) + xx + 1] = hs_pack(v);
+}
+
 __global__ __launch_bounds__(256) void maxpool2_hs_kernel(const HsRec* __restrict__ src, HsRec* __restrict__ dst,
                                                           size_t n_out, int H, int W) {
   const int Ho = H / 2, Wo = W / 2;
@@ -279,9 +316,12 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
   auto pool_fused = [&](int l) { return !no_pool_fuse && l < 4 && conv_hs_can_pool(P.x[l].H, P.x[l].W); };
 
   const size_t npix = (size_t)B * H * W;
-  hipLaunchKernelGGL(prep_input_hs_kernel, g1d(npix), dim3(256), 0, s, x, sigma, sigma_stride, rat(P.in0, 0), H, W, npix);
-  PNPX_LAUNCH_CHECK();
-  PNPX_TRY(rec.mark("prep_input", 0));
+  const bool first_fused = ctx->opt_fuse_first != 0;   // the VALU first convolution replaces prep_input + conv 0
+  if (!first_fused) {
+    hipLaunchKernelGGL(prep_input_hs_kernel, g1d(npix), dim3(256), 0, s, x, sigma, sigma_stride, rat(P.in0, 0), H, W, npix);
+    PNPX_LAUNCH_CHECK();
+    PNPX_TRY(rec.mark("prep_input", 0));
+  }
 
   auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o, int b0, int nb, const ConvHsFuse& fuse) -> int {
     const ConvLayer& L = ctx->conv[li];
@@ -304,6 +344,13 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
                    const ConvHsFuse& fuse) -> int {
     const Act& ta = i1 ? P.da[lvl] : P.a[lvl];   // decoder blocks (two sources) have their own temporaries
     const Act& tb = i1 ? P.db[lvl] : P.b[lvl];
+    if (li == 0 && first_fused) {
+      hipLaunchKernelGGL(conv_first_hs_kernel, dim3((H * W + 255) / 256, 4, nb), dim3(256), 0, s, x + (size_t)b0 * H * W,
+                         sigma + (size_t)b0 * sigma_stride, sigma_stride, ctx->conv0_w, ctx->conv[0].b, rat(ta, b0), H, W,
+                         0.2f);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(rec.mark("conv3x3", 2.0 * 9.0 * 2 * 32 * (double)H * W * nb));
+    } else
     PNPX_TRY(conv(li, i0, i1, ta, b0, nb, ConvHsFuse()));
     PNPX_TRY(conv(li + 1, ta, nullptr, tb, b0, nb, ConvHsFuse()));
     return conv(li + 2, tb, nullptr, o, b0, nb, fuse);

@@ -14,6 +14,7 @@ dbs = [a for a in args if a.endswith(".db")]
 jpath = args[args.index("--json") + 1] if "--json" in args else None
 geom = [int(v) for v in args[args.index("--geom") + 1:args.index("--geom") + 4]] if "--geom" in args else None
 x2 = re.compile(args[args.index("--fetch-x2") + 1] if "--fetch-x2" in args else r"conv_hs")
+cnt = re.compile(args[args.index("--count") + 1] if "--count" in args else r"conv_hs|conv_first")   # rows in the totals
 
 
 def short(n):
@@ -69,14 +70,14 @@ for i, r in enumerate(rows):
     b = (2 * f if dbl else f) + w
     print(f"| {i} | {r['name']} | {us:.1f} | {clk:.2f} | {mfma:.1f} | {lds:.1f} | {conf:.1f} | {act:.0f} | {wait:.0f} | "
           f"{f / 1e6:.0f} | {2 * f / 1e6:.0f}{'*' if dbl else ''} | {w / 1e6:.0f} | {b / (us * 1e-6) / 1e12 if us else 0:.2f} |")
-    if dbl:
+    if cnt.search(r["name"]):
         tot["us"] += us
         tot["bytes"] += b
         tot["n"] += 1
 print()
 print("`*` = doubled FETCH used (16-byte coalesced streams); HBM TB/s = (FETCH [x2 where starred] + WRITE) / duration.")
 if tot["n"]:
-    print(f"\n{tot['n']} starred launches: {tot['us'] / 1e3:.3f} ms, {tot['bytes'] / 1e9:.2f} GB "
+    print(f"\n{tot['n']} convolution launches ({cnt.pattern}): {tot['us'] / 1e3:.3f} ms, {tot['bytes'] / 1e9:.2f} GB "
           f"=> {tot['bytes'] / tot['n'] / 1e6:.0f} MB per launch, {tot['bytes'] / (tot['us'] * 1e-6) / 1e12:.2f} TB/s.")
     if jpath and geom:
         json.dump({"B": geom[0], "H": geom[1], "W": geom[2], "conv_launches": tot["n"],

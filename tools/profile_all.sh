@@ -19,5 +19,14 @@ T="python tools/bench_tasks.py"
 $R --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $O/task_sq -o p -- $T > $O/task_sq.log 2>&1
 $R --pmc FETCH_SIZE -d $O/task_fetch -o p -- $T > $O/task_fetch.log 2>&1
 $R --pmc WRITE_SIZE -d $O/task_write -o p -- $T > $O/task_write.log 2>&1
-find $O -name "*.db" | xargs ls -la
+# summaries (the raw databases exceed the 64 MiB that travel back)
+python tools/rocpd_stats.py $O/bench/bench_results.db > $O/r2_bench_kernel_stats.md
+grep '^{' $O/bench.log | tail -1 > $O/r2_bench_profiled.json
+python tools/pmc_report.py $O/den_sq/p_results.db $O/den_fetch/p_results.db $O/den_write/p_results.db --json $O/r2_pmc_traffic.json --geom 48 256 256 > $O/r2_denoiser_pmc_hs.md
+python tools/pmc_report.py $O/task_sq/p_results.db $O/task_fetch/p_results.db $O/task_write/p_results.db --fetch-x2 'conv_hs' > $O/r2_tasks_pmc_all.md
+python tools/pmc_tasks_summary.py $O/r2_tasks_pmc_all.md "conv_hs|conv3x3|conv_first|upsample2x|prep_input|maxpool|outc_" > $O/r2_tasks_pmc.md
+rm -f $O/r2_tasks_pmc_all.md
+cp $O/task_sq.log $O/r2_tasks_times.txt
+find $O -name "*.db" -delete
+ls -la $O
 tail -2 $O/bench.log | cut -c1-300
