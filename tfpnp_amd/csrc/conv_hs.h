@@ -53,7 +53,7 @@ struct ConvHsArgs {
   float neg_one;           // -1.0f (kept in a scalar register: selects the fused f16 fma-mix forms in the hi/lo split)
   unsigned* range_flag;    // sticky half-split range guard (host-mapped word) or null
   unsigned long long* trace;   // HS_TRACE builds: s_memtime stamps of workgroup 0 / wave 0 (null otherwise)
-  int abl;                     // PNPX_TUNING builds: ablation bits (1 = drop the record stores, 2 = skip the epilogue)
+  int abl;                     // PNPX_TUNING builds: ablation bits (1 = drop the record stores, 2 = skip the epilogue, 4 / 8 = planar-layout addressing of loads / stores)
   int w_mt;                    // cout tile the weights were PACKED for (64 while a 32-cout instance runs: "half tiles")
 };
 

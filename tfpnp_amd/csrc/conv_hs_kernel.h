@@ -133,6 +133,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
     const int hy = r / G::LW;
     const int hx = r - hy * G::LW;
     ioff[k] = (idx < G::IN_LOADS) ? (((q >> 1) * HpWp + hy * a.Wp + hx) * 32 + (q & 1) * 16) : 0;
+#ifdef PNPX_TUNING   // ablation 4 (invalid results): address the halo as if hi / lo were separate dense planes
+    if ((a.abl & 4) && idx < G::IN_LOADS) ioff[k] = (q * HpWp + hy * a.Wp + hx) * 16;
+#endif
   }
 
   struct Tile {
@@ -158,6 +161,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
     const int g0 = chunk * 2;
     const char* src = (g0 < a.G0) ? a.in0 + ((size_t)T.b * a.G0 + g0) * HpWp * 32
                                   : a.in1 + ((size_t)T.b * a.G1 + (g0 - a.G0)) * HpWp * 32;
+#ifdef PNPX_TUNING
+    if (a.abl & 4) return src + ((size_t)T.y0 * a.Wp + T.x0) * 16;
+#endif
     return src + ((size_t)T.y0 * a.Wp + T.x0) * 32;
   };
   // Weight slices are packed [cout / w_mt][chunk][tap][hi,lo][kg][w_mt] x 16 B.  A 32-cout instance may run over a
@@ -313,6 +319,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(rec[i]));
         asm volatile("" ::"v"(off));
+        continue;
+      }
+#endif
+#ifdef PNPX_TUNING   // ablation 8 (invalid results): store hi / lo as two dense planes
+      if (a.abl & 8) {
+        const int poff = ok ? ((g_first + 2 * qp + kg) * 2 * group_stride_rec + pix_rec) * 16 : (int)0x80000000;
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){rec[0], rec[1], rec[2], rec[3]}, rsrc, poff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){rec[4], rec[5], rec[6], rec[7]}, rsrc, poff, group_stride_rec * 16, 0);
         continue;
       }
 #endif
