@@ -19,8 +19,9 @@
 // [2 groups][hi,lo][TH+2][TW+2] x 16 B and the weight slice [9][hi,lo][2][MT] x 16 B go global->LDS by 16-byte
 // LDS-DMA; two stages; the DMA issue of chunk c+1 is interleaved with the taps of chunk c.  Operand fragments
 // are single conflict-free ds_read_b128 (pixel / cout stride 16 B), tap shifts are immediates.
-// Epilogue: bias + LeakyReLU in fp32, re-split to hi/lo, v_permlane32_swap pairs the two half-waves' 4-channel
-// pieces into whole 8-channel records, one coalesced 32-byte record store per lane and group pair.
+// Epilogue: bias + LeakyReLU in fp32, re-split to hi/lo; the weight rows of each 32-cout block are packed in the order
+// that leaves 16 consecutive channels in every lane (hs_row_channel), so a lane owns two whole 8-channel records and
+// stores them with two 16-byte buffer stores each -- no cross-lane traffic.
 #include <cstdlib>
 #include <cstring>
 
@@ -163,7 +164,16 @@ static inline uint16_t f16_bits(_Float16 h) {
 
 int conv_hs_mt(int cout) { return cout >= 64 ? 64 : 32; }
 
-// w[cout][cin][3][3] fp32 -> [cout/mt][cin_pad/16][tap][hi,lo][kg][mt][8] f16, scaled by a power of two.
+// MFMA C layout (32x32): lane half kg, register r holds row (r&3) + 8*(r>>2) + 4*kg.  Weight row i of every 32-cout block
+// is given channel 16*kg + r of the block, so that a lane's 16 registers are 16 consecutive channels = two whole HS8
+// records (conv_hs_kernel.h::store_records) and the epilogue needs no cross-lane traffic.
+static inline int hs_row_channel(int row) {
+  const int kg = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);
+  return 16 * kg + r;
+}
+
+// w[cout][cin][3][3] fp32 -> [cout/mt][cin_pad/16][tap][hi,lo][kg][mt][8] f16 (rows permuted per 32-block, above),
+// scaled by a power of two.
 // Returns the scale s (weights are stored as split(s*w)).
 float pack_conv_weights_hs(const float* w, int cout, int cin, int mt, uint16_t* dst) {
   const int cin_pad = (cin + 15) / 16 * 16;
@@ -182,7 +192,7 @@ float pack_conv_weights_hs(const float* w, int cout, int cin, int mt, uint16_t* 
         for (int kgi = 0; kgi < 2; ++kgi)
           for (int m = 0; m < mt; ++m)
             for (int el = 0; el < 8; ++el) {
-              const int co = ct * mt + m, ci = ch * 16 + kgi * 8 + el;
+              const int co = ct * mt + (m & ~31) + hs_row_channel(m & 31), ci = ch * 16 + kgi * 8 + el;
               const float v = (ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] * s : 0.f;
               const _Float16 hi = (_Float16)v;
               const _Float16 lo = (_Float16)(v - (float)hi);

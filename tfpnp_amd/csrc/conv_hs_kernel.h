@@ -70,13 +70,11 @@ struct HsGeom {
 };
 
 // lo halves of a hi/lo pair: f16(v0 - hi.lo16) | f16(v1 - hi.hi16) << 16, straight from the packed hi register
-// (v - hi is exact in fp32, so this is the single rounding of the reference split).  The trailing s_nop covers the
-// VALU-write -> v_permlane32_swap read hazard, which the compiler cannot see through an asm statement.
+// (v - hi is exact in fp32, so this is the single rounding of the reference split).
 __device__ __forceinline__ unsigned hs_lo_pair(unsigned hi_pk, float neg_one, float v0, float v1) {
   unsigned lo_pk;
   asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-      "s_nop 1"
+      "v_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
       : "=&v"(lo_pk)
       : "v"(hi_pk), "s"(neg_one), "v"(v0), "v"(v1));
   return lo_pk;
@@ -284,36 +282,26 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
   const float c16 = a.inv_scale * HS_ASCALE;   // accumulator -> HS_ASCALE * value (a power of two)
   const float neg_one = a.neg_one;             // -1.0f in a scalar register
   h2 range_chk = {(_Float16)0.f, (_Float16)0.f};
-  // pack 16 activated values (rows of one 32x32 accumulator, already scaled by HS_ASCALE) into 32-byte HS8 records:
-  // after the permlane swaps lanes 0-31 hold all 8 channels of the even group of each pair, lanes 32-63 of the odd.
+  // pack 16 activated values (rows of one 32x32 accumulator, already scaled by HS_ASCALE) into 32-byte HS8 records.
+  // The weight rows of every 32-cout block are packed in the order that makes the MFMA's C layout put channels
+  // 16*kg .. 16*kg+15 of the block into lane half kg (hs_row_channel): register r IS channel 16*kg + r, so a lane holds
+  // two complete 8-channel records (groups 2*kg and 2*kg + 1) and nothing has to move between lanes.
   // `rsrc` is a buffer descriptor of one image's tensor slice; masked lanes pass an out-of-range offset (the store is
   // dropped by the bounds check), so every wave issues exactly the same number of stores (see the counted vmcnt).
   auto store_records = [&](const float (&v)[16], __amdgpu_buffer_rsrc_t rsrc, int pix_rec, int g_first,
                            int group_stride_rec, bool ok) {
-    unsigned hp[4][2], lp[4][2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float v0 = v[q * 4 + e * 2], v1 = v[q * 4 + e * 2 + 1];
-        const h2 hh = {(_Float16)v0, (_Float16)v1};
-        range_chk = hh * (h2){(_Float16)0.f, (_Float16)0.f} + range_chk;   // inf * 0 = NaN: sticky per lane
-        hp[q][e] = __builtin_bit_cast(unsigned, hh);
-        lp[q][e] = hs_lo_pair(hp[q][e], neg_one, v0, v1);
-      }
 #pragma unroll
     for (int qp = 0; qp < 2; ++qp) {
-      unsigned rec[8];  // hi[0..3] dwords, lo[0..3] dwords of one record
+      unsigned rec[8];  // hi[0..3] dwords, lo[0..3] dwords of one record (channels 8*qp .. 8*qp+7 of this lane)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        auto sh = __builtin_amdgcn_permlane32_swap(hp[2 * qp][e], hp[2 * qp + 1][e], false, false);
-        auto sl = __builtin_amdgcn_permlane32_swap(lp[2 * qp][e], lp[2 * qp + 1][e], false, false);
-        rec[e] = sh[0];
-        rec[2 + e] = sh[1];
-        rec[4 + e] = sl[0];
-        rec[6 + e] = sl[1];
+      for (int e = 0; e < 4; ++e) {
+        const float v0 = v[qp * 8 + e * 2], v1 = v[qp * 8 + e * 2 + 1];
+        const h2 hh = {(_Float16)v0, (_Float16)v1};
+        range_chk = hh * (h2){(_Float16)0.f, (_Float16)0.f} + range_chk;   // inf * 0 = NaN: sticky per lane
+        rec[e] = __builtin_bit_cast(unsigned, hh);
+        rec[4 + e] = hs_lo_pair(rec[e], neg_one, v0, v1);
       }
-      const int off = ok ? ((g_first + 2 * qp + kg) * group_stride_rec + pix_rec) * 32 : (int)0x80000000;
+      const int off = ok ? ((g_first + 2 * kg + qp) * group_stride_rec + pix_rec) * 32 : (int)0x80000000;
 #ifdef PNPX_TUNING   // ablation (invalid results): conversion work kept alive, stores dropped
       if (a.abl & 1) {
 #pragma unroll
@@ -321,10 +309,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
         asm volatile("" ::"v"(off));
         continue;
       }
-#endif
-#ifdef PNPX_TUNING   // ablation 8 (invalid results): store hi / lo as two dense planes
-      if (a.abl & 8) {
-        const int poff = ok ? ((g_first + 2 * qp + kg) * 2 * group_stride_rec + pix_rec) * 16 : (int)0x80000000;
+      if (a.abl & 8) {   // ablation 8 (invalid results): store hi / lo as two dense planes
+        const int poff = ok ? ((g_first + 2 * kg + qp) * 2 * group_stride_rec + pix_rec) * 16 : (int)0x80000000;
         __builtin_amdgcn_raw_buffer_store_b128((u32x4){rec[0], rec[1], rec[2], rec[3]}, rsrc, poff, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128((u32x4){rec[4], rec[5], rec[6], rec[7]}, rsrc, poff, group_stride_rec * 16, 0);
         continue;
@@ -350,10 +336,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
     for (int m = 0; m < G::MTB; ++m) {
       float bias[16];
       if constexpr (EPI != EPI_DMASK) {
-        const char* lb = lds + G::BIAS_OFF + (T.ct * MT + m * 32 + 4 * kg) * 4;
+        const char* lb = lds + G::BIAS_OFF + (T.ct * MT + m * 32 + 16 * kg) * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 bq = *reinterpret_cast<const f32x4*>(lb + 32 * q);
+          const f32x4 bq = *reinterpret_cast<const f32x4*>(lb + 16 * q);
 #pragma unroll
           for (int j = 0; j < 4; ++j) bias[q * 4 + j] = bq[j];
         }
@@ -361,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
       float v[NBW][16];
       if constexpr (EPI == EPI_DMASK) {
         // input-gradient convolution: the LeakyReLU derivative comes from the saved forward activation (same record
-        // position as the output record; this lane's 4 channels of group q are hi[4*kg .. 4*kg+3])
+        // position as the output record; this lane's channels 4*q .. 4*q+3 are hi[4*(q&1) ..] of group 2*kg + (q>>1))
 #pragma unroll
         for (int n = 0; n < NBW; ++n) {
           const int y = min(T.y0 + (wave * NBW + n) * G::MBH + py, a.H - 1), x = min(T.x0 + px, a.W - 1);
@@ -371,7 +357,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
             unsigned hh[4] = {0x3c00u, 0x3c00u, 0x3c00u, 0x3c00u};   // no mask: everything "positive" (linear epilogue)
             if (a.dmask) {
               const uint2 w = *reinterpret_cast<const uint2*>(
-                  a.dmask + (rec + (size_t)(T.ct * (MT / 8) + m * 4 + q) * HpWp) * 32 + 8 * kg);
+                  a.dmask + (rec + (size_t)(T.ct * (MT / 8) + m * 4 + 2 * kg + (q >> 1)) * HpWp) * 32 + 8 * (q & 1));
               hh[0] = w.x & 0xffffu;
               hh[1] = w.x >> 16;
               hh[2] = w.y & 0xffffu;
@@ -395,7 +381,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
           for (int q = 0; q < 4; ++q) {
             h4 rh = {0, 0, 0, 0}, rl = {0, 0, 0, 0};
             if (a.res) {
-              const char* rp = a.res + (rec + (size_t)(T.ct * (MT / 8) + m * 4 + q) * HpWp) * 32 + 8 * kg;
+              const char* rp = a.res + (rec + (size_t)(T.ct * (MT / 8) + m * 4 + 2 * kg + (q >> 1)) * HpWp) * 32 + 8 * (q & 1);
               rh = *reinterpret_cast<const h4*>(rp);
               rl = *reinterpret_cast<const h4*>(rp + 16);
             }
@@ -419,7 +405,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
         // out = clamp(x + outc(v) ...): accumulate this lane's 16 channels
         float w16[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) w16[r] = a.outc_w[(r & 3) + 8 * (r >> 2) + 4 * kg];
+        for (int r = 0; r < 16; ++r) w16[r] = a.outc_w[16 * kg + r];
 #pragma unroll
         for (int n = 0; n < NBW; ++n)
 #pragma unroll
