@@ -116,6 +116,7 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     torch.cuda.synchronize()
+    sampler = PowerSampler() if rank == 0 else None          # host thread reading the SMU telemetry, no GPU work
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rewards = episode()
@@ -123,6 +124,7 @@ def main():
     D.barrier()
     torch.cuda.synchronize()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    power = sampler.stop() if sampler else None
 
     iters = N_POLICY_STEPS * ACTION_PACK * args.steps
     value = (1 if strong else world) * iters / elapsed      # iterations over a 48-image batch per second, whole job
@@ -157,6 +159,11 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline(den, dev, B, H, W)
+        out["roofline"]["power"] = power
+        if power and power.get("gfx_clk_mhz_avg"):
+            # the same dense-f16 peak at the clock the power cap actually allowed during the timed region
+            peak_at_clk = PEAK_HS_TFLOPS * power["gfx_clk_mhz_avg"] / 2400.0
+            out["roofline"]["frac_of_peak_at_measured_clock"] = out["roofline"]["achieved"] / peak_at_clk
     if rank == 0 and world == 1 and not args.no_batch_table:
         out["batch_table"] = batch_table(solver, dev, H, W, args.ratio)
     if rank == 0 and world == 1 and not args.no_fp32_mode:
@@ -169,6 +176,47 @@ def main():
     if world > 1:
         D.barrier()          # rank 0 may still be in its (non-collective) roofline pass
         torch.distributed.destroy_process_group()
+
+
+class PowerSampler:
+    """Socket power and shader clock of GPU 0 of this process sampled every 50 ms on a host thread (amdsmi) while the
+    timed region runs: is the run at the package power cap, and at which clock?  Telemetry only; None if unavailable."""
+
+    def __init__(self, period=0.05):
+        import threading
+        self.rows, self.cap_w, self._stop = [], None, threading.Event()
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            h = amdsmi.amdsmi_get_processor_handles()[0]
+            self.cap_w = amdsmi.amdsmi_get_power_cap_info(h)["power_cap"] / 1e6
+        except Exception:
+            self.thread = None
+            return
+
+        def run():
+            while not self._stop.wait(period):
+                try:
+                    p = amdsmi.amdsmi_get_power_info(h)
+                    c = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                    self.rows.append((float(p["current_socket_power"]), float(c["clk"])))
+                except Exception:
+                    pass
+
+        self.thread = threading.Thread(target=run, daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        if self.thread is None:
+            return None
+        self._stop.set()
+        self.thread.join()
+        if not self.rows:
+            return None
+        n = len(self.rows)
+        return {"socket_w_avg": sum(r[0] for r in self.rows) / n, "socket_w_max": max(r[0] for r in self.rows),
+                "cap_w": self.cap_w, "gfx_clk_mhz_avg": sum(r[1] for r in self.rows) / n, "gfx_clk_mhz_max": 2400,
+                "samples": n, "source": "amdsmi current_socket_power / GFX clk, 50 ms period over the timed region"}
 
 
 def roofline(den, dev, B, H, W, reps=3):

@@ -58,6 +58,8 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *      2 (strict): every denoiser / solver entry synchronises its stream before returning and, if the flag was set,
  *         repeats itself in conv_mode 0 -- the caller always receives valid output, at the price of a sync per call.
  *      0: off.
+ *  "train_cache_gb" (default 96): device-memory budget of the training path's activation cache (see
+ *      pnpx_csmri_admm_train); 0 releases it and makes every backward re-compute.
  *  "subbatch" (images per level-0 sub-batch, 0 = whole batch), "fuse_pool", "fuse_outc" (0/1): diagnostics. */
 int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value);
 int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value);
@@ -167,6 +169,29 @@ int pnpx_policy_ob_pack(pnpx_ctx* ctx, int n_entries, const void* const* src_hos
 int pnpx_csmri_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                     const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
                     int H, int W, int T, void* stream);
+/* Training path of the same call: what autograd records and replays when the reference differentiates
+ * ADMMSolver_CSMRI.forward for policy training (PnPEnv.forward, tfpnp/env/base.py:193-206, called from
+ * trainer/mddpg/trainer.py:171-192).
+ * pnpx_csmri_admm_train = pnpx_csmri_admm (bit-identical vars_out) that also fills `saved`, 3*T*B*H*W floats: the
+ *   denoiser input of every iteration [T][B][H*W] followed by the k-space image before the blend [T][B][H*W][2].
+ * pnpx_csmri_admm_backward: given grad_vars_out [B,3,H,W,2] returns grad_vars_in [B,3,H,W,2] (may not alias),
+ *   grad_sigma_d [T][B] and grad_mu [T][B] (iteration-major, dense); `work` is 3*B*H*W floats of caller workspace.
+ *   The denoiser weights are constants (frozen, as in the reference); y0 / mask get no gradient.  Per iteration: one
+ *   masked-FFT adjoint (same three fused passes as the forward), one deterministic per-item reduction (d/d mu) and the
+ *   denoiser VJP (pnpx_unet_denoise_backward's kernels).
+ * Activation cache: within the "train_cache_gb" budget (pnpx_ctx_set_option, default 96 GiB; one 48 x 256^2 iteration
+ *   holds ~5 GiB -- the 288 GB of an MI355X are what make this affordable) the context keeps every denoiser
+ *   activation of the LAST training forward, and *ticket (host memory, written before the call returns) names that
+ *   content; a backward call that presents the same ticket skips the re-computation of the denoiser forwards
+ *   (8 instead of 14.5 ms per iteration at 48 x 256^2).  Any other ticket (0, or one overwritten by a later training
+ *   forward on this context) is answered by re-computation from `saved` -- same gradients, never stale ones. */
+int pnpx_csmri_admm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                          const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
+                          int H, int W, int T, float* saved, unsigned long long* ticket, void* stream);
+int pnpx_csmri_admm_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, const float* sigma_d,
+                             const float* mu, int param_stride, const float* saved, const float* grad_vars_out,
+                             float* grad_vars_in, float* grad_sigma_d, float* grad_mu, float* work, int B, int H,
+                             int W, int T, unsigned long long ticket, void* stream);
 /* HQSSolver_CSMRI.forward (tasks/csmri/solver.py:64-89).  vars [B,2,H,W,2] = cat(x,z). */
 int pnpx_csmri_hqs(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                    const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,

@@ -243,6 +243,93 @@ def test_csmri_solver_gradients(den, oden32, oden64, name, keys):
     compare(d, acts, v0, floor=0.25)
 
 
+def test_csmri_admm_fused_vjp_vs_composed_autograd(den):
+    """pnpx_csmri_admm_backward (one native call: masked-FFT adjoints, d/d mu reduction, denoiser VJPs) against the
+    same loop composed from differentiable building blocks (native denoiser VJP + unitary FFT ops + PyTorch pointwise
+    autograd, ADMMSolver_CSMRI._forward_autograd) -- both run the same denoiser kernels, so they agree to rounding
+    unless a kink decision flips on the 1e-7 difference of their forward values (bounded below); also the
+    iter_num < action_pack case: the unused hyper-parameter columns get exactly zero gradient, and determinism."""
+    from tfpnp_amd.tasks import csmri
+    sol = csmri.ADMMSolver_CSMRI(den)
+    B, H, W, T = 3, 64, 48, 4
+    d = synth.make_csmri_batch(B, H, W, seed=171)
+    a = csmri_actions(B, T + 1, 172, ("sigma_d", "mu"))
+    v0 = sol.reset({"x0": g(d["x0"])})
+    v0 = v0 + 0.05 * torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(3))
+    wts = torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(4))
+    y0, m = g(d["y0"]), g(d["mask"])
+
+    def grads(fn):
+        leaves = [v0.clone().requires_grad_(True), g(a["sigma_d"], True), g(a["mu"], True)]
+        out = fn(*leaves)
+        (out * wts).sum().backward()
+        return out.detach(), [l.grad for l in leaves]
+
+    out_f, gf = grads(lambda v, s_, mu: sol((v, (y0, m)), (s_, mu), iter_num=T))
+    out_c, gc = grads(lambda v, s_, mu: sol._forward_autograd(v, y0, m, s_, mu, T))
+    with torch.no_grad():     # training forward == inference forward up to the un-fused network tail's summation order
+        assert rel(out_f, sol((v0, (y0, m)), (g(a["sigma_d"]), g(a["mu"])), iter_num=T)) < 1e-6
+    assert rel(out_f, out_c) < 1e-5
+    for n, x, y in zip(("variables", "sigma_d", "mu"), gf, gc):
+        print(f"  fused vs composed d/d{n}: {rel(x, y):.2e}")
+        assert rel(x, y) < 2e-2, n
+        assert x.shape == y.shape
+    assert float(gf[0][:, 0].abs().max()) == 0.0             # x of the incoming state is never read by an iteration
+    assert float(gf[1][:, T:].abs().max()) == 0.0 and float(gf[2][:, T:].abs().max()) == 0.0
+    assert float(gf[1][:, :T].abs().min()) > 0 and float(gf[2][:, :T].abs().min()) > 0
+    _, gf2 = grads(lambda v, s_, mu: sol((v, (y0, m)), (s_, mu), iter_num=T))
+    assert all(torch.equal(x, y) for x, y in zip(gf, gf2))   # deterministic reductions
+
+
+def test_csmri_admm_activation_cache(den):
+    """The training path keeps the denoiser activations of the last training forward (pnpx_csmri_admm_train's ticket):
+    (a) gradients with the cache == gradients by re-computation (bit for bit for the same forward: same kernels);
+    (b) a backward whose forward has been overwritten by a later training forward falls back to re-computation -- it
+        must never read the newer activations; (c) the memory is accounted for and released by train_cache_gb = 0."""
+    from tfpnp_amd.tasks import csmri
+    sol = csmri.ADMMSolver_CSMRI(den)
+    ctx = den.context(dev())
+    B, H, W, T = 2, 48, 32, 3
+    y0s, ms, v0s, acts = [], [], [], []
+    for k in range(2):
+        d = synth.make_csmri_batch(B, H, W, seed=181 + k)
+        a = csmri_actions(B, T, 182 + k, ("sigma_d", "mu"))
+        y0s.append(g(d["y0"])); ms.append(g(d["mask"])); v0s.append(sol.reset({"x0": g(d["x0"])}))
+        acts.append((a["sigma_d"], a["mu"]))
+    wts = torch.randn(v0s[0].shape, device=dev(), generator=torch.Generator(dev()).manual_seed(5))
+
+    def forward(k):
+        leaves = [v0s[k].clone().requires_grad_(True), g(acts[k][0], True), g(acts[k][1], True)]
+        return leaves, sol((leaves[0], (y0s[k], ms[k])), tuple(leaves[1:]))
+
+    def backward(leaves, out):
+        (out * wts).sum().backward()
+        return [l.grad.clone() for l in leaves]
+
+    ctx.set_option("train_cache_gb", 0)                             # also drops what earlier tests left in the cache
+    ref = [backward(*forward(k)) for k in range(2)]                 # re-computation only
+    base = ctx.bytes()
+    ctx.set_option("train_cache_gb", 96)
+    try:
+        l0, o0 = forward(0)
+        held = ctx.bytes()
+        assert held > base + T * B * H * W * 4 * 32                 # T arenas are resident now
+        cached0 = backward(l0, o0)                                  # (a) served from the cache
+        # (the un-cached forward runs the fused network tail: forward values differ in the last bit, gradients follow)
+        assert all(rel(x, y) < 2e-2 for x, y in zip(cached0, ref[0]))
+        l0, o0 = forward(0)
+        l1, o1 = forward(1)                                         # overwrites the cache of the first forward
+        cached1 = backward(l1, o1)
+        stale0 = backward(l0, o0)                                   # (b) stale ticket -> re-computation, not wrong data:
+        assert all(torch.equal(x, y) for x, y in zip(stale0, cached0))   # same kernels on the same inputs, bit for bit
+        assert all(rel(x, y) < 2e-2 for x, y in zip(cached1, ref[1]))
+        assert rel(cached1[0], cached0[0]) > 0.1                    # (the two cases do have different gradients)
+        ctx.set_option("train_cache_gb", 0)                         # (c)
+        assert ctx.bytes() < held
+    finally:
+        ctx.set_option("train_cache_gb", 96)
+
+
 def test_pr_solver_gradients(den, oden32, oden64):
     from oracle import pnp_oracle as O
     from tfpnp_amd.tasks import pr

@@ -57,6 +57,9 @@ def test_opcheck_denoiser_and_solver(unet_params):
     a = synth.make_actions(2)[0]
     v0 = torch.cat([g(d["x0"]), g(d["x0"]), torch.zeros_like(g(d["x0"]))], 1)
     torch.library.opcheck(torch.ops.pnpx.csmri_admm, (v0, g(d["y0"]), g(d["mask"]), g(a["sigma_d"]), g(a["mu"]), -1, cid))
+    # the differentiable solver op: schema, fake tensors, and its registered (native) VJP under eager and AOT autograd
+    lv, ls, lm = (t_.clone().requires_grad_(True) for t_ in (v0, g(a["sigma_d"]), g(a["mu"])))
+    torch.library.opcheck(torch.ops.pnpx.csmri_admm_train, (lv, g(d["y0"]), g(d["mask"]), ls, lm, 3, cid))
 
 
 def test_fake_tensor_propagation_and_eager_compile(unet_params):

@@ -84,6 +84,19 @@ using namespace pnpx;
   std::lock_guard<std::mutex> _lk((ctx)->mu); \
   PNPX_HIP(hipSetDevice((ctx)->device))
 
+namespace pnpx {
+void train_cache_free(pnpx_ctx* ctx) {
+  (void)hipDeviceSynchronize();
+  for (auto& a : ctx->train_arena)
+    if (a.buf.p) (void)hipFree(a.buf.p);
+  for (auto& b : ctx->train_pre)
+    if (b.p) (void)hipFree(b.p);
+  ctx->train_arena.clear();
+  ctx->train_pre.clear();
+  ctx->train_ticket = 0;
+}
+}  // namespace pnpx
+
 extern "C" {
 
 const char* pnpx_version(void) { return "pnpx 0.1 (gfx950)"; }
@@ -132,6 +145,7 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx) {
   for (pnpx::UNetArena* a : {&ctx->arena, &ctx->arena_grad})
     if (a->buf.p) (void)hipFree(a->buf.p);
   policy_free(ctx);
+  pnpx::train_cache_free(ctx);
   if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
   for (auto& t : ctx->twiddle)
     if (t.second) (void)hipFree(t.second);
@@ -200,6 +214,11 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     *ctx->range_flag_host = 0;
     return PNPX_OK;
   }
+  if (is("train_cache_gb") && value >= 0) {   // shrinking to 0 also releases what is held
+    ctx->opt_train_cache_gb = value;
+    if (value == 0) pnpx::train_cache_free(ctx);
+    return PNPX_OK;
+  }
   set_error("pnpx_ctx_set_option: unknown option '%s' or bad value %d", key ? key : "(null)", value);
   return PNPX_ERR_ARG;
 }
@@ -217,6 +236,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fuse_outc")) *value = ctx->opt_fuse_outc;
   else if (is("fuse_first")) *value = ctx->opt_fuse_first;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
+  else if (is("train_cache_gb")) *value = ctx->opt_train_cache_gb;
   else {
     set_error("pnpx_ctx_get_option: unknown option '%s'", key ? key : "(null)");
     return PNPX_ERR_ARG;
@@ -237,9 +257,11 @@ int pnpx_ctx_status(pnpx_ctx* ctx) {
 }
 
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
-  return ctx ? ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_grad.buf.bytes +
-                   ctx->scratch.bytes
-             : 0;
+  if (!ctx) return 0;
+  size_t n = ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_grad.buf.bytes + ctx->scratch.bytes;
+  for (const auto& a : ctx->train_arena) n += a.buf.bytes;
+  for (const auto& b : ctx->train_pre) n += b.bytes;
+  return n;
 }
 
 size_t pnpx_unet_num_params(void) {
@@ -383,6 +405,7 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
   ctx->weights.p = p;
   ctx->weights.bytes = host.size() * sizeof(float);
   ctx->has_weights = true;
+  ctx->train_ticket = 0;      // activations cached by a training forward belong to the previous weights
   return PNPX_OK;
 }
 

@@ -121,6 +121,8 @@ struct pnpx_ctx {
   int opt_fuse_outc = 1;           // fused 1x1 out-conv + residual + clamp epilogue
   int opt_fuse_first = 1;          // VALU first convolution straight from the fp32 image (no padded-input tensor)
   int opt_range_guard = 1;         // 0 off, 1 sticky flag + latch to conv_mode 0, 2 strict (sync + transparent re-run)
+  int opt_train_cache_gb = 96;     // training path: keep the activations of up to this many GiB of denoiser forwards for
+                                   // the backward pass instead of re-computing them (0 = always re-compute)
   // --- half-split range guard: host-mapped word the conv_hs epilogues set when a stored value leaves the f16 range
   unsigned* range_flag_host = nullptr;   // pinned host allocation
   unsigned* range_flag_dev = nullptr;    // its device address
@@ -136,6 +138,12 @@ struct pnpx_ctx {
   //     arena = forward pass in the ctx's conv_mode (also the re-computation inside the backward pass);
   //     arena_grad = gradients of every activation (fp32 planar)
   pnpx::UNetArena arena, arena_grad;
+  // training path (pnpx_csmri_admm_train / _backward): one activation arena + pre-clamp output per inner iteration of
+  // the LAST training forward, identified by train_ticket (0 = nothing cached)
+  std::vector<pnpx::UNetArena> train_arena;
+  std::vector<pnpx::DeviceBuf> train_pre;
+  unsigned long long train_ticket = 0, train_counter = 0;
+  int train_B = 0, train_H = 0, train_W = 0, train_T = 0, train_mode = -1;
   // --- policy actor
   pnpx::PolicyNet policy;
   // --- solver scratch (complex fields etc.), grown on demand
@@ -184,8 +192,13 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
                  int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena = nullptr, int mode = -1,
                  bool keep_all = false);   // keep_all: store every activation (no fused network tail) -- backward pass
 // VJP of the denoiser wrt x and sigma (unet_bwd.hip): recomputes the forward pass in fp32 and back-propagates.
+// cached != NULL: the activations (a keep_all forward of exactly this input in `cached`) and its pre-clamp output are
+// reused instead of re-computed.
 int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out,
-                          float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s);
+                          float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s,
+                          UNetArena* cached = nullptr, const float* cached_pre = nullptr);
+size_t unet_arena_bytes(int mode, int B, int H, int W);
+void train_cache_free(pnpx_ctx* ctx);
 
 // Policy actor (policy.hip)
 size_t policy_num_params(int num_inputs, int n_det, int spi_head);

@@ -63,6 +63,14 @@ struct LoadSlotPlusSlot {  // x + u, both complex
   }
 };
 
+struct LoadSlotMinusSlot {  // a - c, both complex (backward: cotangent of z' = gz' - gu')
+  CSlot a, c;
+  __device__ float2 operator()(int b, int y, int x) const {
+    const float2 p = a.at(b, y, x), q = c.at(b, y, x);
+    return make_float2(p.x - q.x, p.y - q.y);
+  }
+};
+
 // ------------------------------------------------------------------ k-space functors (column pass)
 struct KSpace {
   const float2* y0;      // [B,1,H,W,2]
@@ -79,6 +87,35 @@ struct MidBlend {  // k[mask] = ((mu*k) + y0)[mask] / (1 + mu)      tasks/csmri/
     const float2 y = k.y0[o];
     const float den = addr(1.f, mu);
     return make_float2(divr(addr(mulr(mu, v.x), y.x), den), divr(addr(mulr(mu, v.y), y.y), den));
+  }
+};
+struct MidBlendSave {  // MidBlend that also keeps the k-space image BEFORE the blend (training path: d blend / d mu needs it)
+  KSpace k;
+  float2* save;          // [B,H,W] complex
+  __device__ float2 operator()(int b, int ky, int kx, float2 v) const {
+    save[(size_t)b * k.HW + (size_t)ky * k.W + kx] = v;
+    return MidBlend{k}(b, ky, kx, v);
+  }
+};
+// Adjoint of MidBlend.  With k' = mask ? (mu k + y0) / (1 + mu) : k, a cotangent g' of k' gives
+//   g = mask ? mu / (1 + mu) * g' : g'          and        d<g', k'>/d mu = <g', k - y0> / (1 + mu)^2 on the mask;
+// the per-pixel terms of the latter go to `contrib` and are summed per item afterwards (item_sum_kernel).
+struct MidBlendAdjoint {
+  KSpace k;
+  const float2* ksaved;  // k of the forward iteration
+  float* contrib;        // [B,H,W]
+  __device__ float2 operator()(int b, int ky, int kx, float2 g) const {
+    const size_t o = (size_t)b * k.HW + (size_t)ky * k.W + kx;
+    if (!k.mask[o]) {
+      contrib[o] = 0.f;
+      return g;
+    }
+    const float mu = k.par[(size_t)b * k.stride];
+    const float den = 1.f + mu;
+    const float2 y = k.y0[o], kv = ksaved[o];
+    contrib[o] = (g.x * (kv.x - y.x) + g.y * (kv.y - y.y)) / (den * den);
+    const float f = mu / den;
+    return make_float2(f * g.x, f * g.y);
   }
 };
 struct MidResidual {  // temp = k - y0; temp[~mask] = 0               tasks/csmri/solver.py:109-110
@@ -105,6 +142,18 @@ struct StoreAdmm {  // z = ifft2c(k); u = u + x - z; emits Re(z - u_new) (+ x as
     uo.at(b, y, x) = un;
     d.at(b, y, x) = subr(zv.x, un.x);
     if (write_x) xo.at(b, y, x) = make_float2(xv, 0.f);
+  }
+};
+// Backward of one ADMM iteration after the data step's adjoint: gs = cotangent of (x + u).
+//   cotangent of the denoiser output xr = Re(gx' + gu' + gs);   running cotangent of u = gu' + gs
+struct StoreAdmmAdjoint {
+  Slot gu;
+  CSlot gx;
+  RealImg gxr;
+  __device__ void operator()(int b, int y, int x, float2 gs) const {
+    const float2 a = gu.at(b, y, x);
+    gxr.at(b, y, x) = gx.at(b, y, x).x + a.x + gs.x;
+    gu.at(b, y, x) = make_float2(a.x + gs.x, a.y + gs.y);
   }
 };
 struct StoreAdmmCx {  // same with a complex x held in a slot (RED-ADMM); no denoiser input emitted
@@ -190,6 +239,33 @@ __global__ void red_update_kernel(const float* __restrict__ xh, const float2* __
                                       divr(addr(mulr(l, 0.f), mulr(m, subr(zv.y, uv.y))), den));
 }
 
+// backward of d = Re(z - u): gz = r2c(gd), gu -= r2c(gd); x of the previous state is not read by an iteration: gx = 0
+__global__ void admm_adjoint_finish_kernel(const float* __restrict__ gd, float2* g, size_t istride, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  float2* gi = g + b * istride + r;
+  const float v = gd[i];
+  const float2 gu = gi[2 * (size_t)HW];
+  gi[0] = make_float2(0.f, 0.f);
+  gi[HW] = make_float2(v, 0.f);
+  gi[2 * (size_t)HW] = make_float2(gu.x - v, gu.y);
+}
+// out[b] = sum of the HW values of item b, fixed summation order (deterministic)
+__global__ void __launch_bounds__(256) item_sum_kernel(const float* __restrict__ c, float* __restrict__ out, int HW) {
+  __shared__ float sh[256];
+  const float* p = c + (size_t)blockIdx.x * HW;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) a += p[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
 struct Scratch {
   float* d;    // [B,1,H,W] denoiser input
   float* xr;   // [B,1,H,W] denoiser output
@@ -233,13 +309,44 @@ using namespace pnpx;
   std::lock_guard<std::mutex> _lk((ctx)->mu);          \
   PNPX_HIP(hipSetDevice((ctx)->device))
 
-extern "C" int pnpx_csmri_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
-                               const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
-                               int H, int W, int T, void* stream) {
-  LOCK_CTX(ctx);
-  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+// Activation cache of the training path: iteration i of a training forward runs its denoiser in train_arena[i] with
+// every activation kept, so the backward pass does not have to re-compute the forward (one arena is ~5 GiB at 48 x 256^2;
+// the budget is the "train_cache_gb" option).  Returns false when the budget does not cover T iterations.
+static bool train_cache_prepare(pnpx_ctx* ctx, int B, int H, int W, int T) {
+  ctx->train_ticket = 0;      // whatever was cached is about to be overwritten
+  const size_t per = unet_arena_bytes(ctx->conv_mode, B, H, W) + sizeof(float) * (size_t)B * H * W;
+  if (ctx->opt_train_cache_gb <= 0 || T <= 0 || per * (size_t)T > ((size_t)ctx->opt_train_cache_gb << 30)) return false;
+  if ((int)ctx->train_arena.size() < T) {
+    ctx->train_arena.resize(T);
+    ctx->train_pre.resize(T);
+  }
+  for (int i = 0; i < T; ++i) {
+    DeviceBuf& pb = ctx->train_pre[i];
+    const size_t need = sizeof(float) * (size_t)B * H * W;
+    if (pb.bytes >= need) continue;
+    (void)hipDeviceSynchronize();
+    if (pb.p) (void)hipFree(pb.p);
+    pb = DeviceBuf();
+    void* q = nullptr;
+    if (hipMalloc(&q, need) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    pb.p = q;
+    pb.bytes = need;
+  }
+  return true;
+}
+
+// ADMM forward; `saved` != NULL (training path) keeps, per iteration, the denoiser input d_i [T][B][HW] floats followed
+// by the k-space image before the blend k_i [T][B][HW] complex, and (budget permitting) the denoiser activations in the
+// context's training cache; *ticket_out identifies that cache content (0: nothing cached, the backward re-computes).
+static int admm_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const uint8_t* mask,
+                        const float* sigma_d, const float* mu, int param_stride, int B, int H, int W, int T,
+                        float* saved, hipStream_t s, unsigned long long* ticket_out = nullptr) {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ticket_out) *ticket_out = 0;
+  bool cache = saved && ticket_out && train_cache_prepare(ctx, B, H, W, T);
   const int HW = H * W;
   const size_t is = 3 * (size_t)HW;
   Scratch S;
@@ -260,14 +367,117 @@ extern "C" int pnpx_csmri_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_
   StoreC kst{S.k, H, W};
   LoadC kld{S.k, H, W};
   for (int i = 0; i < T; ++i) {
-    PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    if (saved)
+      PNPX_HIP(hipMemcpyAsync(saved + (size_t)i * B * HW, S.d, sizeof(float) * B * HW, hipMemcpyDeviceToDevice, s));
+    if (cache) {
+      const int st = unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, static_cast<float*>(ctx->train_pre[i].p), B,
+                                  H, W, s, nullptr, &ctx->train_arena[i], ctx->conv_mode, true);
+      if (st == PNPX_ERR_ALLOC) {   // out of memory for the cache: give it back and carry on without
+        train_cache_free(ctx);
+        cache = false;
+      } else if (st != PNPX_OK) {
+        return st;
+      }
+    }
+    if (!cache) PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
     CSlot ui{(i == 0 ? vin : vout) + 2 * HW, is, W, HW};
     PNPX_TRY((launch_rows<false>(P, LoadXrPlusU{xr, ui}, kst, s)));
     KSpace ks{reinterpret_cast<const float2*>(y0), mask, mu + i, param_stride, W, HW};
-    PNPX_TRY((launch_cols<false, true>(P, kld, MidBlend{ks}, kst, s)));
+    if (saved) {
+      float2* ksave = reinterpret_cast<float2*>(saved + (size_t)T * B * HW) + (size_t)i * B * HW;
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidBlendSave{ks, ksave}, kst, s)));
+    } else {
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidBlend{ks}, kst, s)));
+    }
     PNPX_TRY((launch_rows<true>(P, kld, StoreAdmm{zo, uo, xo, ui, xr, d, i == T - 1}, s)));
   }
+  if (cache) {
+    ctx->train_ticket = ++ctx->train_counter;
+    ctx->train_B = B;
+    ctx->train_H = H;
+    ctx->train_W = W;
+    ctx->train_T = T;
+    ctx->train_mode = ctx->conv_mode;
+    *ticket_out = ctx->train_ticket;
+  }
   return PNPX_OK;
+}
+
+extern "C" int pnpx_csmri_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                               const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
+                               int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return admm_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, mu, param_stride, B, H, W, T, nullptr, s);
+  });
+}
+
+extern "C" int pnpx_csmri_admm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                                     const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride,
+                                     int B, int H, int W, int T, float* saved, unsigned long long* ticket,
+                                     void* stream) {
+  LOCK_CTX(ctx);
+  if ((!saved && T > 0) || !ticket) {
+    pnpx::set_error("csmri_admm_train: saved / ticket is null");
+    return PNPX_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return admm_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, mu, param_stride, B, H, W, T, saved, s, ticket);
+  });
+}
+
+// Vector-Jacobian product of the T-iteration ADMM map wrt (variables, sigma_d, mu), iterations walked in reverse:
+//   forward i:   x = r2c(D(d_i, sigma_i)),  d_i = Re(z - u);   z' = F^-1 blend_mu_i(F(x + u));   u' = u + x - z'
+//   backward i:  gz~ = gz' - gu';  gs = F^-1 blend^T(F gz~)  [F unitary: adjoint = inverse];  g_mu_i = sum contrib
+//                gxr = Re(gx' + gu' + gs);  gu~ = gu' + gs;  (gd, g_sigma_i) = D^T(gxr);  gz = r2c(gd), gu = gu~ - r2c(gd), gx = 0
+extern "C" int pnpx_csmri_admm_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, const float* sigma_d,
+                                        const float* mu, int param_stride, const float* saved,
+                                        const float* grad_vars_out, float* grad_vars_in, float* grad_sigma_d,
+                                        float* grad_mu, float* work, int B, int H, int W, int T,
+                                        unsigned long long ticket, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    PNPX_TRY(check_common(grad_vars_out, grad_vars_in, y0, mask, sigma_d, B, H, W, T, param_stride));
+    if (T > 0 && (!saved || !grad_sigma_d || !grad_mu || !work || !mu)) {
+      set_error("csmri_admm_backward: null pointer");
+      return PNPX_ERR_ARG;
+    }
+    const int HW = H * W;
+    const size_t is = 3 * (size_t)HW, n = (size_t)B * HW;
+    PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+    if (T == 0) return PNPX_OK;
+    FftPlan2D P;
+    PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
+    float2* g = reinterpret_cast<float2*>(grad_vars_in);
+    float *gxr = work, *gd = work + n, *contrib = work + 2 * n;
+    const float* saved_d = saved;
+    const float2* saved_k = reinterpret_cast<const float2*>(saved + (size_t)T * n);
+    // the activations of the matching training forward, if this context still holds them
+    const bool cached = ticket != 0 && ticket == ctx->train_ticket && B == ctx->train_B && H == ctx->train_H &&
+                        W == ctx->train_W && T == ctx->train_T;
+    for (int i = T - 1; i >= 0; --i) {
+      Scratch S;   // the k-space transit buffer lives in the context scratch, which the denoiser VJP may re-allocate
+      PNPX_TRY(get_scratch(ctx, B, H, W, &S));
+      StoreC kst{S.k, H, W};
+      LoadC kld{S.k, H, W};
+      CSlot gx{g, is, W, HW}, gz{g + HW, is, W, HW}, guc{g + 2 * HW, is, W, HW};
+      Slot gu{g + 2 * HW, is, W, HW};
+      PNPX_TRY((launch_rows<false>(P, LoadSlotMinusSlot{gz, guc}, kst, s)));
+      KSpace ks{reinterpret_cast<const float2*>(y0), mask, mu + i, param_stride, W, HW};
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidBlendAdjoint{ks, saved_k + (size_t)i * n, contrib}, kst, s)));
+      PNPX_TRY((launch_rows<true>(P, kld, StoreAdmmAdjoint{gu, gx, RealImg{gxr, W, HW}}, s)));
+      hipLaunchKernelGGL(item_sum_kernel, dim3(B), dim3(256), 0, s, contrib, grad_mu + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(unet_denoise_backward(ctx, saved_d + (size_t)i * n, sigma_d + i, param_stride, gxr, gd,
+                                     grad_sigma_d + (size_t)i * B, B, H, W, s, cached ? &ctx->train_arena[i] : nullptr,
+                                     cached ? static_cast<const float*>(ctx->train_pre[i].p) : nullptr));
+      hipLaunchKernelGGL(admm_adjoint_finish_kernel, g1(n), dim3(256), 0, s, gd, g, is, HW, B);
+      PNPX_LAUNCH_CHECK();
+    }
+    return PNPX_OK;
   });
 }
 

@@ -264,6 +264,8 @@ int reserve_arena(pnpx_ctx* ctx, UNetArena& ar, int mode, int B, int H, int W, s
   return PNPX_OK;
 }
 
+size_t unet_arena_bytes(int mode, int B, int H, int W) { return make_plan(mode, B, H, W).total; }
+
 int ctx_reserve_unet(pnpx_ctx* ctx, int B, int H, int W) {
   return reserve_arena(ctx, ctx->arena, ctx->conv_mode, B, H, W, 0);
 }

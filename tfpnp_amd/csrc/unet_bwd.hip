@@ -386,7 +386,8 @@ GradPlan make_grad_plan(int mode, int capB, int H, int W) {
 }  // namespace
 
 int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out,
-                          float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s) {
+                          float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s, UNetArena* cached,
+                          const float* cached_pre) {
   if (!ctx->has_weights) {
     set_error("denoiser backward called before pnpx_unet_load");
     return PNPX_ERR_NO_WEIGHTS;
@@ -409,11 +410,21 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
   // 1. recompute the forward pass with the context's own kernel family into the context's activation arena, keeping
   //    every activation (no fused network tail): the backward needs signs (LeakyReLU'), orderings (max-pool routing)
   //    and the pre-clamp output only, which the half-split activations give exactly as well as fp32 ones.
-  const int fmode = ctx->conv_mode;
+  //    (skipped when the caller kept them: `cached` is the arena of a keep_all forward of this very input)
+  const int fmode = cached ? cached->mode : ctx->conv_mode;
   const bool hs = (fmode == CONV_HS);
-  PNPX_TRY(unet_denoise(ctx, x, sigma, sigma_stride, out_tmp, pre, B, H, W, s, nullptr, &ctx->arena, fmode, true));
-  const UNetPlan F = make_plan(fmode, ctx->arena.capB, H, W);
-  char* FA = static_cast<char*>(ctx->arena.buf.p);
+  UNetArena& fa = cached ? *cached : ctx->arena;
+  if (cached) {
+    if (!(B <= cached->capB && H == cached->capH && W == cached->capW && cached_pre)) {
+      set_error("denoiser backward: the cached activations do not belong to a %dx%dx%d forward", B, H, W);
+      return PNPX_ERR_ARG;
+    }
+    pre = const_cast<float*>(cached_pre);
+  } else {
+    PNPX_TRY(unet_denoise(ctx, x, sigma, sigma_stride, out_tmp, pre, B, H, W, s, nullptr, &ctx->arena, fmode, true));
+  }
+  const UNetPlan F = make_plan(fmode, fa.capB, H, W);
+  char* FA = static_cast<char*>(fa.buf.p);
   auto sact = [&](const Act& d) { return SavedAct{FA + d.off, hs ? 1 : 0}; };
 
   // 2. gradient arena (zero borders: gradients are convolution INPUTS of the adjoint convs)

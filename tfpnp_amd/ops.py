@@ -348,6 +348,53 @@ def csmri_admm(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
     return _csmri_common("pnpx_csmri_admm", 3, ctx, variables, y0, mask, (sigma_d, mu), iter_num)
 
 
+def csmri_admm_train(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
+    """pnpx_csmri_admm_train: the ADMM forward that also returns what its VJP needs -> (next state, saved [3*T*B*H*W],
+    ticket of the context's activation cache (int, 0 = not cached))."""
+    v = _vars(variables, 3, True)
+    B, _, H, W, _ = v.shape
+    y0, m = _f32(y0, "y0"), _mask_u8(mask)
+    if y0.numel() != B * H * W * 2 or m.numel() != B * H * W:
+        raise PnpxError("y0/mask do not match the state's [B,H,W]")
+    ps, T = _params(B, sigma_d, mu)
+    if iter_num is not None:
+        if iter_num > T:
+            raise PnpxError(f"iter_num {iter_num} exceeds the {T} hyper-parameter columns provided")
+        T = iter_num
+    out = torch.empty_like(v)
+    saved = torch.empty(3 * T * B * H * W, dtype=torch.float32, device=v.device)
+    if B == 0:
+        return out, saved, 0
+    ticket = C.c_ulonglong(0)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().pnpx_csmri_admm_train(ctx.handle, _p(v), _p(out), _p(y0), _p(m), _p(ps[0]), _p(ps[1]),
+                                               ps[0].shape[1], B, H, W, T, _p(saved), C.byref(ticket), _stream(v)))
+    return out, saved, int(ticket.value)
+
+
+def csmri_admm_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num=None, ticket=0):
+    """pnpx_csmri_admm_backward -> (grad variables [B,3,H,W,2], grad sigma_d [B,T], grad mu [B,T])."""
+    g = _vars(grad_out, 3, True)
+    B, _, H, W, _ = g.shape
+    y0, m = _f32(y0, "y0"), _mask_u8(mask)
+    ps, T = _params(B, sigma_d, mu)
+    T = T if iter_num is None else iter_num
+    if saved.numel() != 3 * T * B * H * W:
+        raise PnpxError("saved does not belong to a forward of this shape / iteration count")
+    gin = torch.empty_like(g)
+    gs = torch.zeros(T, B, dtype=torch.float32, device=g.device)
+    gm = torch.zeros(T, B, dtype=torch.float32, device=g.device)
+    if B and T:
+        work = torch.empty(3 * B * H * W, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(_lib.lib().pnpx_csmri_admm_backward(ctx.handle, _p(y0), _p(m), _p(ps[0]), _p(ps[1]), ps[0].shape[1],
+                                                      _p(saved), _p(g), _p(gin), _p(gs), _p(gm), _p(work), B, H, W, T,
+                                                      int(ticket), _stream(g)))
+    elif B:
+        gin.copy_(g)
+    return gin, gs.t().contiguous(), gm.t().contiguous()
+
+
 def csmri_hqs(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
     return _csmri_common("pnpx_csmri_hqs", 2, ctx, variables, y0, mask, (sigma_d, mu), iter_num)
 

@@ -38,12 +38,14 @@ class ADMMSolver_CSMRI(CSMRIMixin, ADMMSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, mask) = inputs
         sigma_d, mu = parameters
-        if A.needs_grad(variables, sigma_d, mu):
-            return self._forward_autograd(variables, y0, mask, sigma_d, mu, iter_num)
+        if A.needs_grad(variables, sigma_d, mu):      # training path: native forward + native VJP (csmri.hip)
+            return T.call("csmri_admm_train", variables, y0, mask, sigma_d, mu, -1 if iter_num is None else iter_num,
+                          self._ctx(variables).cid)[0]
         return T.call("csmri_admm", variables, y0, mask, sigma_d, mu, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
     def _forward_autograd(self, variables, y0, mask, sigma_d, mu, iter_num):
-        """Training path (PnPEnv.forward under autograd): the reference's loop, tasks/csmri/solver.py:43-55."""
+        """The reference's loop (tasks/csmri/solver.py:43-55) from differentiable building blocks: the composition the
+        fused native VJP (pnpx_csmri_admm_backward) is tested against; the other solvers' training paths look like this."""
         x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
         B = x.shape[0]
         m = (mask != 0).unsqueeze(-1)

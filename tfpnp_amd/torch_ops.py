@@ -223,6 +223,63 @@ def csmri_admm(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu:
 csmri_admm.register_fake(_same)
 
 
+@_lib_def("pnpx::csmri_admm_train", mutates_args=(), device_types="cuda")
+def csmri_admm_train(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int,
+                     ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """Differentiable ADMMSolver_CSMRI.forward: same result as csmri_admm plus what its native VJP replays: the
+    per-iteration denoiser inputs and k-space images (`saved`) and the ticket of the context's activation cache (a
+    one-element int64 CPU tensor; see pnpx_csmri_admm_train).  What PnPEnv.forward calls under autograd
+    (tfpnp/env/base.py:193-206)."""
+    out, saved, ticket = ops.csmri_admm_train(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, _it(iter_num))
+    return out, saved, torch.tensor([ticket], dtype=torch.int64)
+
+
+@csmri_admm_train.register_fake
+def _(variables, y0, mask, sigma_d, mu, iter_num, ctx):
+    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
+    B, _, H, W, _ = variables.shape
+    return (torch.empty_like(variables, memory_format=torch.contiguous_format),
+            torch.empty((3 * T * B * H * W,), dtype=variables.dtype, device=variables.device),
+            torch.empty((1,), dtype=torch.int64))
+
+
+@_lib_def("pnpx::csmri_admm_backward", mutates_args=(), device_types="cuda")
+def csmri_admm_backward(y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, saved: Tensor, ticket: Tensor,
+                        grad_out: Tensor, iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """VJP of csmri_admm_train wrt (variables, sigma_d[:, :T], mu[:, :T]): reverse walk of the T iterations, natively."""
+    return ops.csmri_admm_backward(_ctx(ctx, grad_out), y0, mask, sigma_d, mu, saved, grad_out, _it(iter_num),
+                                   ticket=int(ticket[0]))
+
+
+@csmri_admm_backward.register_fake
+def _(y0, mask, sigma_d, mu, saved, ticket, grad_out, iter_num, ctx):
+    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
+    B = grad_out.shape[0]
+    e = lambda: torch.empty((B, T), dtype=grad_out.dtype, device=grad_out.device)
+    return torch.empty_like(grad_out, memory_format=torch.contiguous_format), e(), e()
+
+
+def _admm_train_setup(ctx, inputs, output):
+    _, y0, mask, sigma_d, mu, ctx.iter_num, ctx.cid = inputs
+    ctx.save_for_backward(y0, mask, sigma_d, mu, output[1], output[2])
+
+
+def _admm_train_bwd(ctx, g_out, _g_saved, _g_ticket):
+    y0, mask, sigma_d, mu, saved, ticket = ctx.saved_tensors
+    gv, gs, gm = torch.ops.pnpx.csmri_admm_backward(y0, mask, sigma_d, mu, saved, ticket, g_out.contiguous(),
+                                                    ctx.iter_num, ctx.cid)
+
+    def like(g, p):      # gradients of the columns that were iterated; the rest of [B, action_pack] did not take part
+        full = torch.zeros_like(p.reshape(p.shape[0], -1))
+        full[:, :g.shape[1]] = g
+        return full.view_as(p)
+
+    return gv, None, None, like(gs, sigma_d), like(gm, mu), None, None
+
+
+csmri_admm_train.register_autograd(_admm_train_bwd, setup_context=_admm_train_setup)
+
+
 @_lib_def("pnpx::csmri_hqs", mutates_args=(), device_types="cuda")
 def csmri_hqs(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int, ctx: int) -> Tensor:
     """HQSSolver_CSMRI.forward (tasks/csmri/solver.py:64-89)."""
@@ -309,5 +366,6 @@ def call(name, *args):
 
 
 ALL_OPS = ("unet_denoise", "unet_denoise_preclamp", "unet_denoise_backward", "policy_forward", "fft2", "cdp_forward",
-           "cdp_backward", "spi_inverse", "psnr", "radon_forward", "radon_backprojection", "csmri_admm", "csmri_hqs",
+           "cdp_backward", "spi_inverse", "psnr", "radon_forward", "radon_backprojection", "csmri_admm", "csmri_admm_train",
+           "csmri_admm_backward", "csmri_hqs",
            "csmri_pg", "csmri_apg", "csmri_redadmm", "pr_iadmm", "spi_admm", "ct_iadmm", "ct_pg")
