@@ -88,6 +88,17 @@ int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* 
  * The forward pass is re-computed internally in exact fp32 (gradient checkpointing); nothing is kept between calls. */
 int pnpx_unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, const float* grad_out,
                                float* grad_x, float* grad_sigma, int B, int H, int W, void* stream);
+/* The same pair for autograd graphs that hold many denoiser calls (the reference differentiates T solver iterations,
+ * PnPEnv.forward -> solver.forward, tfpnp/env/base.py:193-206): pnpx_unet_denoise_train = pnpx_unet_denoise that also
+ * parks every activation of this forward in the context's training ring and names it with *ticket (host memory; 0 when
+ * the ring is off or out of budget); pnpx_unet_denoise_backward_ticket skips the re-computation when the ring still
+ * holds that ticket and re-computes otherwise (ticket 0, slot re-used by a later forward, other weights) -- identical
+ * result either way.  Ring length = "train_cache_gb" budget / arena size (5 GiB at 48 x 256^2), at most 64 slots. */
+int pnpx_unet_denoise_train(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, int B, int H, int W,
+                            unsigned long long* ticket, void* stream);
+int pnpx_unet_denoise_backward_ticket(pnpx_ctx* ctx, const float* x, const float* sigma, const float* grad_out,
+                                      float* grad_x, float* grad_sigma, int B, int H, int W, unsigned long long ticket,
+                                      void* stream);
 /* Per-layer timing of one denoise call with HIP events on `stream` (synchronises).  ms_out[i] for the
  * i-th kernel launch of the forward pass, flops_out[i] its algorithmic FLOPs (0 for non-conv launches),
  * names_out[i] a static string.  Returns the number of entries written (<= cap) in *n_out. */
@@ -179,12 +190,12 @@ int pnpx_csmri_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const 
  *   The denoiser weights are constants (frozen, as in the reference); y0 / mask get no gradient.  Per iteration: one
  *   masked-FFT adjoint (same three fused passes as the forward), one deterministic per-item reduction (d/d mu) and the
  *   denoiser VJP (pnpx_unet_denoise_backward's kernels).
- * Activation cache: within the "train_cache_gb" budget (pnpx_ctx_set_option, default 96 GiB; one 48 x 256^2 iteration
- *   holds ~5 GiB -- the 288 GB of an MI355X are what make this affordable) the context keeps every denoiser
- *   activation of the LAST training forward, and *ticket (host memory, written before the call returns) names that
- *   content; a backward call that presents the same ticket skips the re-computation of the denoiser forwards
- *   (8 instead of 14.5 ms per iteration at 48 x 256^2).  Any other ticket (0, or one overwritten by a later training
- *   forward on this context) is answered by re-computation from `saved` -- same gradients, never stale ones. */
+ * Activation ring: every iteration's denoiser forward is a pnpx_unet_denoise_train call (above), so within the
+ *   "train_cache_gb" budget (default 96 GiB; ~5 GiB per 48 x 256^2 iteration -- the 288 GB of an MI355X are what make
+ *   this affordable) the backward pass does not re-compute the denoiser forwards (8 instead of 14.5 ms per iteration at
+ *   48 x 256^2).  *ticket (host memory, written before the call returns) is iteration 0's ticket, iteration i holds
+ *   ticket + i; slots that a later training forward has re-used are answered by re-computation from `saved` -- same
+ *   gradients, never stale ones. */
 int pnpx_csmri_admm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                           const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
                           int H, int W, int T, float* saved, unsigned long long* ticket, void* stream);

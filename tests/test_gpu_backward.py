@@ -282,7 +282,7 @@ def test_csmri_admm_fused_vjp_vs_composed_autograd(den):
 
 
 def test_csmri_admm_activation_cache(den):
-    """The training path keeps the denoiser activations of the last training forward (pnpx_csmri_admm_train's ticket):
+    """The training path parks the denoiser activations of training forwards in a ring (tickets):
     (a) gradients with the cache == gradients by re-computation (bit for bit for the same forward: same kernels);
     (b) a backward whose forward has been overwritten by a later training forward falls back to re-computation -- it
         must never read the newer activations; (c) the memory is accounted for and released by train_cache_gb = 0."""
@@ -313,12 +313,13 @@ def test_csmri_admm_activation_cache(den):
     try:
         l0, o0 = forward(0)
         held = ctx.bytes()
-        assert held > base + T * B * H * W * 4 * 32                 # T arenas are resident now
+        assert held > base + T * B * H * W * 4 * 32                 # T ring slots are resident now
         cached0 = backward(l0, o0)                                  # (a) served from the cache
         # (the un-cached forward runs the fused network tail: forward values differ in the last bit, gradients follow)
         assert all(rel(x, y) < 2e-2 for x, y in zip(cached0, ref[0]))
         l0, o0 = forward(0)
-        l1, o1 = forward(1)                                         # overwrites the cache of the first forward
+        for _ in range(64 // T + 1):                                # enough later forwards to re-use every slot of the
+            l1, o1 = forward(1)                                     # ring (at most 64 slots, T per forward)
         cached1 = backward(l1, o1)
         stale0 = backward(l0, o0)                                   # (b) stale ticket -> re-computation, not wrong data:
         assert all(torch.equal(x, y) for x, y in zip(stale0, cached0))   # same kernels on the same inputs, bit for bit

@@ -59,7 +59,17 @@ def test_opcheck_denoiser_and_solver(unet_params):
     torch.library.opcheck(torch.ops.pnpx.csmri_admm, (v0, g(d["y0"]), g(d["mask"]), g(a["sigma_d"]), g(a["mu"]), -1, cid))
     # the differentiable solver op: schema, fake tensors, and its registered (native) VJP under eager and AOT autograd
     lv, ls, lm = (t_.clone().requires_grad_(True) for t_ in (v0, g(a["sigma_d"]), g(a["mu"])))
-    torch.library.opcheck(torch.ops.pnpx.csmri_admm_train, (lv, g(d["y0"]), g(d["mask"]), ls, lm, 3, cid))
+    # (their ticket output is a fresh number per call by design, so the eager-vs-AOT output comparison does not apply;
+    #  schema, fake-tensor and autograd-registration checks do, and the gradients are compared in test_gpu_backward.py)
+    parts = ("test_schema", "test_faketensor", "test_autograd_registration")
+    torch.library.opcheck(torch.ops.pnpx.csmri_admm_train, (lv, g(d["y0"]), g(d["mask"]), ls, lm, 3, cid), test_utils=parts)
+    torch.library.opcheck(torch.ops.pnpx.unet_denoise_train, (x, s, cid), test_utils=parts)
+    out, ticket = torch.ops.pnpx.unet_denoise_train(x, s, cid)
+    assert ticket.device.type == "cpu" and int(ticket[0]) > 0
+    assert (out - torch.ops.pnpx.unet_denoise(x, s, cid)).abs().max() < 1e-6
+    gx, gs = torch.autograd.grad(out.sum(), (x, s))
+    gx2, gs2 = torch.ops.pnpx.unet_denoise_backward(x.detach(), s.detach(), torch.ones_like(out), cid)   # re-computation
+    assert torch.equal(gx, gx2) and torch.equal(gs, gs2)
 
 
 def test_fake_tensor_propagation_and_eager_compile(unet_params):

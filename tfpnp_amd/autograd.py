@@ -21,7 +21,9 @@ def needs_grad(*tensors):
 
 
 def denoise(native_ctx, x, sigma):
-    return T.call("unet_denoise", x, sigma, native_ctx.cid)          # VJP registered with the dispatcher
+    if needs_grad(x, sigma):      # activations parked in the context's training ring for the registered VJP
+        return T.call("unet_denoise_train", x, sigma, native_ctx.cid)[0]
+    return T.call("unet_denoise", x, sigma, native_ctx.cid)
 
 
 def fft2(x, inverse=False, centered=True):

@@ -84,19 +84,6 @@ using namespace pnpx;
   std::lock_guard<std::mutex> _lk((ctx)->mu); \
   PNPX_HIP(hipSetDevice((ctx)->device))
 
-namespace pnpx {
-void train_cache_free(pnpx_ctx* ctx) {
-  (void)hipDeviceSynchronize();
-  for (auto& a : ctx->train_arena)
-    if (a.buf.p) (void)hipFree(a.buf.p);
-  for (auto& b : ctx->train_pre)
-    if (b.p) (void)hipFree(b.p);
-  ctx->train_arena.clear();
-  ctx->train_pre.clear();
-  ctx->train_ticket = 0;
-}
-}  // namespace pnpx
-
 extern "C" {
 
 const char* pnpx_version(void) { return "pnpx 0.1 (gfx950)"; }
@@ -216,6 +203,7 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
   }
   if (is("train_cache_gb") && value >= 0) {   // shrinking to 0 also releases what is held
     ctx->opt_train_cache_gb = value;
+    ctx->train_alloc_failed = false;
     if (value == 0) pnpx::train_cache_free(ctx);
     return PNPX_OK;
   }
@@ -259,8 +247,7 @@ int pnpx_ctx_status(pnpx_ctx* ctx) {
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
   if (!ctx) return 0;
   size_t n = ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_grad.buf.bytes + ctx->scratch.bytes;
-  for (const auto& a : ctx->train_arena) n += a.buf.bytes;
-  for (const auto& b : ctx->train_pre) n += b.bytes;
+  for (const auto& sl : ctx->train_ring) n += sl.arena.buf.bytes + sl.pre.bytes;
   return n;
 }
 
@@ -405,7 +392,7 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
   ctx->weights.p = p;
   ctx->weights.bytes = host.size() * sizeof(float);
   ctx->has_weights = true;
-  ctx->train_ticket = 0;      // activations cached by a training forward belong to the previous weights
+  pnpx::train_cache_free(ctx);   // activations parked by training forwards belong to the previous weights
   return PNPX_OK;
 }
 
@@ -430,6 +417,32 @@ int pnpx_unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma
     return PNPX_ERR_ARG;
   }
   return unet_denoise_backward(ctx, x, sigma, 1, grad_out, grad_x, grad_sigma, B, H, W, static_cast<hipStream_t>(stream));
+  });
+}
+
+int pnpx_unet_denoise_train(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, int B, int H, int W,
+                            unsigned long long* ticket, void* stream) {
+  LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+    if (!x || !sigma || !out || !ticket) {
+      set_error("pnpx_unet_denoise_train: null pointer");
+      return PNPX_ERR_ARG;
+    }
+    return unet_denoise_train(ctx, x, sigma, 1, out, B, H, W, static_cast<hipStream_t>(stream), ticket);
+  });
+}
+
+int pnpx_unet_denoise_backward_ticket(pnpx_ctx* ctx, const float* x, const float* sigma, const float* grad_out,
+                                      float* grad_x, float* grad_sigma, int B, int H, int W, unsigned long long ticket,
+                                      void* stream) {
+  LOCK_CTX(ctx);
+  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+    if (!x || !sigma || !grad_out || !grad_x || !grad_sigma) {
+      set_error("pnpx_unet_denoise_backward_ticket: null pointer");
+      return PNPX_ERR_ARG;
+    }
+    return unet_denoise_backward_ticket(ctx, x, sigma, 1, grad_out, grad_x, grad_sigma, B, H, W,
+                                        static_cast<hipStream_t>(stream), ticket);
   });
 }
 

@@ -138,12 +138,19 @@ struct pnpx_ctx {
   //     arena = forward pass in the ctx's conv_mode (also the re-computation inside the backward pass);
   //     arena_grad = gradients of every activation (fp32 planar)
   pnpx::UNetArena arena, arena_grad;
-  // training path (pnpx_csmri_admm_train / _backward): one activation arena + pre-clamp output per inner iteration of
-  // the LAST training forward, identified by train_ticket (0 = nothing cached)
-  std::vector<pnpx::UNetArena> train_arena;
-  std::vector<pnpx::DeviceBuf> train_pre;
-  unsigned long long train_ticket = 0, train_counter = 0;
-  int train_B = 0, train_H = 0, train_W = 0, train_T = 0, train_mode = -1;
+  // training path: a ring of activation arenas.  Every denoiser forward run for autograd (pnpx_unet_denoise_train, the
+  // iterations of pnpx_csmri_admm_train) takes the next slot, keeps every activation + the pre-clamp output there and
+  // hands out a ticket; a VJP that presents a ticket still held by its slot skips the re-computation of the forward.
+  struct TrainSlot {
+    pnpx::UNetArena arena;
+    pnpx::DeviceBuf pre;
+    unsigned long long ticket = 0;
+    int B = 0;
+  };
+  std::vector<TrainSlot> train_ring;
+  unsigned long long train_counter = 0;
+  int train_H = 0, train_W = 0, train_mode = -1;   // geometry the ring is laid out for
+  bool train_alloc_failed = false;                 // stop retrying after an out-of-memory until the option is set again
   // --- policy actor
   pnpx::PolicyNet policy;
   // --- solver scratch (complex fields etc.), grown on demand
@@ -199,6 +206,14 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
                           UNetArena* cached = nullptr, const float* cached_pre = nullptr);
 size_t unet_arena_bytes(int mode, int B, int H, int W);
 void train_cache_free(pnpx_ctx* ctx);
+// Denoiser forward for autograd: like unet_denoise, additionally parks the activations in the training ring; *ticket = 0
+// when the ring is disabled / out of budget (the VJP then re-computes).
+int unet_denoise_train(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, int B, int H,
+                       int W, hipStream_t s, unsigned long long* ticket);
+// VJP that looks the ticket up in the ring first (ticket 0 / overwritten slot: re-computation)
+int unet_denoise_backward_ticket(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride,
+                                 const float* grad_out, float* grad_x, float* grad_sigma, int B, int H, int W,
+                                 hipStream_t s, unsigned long long ticket);
 
 // Policy actor (policy.hip)
 size_t policy_num_params(int num_inputs, int n_det, int spi_head);

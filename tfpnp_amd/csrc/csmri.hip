@@ -309,44 +309,16 @@ using namespace pnpx;
   std::lock_guard<std::mutex> _lk((ctx)->mu);          \
   PNPX_HIP(hipSetDevice((ctx)->device))
 
-// Activation cache of the training path: iteration i of a training forward runs its denoiser in train_arena[i] with
-// every activation kept, so the backward pass does not have to re-compute the forward (one arena is ~5 GiB at 48 x 256^2;
-// the budget is the "train_cache_gb" option).  Returns false when the budget does not cover T iterations.
-static bool train_cache_prepare(pnpx_ctx* ctx, int B, int H, int W, int T) {
-  ctx->train_ticket = 0;      // whatever was cached is about to be overwritten
-  const size_t per = unet_arena_bytes(ctx->conv_mode, B, H, W) + sizeof(float) * (size_t)B * H * W;
-  if (ctx->opt_train_cache_gb <= 0 || T <= 0 || per * (size_t)T > ((size_t)ctx->opt_train_cache_gb << 30)) return false;
-  if ((int)ctx->train_arena.size() < T) {
-    ctx->train_arena.resize(T);
-    ctx->train_pre.resize(T);
-  }
-  for (int i = 0; i < T; ++i) {
-    DeviceBuf& pb = ctx->train_pre[i];
-    const size_t need = sizeof(float) * (size_t)B * H * W;
-    if (pb.bytes >= need) continue;
-    (void)hipDeviceSynchronize();
-    if (pb.p) (void)hipFree(pb.p);
-    pb = DeviceBuf();
-    void* q = nullptr;
-    if (hipMalloc(&q, need) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    pb.p = q;
-    pb.bytes = need;
-  }
-  return true;
-}
-
 // ADMM forward; `saved` != NULL (training path) keeps, per iteration, the denoiser input d_i [T][B][HW] floats followed
-// by the k-space image before the blend k_i [T][B][HW] complex, and (budget permitting) the denoiser activations in the
-// context's training cache; *ticket_out identifies that cache content (0: nothing cached, the backward re-computes).
+// by the k-space image before the blend k_i [T][B][HW] complex, and parks the denoiser activations of every iteration
+// in the context's training ring (unet_denoise_train): iteration i holds ticket *ticket_out + i (tickets are handed
+// out consecutively under the context lock; 0: the first iteration was not parked).
 static int admm_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const uint8_t* mask,
                         const float* sigma_d, const float* mu, int param_stride, int B, int H, int W, int T,
                         float* saved, hipStream_t s, unsigned long long* ticket_out = nullptr) {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
   if (ticket_out) *ticket_out = 0;
-  bool cache = saved && ticket_out && train_cache_prepare(ctx, B, H, W, T);
+  const bool park = saved && ticket_out;
   const int HW = H * W;
   const size_t is = 3 * (size_t)HW;
   Scratch S;
@@ -369,17 +341,13 @@ static int admm_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, co
   for (int i = 0; i < T; ++i) {
     if (saved)
       PNPX_HIP(hipMemcpyAsync(saved + (size_t)i * B * HW, S.d, sizeof(float) * B * HW, hipMemcpyDeviceToDevice, s));
-    if (cache) {
-      const int st = unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, static_cast<float*>(ctx->train_pre[i].p), B,
-                                  H, W, s, nullptr, &ctx->train_arena[i], ctx->conv_mode, true);
-      if (st == PNPX_ERR_ALLOC) {   // out of memory for the cache: give it back and carry on without
-        train_cache_free(ctx);
-        cache = false;
-      } else if (st != PNPX_OK) {
-        return st;
-      }
+    if (park) {
+      unsigned long long tk = 0;
+      PNPX_TRY(unet_denoise_train(ctx, S.d, sigma_d + i, param_stride, S.xr, B, H, W, s, &tk));
+      if (i == 0) *ticket_out = tk;
+    } else {
+      PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
     }
-    if (!cache) PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
     CSlot ui{(i == 0 ? vin : vout) + 2 * HW, is, W, HW};
     PNPX_TRY((launch_rows<false>(P, LoadXrPlusU{xr, ui}, kst, s)));
     KSpace ks{reinterpret_cast<const float2*>(y0), mask, mu + i, param_stride, W, HW};
@@ -390,15 +358,6 @@ static int admm_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, co
       PNPX_TRY((launch_cols<false, true>(P, kld, MidBlend{ks}, kst, s)));
     }
     PNPX_TRY((launch_rows<true>(P, kld, StoreAdmm{zo, uo, xo, ui, xr, d, i == T - 1}, s)));
-  }
-  if (cache) {
-    ctx->train_ticket = ++ctx->train_counter;
-    ctx->train_B = B;
-    ctx->train_H = H;
-    ctx->train_W = W;
-    ctx->train_T = T;
-    ctx->train_mode = ctx->conv_mode;
-    *ticket_out = ctx->train_ticket;
   }
   return PNPX_OK;
 }
@@ -455,9 +414,7 @@ extern "C" int pnpx_csmri_admm_backward(pnpx_ctx* ctx, const float* y0, const ui
     float *gxr = work, *gd = work + n, *contrib = work + 2 * n;
     const float* saved_d = saved;
     const float2* saved_k = reinterpret_cast<const float2*>(saved + (size_t)T * n);
-    // the activations of the matching training forward, if this context still holds them
-    const bool cached = ticket != 0 && ticket == ctx->train_ticket && B == ctx->train_B && H == ctx->train_H &&
-                        W == ctx->train_W && T == ctx->train_T;
+
     for (int i = T - 1; i >= 0; --i) {
       Scratch S;   // the k-space transit buffer lives in the context scratch, which the denoiser VJP may re-allocate
       PNPX_TRY(get_scratch(ctx, B, H, W, &S));
@@ -471,9 +428,9 @@ extern "C" int pnpx_csmri_admm_backward(pnpx_ctx* ctx, const float* y0, const ui
       PNPX_TRY((launch_rows<true>(P, kld, StoreAdmmAdjoint{gu, gx, RealImg{gxr, W, HW}}, s)));
       hipLaunchKernelGGL(item_sum_kernel, dim3(B), dim3(256), 0, s, contrib, grad_mu + (size_t)i * B, HW);
       PNPX_LAUNCH_CHECK();
-      PNPX_TRY(unet_denoise_backward(ctx, saved_d + (size_t)i * n, sigma_d + i, param_stride, gxr, gd,
-                                     grad_sigma_d + (size_t)i * B, B, H, W, s, cached ? &ctx->train_arena[i] : nullptr,
-                                     cached ? static_cast<const float*>(ctx->train_pre[i].p) : nullptr));
+      // iteration i parked its activations under ticket + i (if the ring still holds them; else re-computation)
+      PNPX_TRY(unet_denoise_backward_ticket(ctx, saved_d + (size_t)i * n, sigma_d + i, param_stride, gxr, gd,
+                                            grad_sigma_d + (size_t)i * B, B, H, W, s, ticket ? ticket + i : 0));
       hipLaunchKernelGGL(admm_adjoint_finish_kernel, g1(n), dim3(256), 0, s, gd, g, is, HW, B);
       PNPX_LAUNCH_CHECK();
     }

@@ -266,6 +266,86 @@ int reserve_arena(pnpx_ctx* ctx, UNetArena& ar, int mode, int B, int H, int W, s
 
 size_t unet_arena_bytes(int mode, int B, int H, int W) { return make_plan(mode, B, H, W).total; }
 
+void train_cache_free(pnpx_ctx* ctx) {
+  (void)hipDeviceSynchronize();
+  for (auto& sl : ctx->train_ring) {
+    if (sl.arena.buf.p) (void)hipFree(sl.arena.buf.p);
+    if (sl.pre.p) (void)hipFree(sl.pre.p);
+  }
+  ctx->train_ring.clear();
+  ctx->train_H = ctx->train_W = 0;
+  ctx->train_mode = -1;
+}
+
+// Next slot of the training ring for a B x H x W forward, or nullptr (ring disabled, budget below one arena, or out of
+// memory).  The ring serves one geometry / kernel family at a time and is re-laid out when that changes; its length is
+// what the "train_cache_gb" budget buys at the largest batch seen (at most 64 slots).
+static pnpx_ctx::TrainSlot* train_slot_acquire(pnpx_ctx* ctx, int B, int H, int W) {
+  if (ctx->opt_train_cache_gb <= 0 || ctx->train_alloc_failed) return nullptr;
+  const int mode = ctx->conv_mode;
+  int capB = B;
+  for (const auto& sl : ctx->train_ring) capB = sl.arena.capB > capB ? sl.arena.capB : capB;
+  const size_t per = unet_arena_bytes(mode, capB, H, W) + sizeof(float) * (size_t)capB * H * W;
+  size_t n = ((size_t)ctx->opt_train_cache_gb << 30) / per;
+  if (n == 0) return nullptr;
+  if (n > 64) n = 64;
+  if (H != ctx->train_H || W != ctx->train_W || mode != ctx->train_mode || n != ctx->train_ring.size()) {
+    train_cache_free(ctx);
+    ctx->train_ring.resize(n);
+    ctx->train_H = H;
+    ctx->train_W = W;
+    ctx->train_mode = mode;
+  }
+  pnpx_ctx::TrainSlot& sl = ctx->train_ring[ctx->train_counter % ctx->train_ring.size()];
+  sl.ticket = 0;
+  const size_t need = sizeof(float) * (size_t)B * H * W;
+  if (sl.pre.bytes < need) {
+    (void)hipDeviceSynchronize();
+    if (sl.pre.p) (void)hipFree(sl.pre.p);
+    sl.pre = DeviceBuf();
+    void* q = nullptr;
+    if (hipMalloc(&q, need) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->train_alloc_failed = true;
+      train_cache_free(ctx);
+      return nullptr;
+    }
+    sl.pre.p = q;
+    sl.pre.bytes = need;
+  }
+  return &sl;
+}
+
+int unet_denoise_train(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, int B, int H,
+                       int W, hipStream_t s, unsigned long long* ticket) {
+  *ticket = 0;
+  if (pnpx_ctx::TrainSlot* sl = train_slot_acquire(ctx, B, H, W)) {
+    const int st = unet_denoise(ctx, x, sigma, sigma_stride, out, static_cast<float*>(sl->pre.p), B, H, W, s, nullptr,
+                                &sl->arena, ctx->conv_mode, true);
+    if (st == PNPX_OK) {
+      sl->ticket = *ticket = ++ctx->train_counter;
+      sl->B = B;
+      return PNPX_OK;
+    }
+    if (st != PNPX_ERR_ALLOC) return st;
+    ctx->train_alloc_failed = true;   // out of memory for the ring: give it back and carry on without
+    train_cache_free(ctx);
+  }
+  return unet_denoise(ctx, x, sigma, sigma_stride, out, nullptr, B, H, W, s, nullptr);
+}
+
+int unet_denoise_backward_ticket(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride,
+                                 const float* grad_out, float* grad_x, float* grad_sigma, int B, int H, int W,
+                                 hipStream_t s, unsigned long long ticket) {
+  if (ticket != 0 && !ctx->train_ring.empty() && H == ctx->train_H && W == ctx->train_W) {
+    pnpx_ctx::TrainSlot& sl = ctx->train_ring[(ticket - 1) % ctx->train_ring.size()];
+    if (sl.ticket == ticket && sl.B == B)
+      return unet_denoise_backward(ctx, x, sigma, sigma_stride, grad_out, grad_x, grad_sigma, B, H, W, s, &sl.arena,
+                                   static_cast<const float*>(sl.pre.p));
+  }
+  return unet_denoise_backward(ctx, x, sigma, sigma_stride, grad_out, grad_x, grad_sigma, B, H, W, s);
+}
+
 int ctx_reserve_unet(pnpx_ctx* ctx, int B, int H, int W) {
   return reserve_arena(ctx, ctx->arena, ctx->conv_mode, B, H, W, 0);
 }

@@ -195,8 +195,26 @@ def unet_denoise(ctx, x, sigma, return_preclamp=False):
     return (out, pre) if return_preclamp else out
 
 
-def unet_denoise_backward(ctx, x, sigma, grad_out):
-    """(grad_x [B,1,H,W], grad_sigma [B]) = J^T grad_out of unet_denoise (forward re-computed natively in fp32)."""
+def unet_denoise_train(ctx, x, sigma):
+    """Denoiser forward for autograd -> (out [B,1,H,W], ticket): the activations are parked in the context's training
+    ring under `ticket` (0: not parked) so that unet_denoise_backward(..., ticket=) need not re-compute them."""
+    x = _f32(x, "x")
+    sigma = _f32(sigma, "sigma").reshape(-1)
+    if x.dim() != 4 or x.shape[1] != 1 or sigma.numel() != x.shape[0]:
+        raise PnpxError(f"denoiser input must be [B,1,H,W] with sigma [B], got {tuple(x.shape)} / {tuple(sigma.shape)}")
+    B, _, H, W = x.shape
+    out = torch.empty_like(x)
+    ticket = C.c_ulonglong(0)
+    if B:
+        with torch.cuda.device(x.device):
+            check(_lib.lib().pnpx_unet_denoise_train(ctx.handle, _p(x), _p(sigma), _p(out), B, H, W, C.byref(ticket),
+                                                     _stream(x)))
+    return out, int(ticket.value)
+
+
+def unet_denoise_backward(ctx, x, sigma, grad_out, ticket=0):
+    """(grad_x [B,1,H,W], grad_sigma [B]) = J^T grad_out of unet_denoise; the forward pass is re-computed natively unless
+    `ticket` names activations the context's training ring still holds."""
     x = _f32(x, "x")
     sigma = _f32(sigma, "sigma").reshape(-1)
     grad_out = _f32(grad_out, "grad_out")
@@ -206,8 +224,8 @@ def unet_denoise_backward(ctx, x, sigma, grad_out):
     gx = torch.empty_like(x)
     gs = torch.empty((B,), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
-        check(_lib.lib().pnpx_unet_denoise_backward(ctx.handle, _p(x), _p(sigma), _p(grad_out), _p(gx), _p(gs), B, H, W,
-                                                    _stream(x)))
+        check(_lib.lib().pnpx_unet_denoise_backward_ticket(ctx.handle, _p(x), _p(sigma), _p(grad_out), _p(gx), _p(gs), B, H,
+                                                           W, int(ticket), _stream(x)))
     return gx, gs
 
 

@@ -50,8 +50,12 @@ class UNetDenoiser2D(torch.nn.Module):
 
     def forward(self, x, sigma):
         # x: [B,1,H,W]; sigma: [B]      (denoiser/base.py:23-32)
-        # one dispatcher op; its registered autograd formula is the native VJP wrt x and sigma (training path)
-        return T.call("unet_denoise", x, sigma, self.context(x.device).cid)
+        # one dispatcher op; its registered autograd formula is the native VJP wrt x and sigma.  Under autograd the
+        # training variant runs: same kernels, and the activations stay in the context's ring for that VJP
+        cid = self.context(x.device).cid
+        if torch.is_grad_enabled() and (x.requires_grad or sigma.requires_grad):
+            return T.call("unet_denoise_train", x, sigma, cid)[0]
+        return T.call("unet_denoise", x, sigma, cid)
 
     def forward_preclamp(self, x, sigma):
         """(clamped, pre-clamp) outputs -- the pre-clamp UNet output is what the parity tests compare."""

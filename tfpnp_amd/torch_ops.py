@@ -79,6 +79,45 @@ def _denoise_bwd(ctx, g):
 unet_denoise.register_autograd(_denoise_bwd, setup_context=_denoise_setup)
 
 
+@_lib_def("pnpx::unet_denoise_train", mutates_args=(), device_types="cuda")
+def unet_denoise_train(x: Tensor, sigma: Tensor, ctx: int) -> Tuple[Tensor, Tensor]:
+    """unet_denoise for autograd graphs: also parks the activations in the context's training ring; the second output is
+    the ticket (one-element int64 CPU tensor) its VJP presents to skip the re-computation (pnpx_unet_denoise_train)."""
+    out, ticket = ops.unet_denoise_train(_ctx(ctx, x), x, sigma)
+    return out, torch.tensor([ticket], dtype=torch.int64)
+
+
+@unet_denoise_train.register_fake
+def _(x, sigma, ctx):
+    return torch.empty_like(x, memory_format=torch.contiguous_format), torch.empty((1,), dtype=torch.int64)
+
+
+@_lib_def("pnpx::unet_denoise_backward_ticket", mutates_args=(), device_types="cuda")
+def unet_denoise_backward_ticket(x: Tensor, sigma: Tensor, grad_out: Tensor, ticket: Tensor, ctx: int) -> Tuple[Tensor, Tensor]:
+    """VJP of unet_denoise_train: served from the training ring if it still holds `ticket`, else by re-computation."""
+    return ops.unet_denoise_backward(_ctx(ctx, x), x, sigma.reshape(-1), grad_out, ticket=int(ticket[0]))
+
+
+@unet_denoise_backward_ticket.register_fake
+def _(x, sigma, grad_out, ticket, ctx):
+    return (torch.empty_like(x, memory_format=torch.contiguous_format),
+            torch.empty((x.shape[0],), dtype=x.dtype, device=x.device))
+
+
+def _denoise_train_setup(ctx, inputs, output):
+    x, sigma, ctx.cid = inputs
+    ctx.save_for_backward(x, sigma, output[1])
+
+
+def _denoise_train_bwd(ctx, g, _g_ticket):
+    x, sigma, ticket = ctx.saved_tensors
+    gx, gs = torch.ops.pnpx.unet_denoise_backward_ticket(x, sigma, g.contiguous(), ticket, ctx.cid)
+    return gx, gs.view_as(sigma), None
+
+
+unet_denoise_train.register_autograd(_denoise_train_bwd, setup_context=_denoise_train_setup)
+
+
 @_lib_def("pnpx::policy_forward", mutates_args=(), device_types="cuda")
 def policy_forward(ob: Tensor, ctx: int) -> Tuple[Tensor, Tensor]:
     """ResNetActorBase.forward in eval mode (tfpnp/policy/network.py:129-147): ob [B,C,H,W] -> (probs [B,2], det [B,n])."""
@@ -365,7 +404,8 @@ def call(name, *args):
     return getattr(torch.ops.pnpx, name)(*args)
 
 
-ALL_OPS = ("unet_denoise", "unet_denoise_preclamp", "unet_denoise_backward", "policy_forward", "fft2", "cdp_forward",
+ALL_OPS = ("unet_denoise", "unet_denoise_preclamp", "unet_denoise_backward", "unet_denoise_train",
+           "unet_denoise_backward_ticket", "policy_forward", "fft2", "cdp_forward",
            "cdp_backward", "spi_inverse", "psnr", "radon_forward", "radon_backprojection", "csmri_admm", "csmri_admm_train",
            "csmri_admm_backward", "csmri_hqs",
            "csmri_pg", "csmri_apg", "csmri_redadmm", "pr_iadmm", "spi_admm", "ct_iadmm", "ct_pg")

@@ -33,9 +33,10 @@ def step(fn):
 
 
 ctx = den.context(dev)
-for name, gb, fn in (("fused, cached acts", 96, lambda v, s, mu: sol((v, (y0, m)), (s, mu))),
+for name, gb, fn in (("fused, ring", 96, lambda v, s, mu: sol((v, (y0, m)), (s, mu))),
                      ("fused, recompute", 0, lambda v, s, mu: sol((v, (y0, m)), (s, mu))),
-                     ("composed autograd", 0, lambda v, s, mu: sol._forward_autograd(v, y0, m, s, mu, None))):
+                     ("composed, ring", 96, lambda v, s, mu: sol._forward_autograd(v, y0, m, s, mu, None)),
+                     ("composed, recompute", 0, lambda v, s, mu: sol._forward_autograd(v, y0, m, s, mu, None))):
     ctx.set_option("train_cache_gb", gb)
     step(fn)
     print(f"  context holds {ctx.bytes() / 2**30:.1f} GiB")
