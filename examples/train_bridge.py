@@ -62,7 +62,7 @@ def train(steps=12, B=4, H=64, action_pack=3, lr=3e-2, seed=0, log=print):
         opt.step()
         history.append(float(reward.detach().mean()))
         log(f"step {it:2d}  mean delta-PSNR reward {history[-1]:+.4f} dB   sigma_d[0] "
-            f"{[round(float(v) * 255, 1) for v in action['sigma_d'][0]]}  mu[0] {[round(float(v), 3) for v in action['mu'][0]]}")
+            f"{[round(v * 255, 1) for v in action['sigma_d'][0].tolist()]}  mu[0] {[round(v, 3) for v in action['mu'][0].tolist()]}")
     return history
 
 

@@ -315,3 +315,37 @@ def test_two_devices_in_one_process(unet_params):
         th.join()
     assert not errs, errs
     assert torch.equal(out[0], out[1])
+
+
+def test_solver_call_is_hipgraph_capturable(den):
+    """One solver call (all inner iterations: denoiser launches, fused FFT passes, range-guard bookkeeping) records
+    into a hipGraph (torch.cuda.graph) once its workspaces exist, and a replay reproduces the eager result bit for bit --
+    i.e. the native path issues nothing but stream-ordered work (no hidden allocation, host read-back or default-stream
+    operation) in steady state.  (Replay is not faster: the path is GPU-bound down to B=1, tools/graph_capture.py.)"""
+    from tfpnp_amd.tasks import csmri
+    sol = csmri.ADMMSolver_CSMRI(den)
+    B, H, W, T = 3, 64, 64, 4
+    d = synth.make_csmri_batch(B, H, W, seed=311)
+    a = csmri_actions(B, T, 312, ("sigma_d", "mu"))
+    v0, y0, m = sol.reset({"x0": g(d["x0"])}), g(d["y0"]), g(d["mask"])
+    sg, mu = g(a["sigma_d"]), g(a["mu"])
+    with torch.no_grad():
+        ref = sol((v0, (y0, m)), (sg, mu)).clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            sol((v0, (y0, m)), (sg, mu))
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = sol((v0, (y0, m)), (sg, mu))
+        for _ in range(3):
+            out.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+        v0.copy_(sol.reset({"x0": g(d["x0"])}) * 0.5)       # new data through the same captured pointers
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, sol((v0, (y0, m)), (sg, mu)))
+    den.context(dev()).status()
