@@ -23,7 +23,6 @@ Prints ONE JSON line on rank 0 (fields: see the contract in the task statement) 
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

@@ -6,7 +6,6 @@ reference.  Everything that computes (fft2, ifft2, cdp_*, spi_inverse, Radon) is
 import numpy as np
 import torch
 
-from .. import ops
 from .. import torch_ops as T
 
 

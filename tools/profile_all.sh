@@ -19,6 +19,11 @@ T="python tools/bench_tasks.py"
 $R --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $O/task_sq -o p -- $T > $O/task_sq.log 2>&1
 $R --pmc FETCH_SIZE -d $O/task_fetch -o p -- $T > $O/task_fetch.log 2>&1
 $R --pmc WRITE_SIZE -d $O/task_write -o p -- $T > $O/task_write.log 2>&1
+# 4. the training path (fused ADMM forward + VJP, activation ring on / off, composed path)
+$R --stats -d $O/train -o t -- python tools/time_train.py 48 256 5 > $O/r2_train_times.txt 2>&1
+python tools/rocpd_stats.py $O/train/t_results.db > $O/r2_train_kernel_stats.md
+# 5. power / clock telemetry while the denoiser loops
+bash tools/power_probe.sh $O/r2_power_probe.txt > /dev/null 2>&1
 # summaries (the raw databases exceed the 64 MiB that travel back)
 python tools/rocpd_stats.py $O/bench/bench_results.db > $O/r2_bench_kernel_stats.md
 grep '^{' $O/bench.log | tail -1 > $O/r2_bench_profiled.json
