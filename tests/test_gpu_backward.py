@@ -281,6 +281,28 @@ def test_csmri_admm_fused_vjp_vs_composed_autograd(den):
     assert all(torch.equal(x, y) for x, y in zip(gf, gf2))   # deterministic reductions
 
 
+def test_csmri_admm_train_degenerate_calls(den):
+    """iter_num = 0 (identity: gradient passes straight through, hyper-parameters get zeros) and an empty batch."""
+    from tfpnp_amd.tasks import csmri
+    sol = csmri.ADMMSolver_CSMRI(den)
+    B, H, W = 2, 32, 32
+    d = synth.make_csmri_batch(B, H, W, seed=191)
+    a = csmri_actions(B, 3, 192, ("sigma_d", "mu"))
+    y0, m = g(d["y0"]), g(d["mask"])
+    v = sol.reset({"x0": g(d["x0"])}).requires_grad_(True)
+    sg, mu = g(a["sigma_d"], True), g(a["mu"], True)
+    out = sol((v, (y0, m)), (sg, mu), iter_num=0)
+    assert torch.equal(out, v)
+    wts = torch.randn_like(out)
+    (out * wts).sum().backward()
+    assert torch.equal(v.grad, wts) and float(sg.grad.abs().max()) == 0.0 and float(mu.grad.abs().max()) == 0.0
+    ve = v.detach()[:0].requires_grad_(True)
+    oe = sol((ve, (y0[:0], m[:0])), (sg.detach()[:0].requires_grad_(True), mu.detach()[:0]))
+    assert oe.shape == (0, 3, H, W, 2)
+    oe.sum().backward()
+    assert ve.grad.shape == ve.shape
+
+
 def test_csmri_admm_activation_cache(den):
     """The training path parks the denoiser activations of training forwards in a ring (tickets):
     (a) gradients with the cache == gradients by re-computation (bit for bit for the same forward: same kernels);

@@ -309,9 +309,10 @@ def _admm_train_bwd(ctx, g_out, _g_saved, _g_ticket):
                                                     ctx.iter_num, ctx.cid)
 
     def like(g, p):      # gradients of the columns that were iterated; the rest of [B, action_pack] did not take part
-        full = torch.zeros_like(p.reshape(p.shape[0], -1))
-        full[:, :g.shape[1]] = g
-        return full.view_as(p)
+        full = torch.zeros_like(p)
+        if p.numel():
+            full.view(p.shape[0], -1)[:, :g.shape[1]] = g
+        return full
 
     return gv, None, None, like(gs, sigma_d), like(gm, mu), None, None
 
