@@ -35,11 +35,48 @@ def save(name, **kw):
     print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KB)")
 
 
+def gradient_goldens(den):
+    """(9) the reference's OWN autograd through its solver and env (the training path, tfpnp/env/base.py:193-206 called
+    from trainer/mddpg/trainer.py:171-192): d sum(out * wts) / d (variables, sigma_d, mu) of ADMMSolver_CSMRI.forward on
+    the kink-free case, and d sum(reward) / d policy logits of CSMRIEnv.forward."""
+    from tests.golden_inputs import GRAD_CASE as C
+    cs = ref_shim.load_task_module("csmri", "solver")
+    env_mod = ref_shim.load_task_module("csmri", "env")
+    sol = cs.ADMMSolver_CSMRI(den)
+    d = synth.make_csmri_batch(C.B, C.H, C.W, seed=C.data_seed)
+    a = csmri_actions(C.B, C.T, C.action_seed, ("sigma_d", "mu"))
+    with torch.no_grad():
+        v0 = sol.reset({"x0": t(d["x0"])})
+    wts = np.random.RandomState(C.wts_seed).standard_normal(tuple(v0.shape)).astype(np.float32)
+    leaves = [v0.clone().requires_grad_(True), t(a["sigma_d"]).requires_grad_(True), t(a["mu"]).requires_grad_(True)]
+    out = sol((leaves[0], (t(d["y0"]), t(d["mask"]))), (leaves[1], leaves[2]))
+    (out * t(wts)).sum().backward()
+    res = {"admm_out": out.detach(), "admm_grad_variables": leaves[0].grad, "admm_grad_sigma_d": leaves[1].grad,
+           "admm_grad_mu": leaves[2].grad}
+    # env.forward: reward differentiated wrt policy-like logits
+    d2 = synth.make_csmri_batch(C.env_B, C.env_H, C.env_W, seed=C.env_data_seed)
+    env = env_mod.CSMRIEnv(None, cs.ADMMSolver_CSMRI(den), max_episode_step=6)
+    with torch.no_grad():
+        ob = env.reset(data={k: t(v).clone() for k, v in d2.items() if isinstance(v, np.ndarray)})
+    raw0 = np.random.RandomState(C.env_raw_seed).standard_normal((C.env_B, 10)).astype(np.float32)
+    raw = t(raw0).requires_grad_(True)
+    action = {"sigma_d": torch.sigmoid(raw[:, :5]) * 70 / 255, "mu": torch.sigmoid(raw[:, 5:])}
+    _, reward = env.forward(ob, action)
+    reward.sum().backward()
+    res.update(env_reward=reward.detach(), env_grad_raw=raw.grad)
+    save("csmri_grads", in_sha=sha(d["y0"], d["mask"], d["x0"], a["sigma_d"], a["mu"], wts, d2["y0"], raw0), **res)
+
+
 def main():
     assert ref_shim.available(), "reference not mounted"
     ref_shim.install()
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--only-grads" in sys.argv:
+        den = ref_shim.make_denoiser(synth.make_unet_params(WEIGHT_SEED), tempfile.mkdtemp())
+        print("[9] gradients")
+        gradient_goldens(den)
+        return
     from tfpnp.utils import transforms as T
     from tfpnp.pnp.denoiser.models.unet import UNet
     from tfpnp.env.base import torch_psnr
@@ -219,6 +256,8 @@ def main():
                 break
         ro["n_steps"] = np.array(s + 1)
         save("policy_rollout_csmri", **ro)
+    print("[9] gradients")
+    gradient_goldens(den)
     print("done")
 
 

@@ -3,6 +3,7 @@ and by the tests (which rebuild the same inputs and compare against tests/golden
 import hashlib
 
 import numpy as np
+import torch
 
 from tfpnp_amd import synth
 
@@ -100,3 +101,63 @@ def ellipse_sinogram(ells, angles, det):
             tt = s - (e["cx"] * np.cos(th) + e["cy"] * np.sin(th))
             out[v] += e["rho"] * 2 * e["a"] * e["b"] * np.sqrt(np.maximum(r2 - tt ** 2, 0.0)) / r2
     return out.astype(np.float32)
+
+
+# ------------------------------------------------------------------ gradient cases
+class GRAD_CASE:
+    """The CS-MRI ADMM case whose gradients are pinned to the real reference's autograd (tests/golden/csmri_grads.npz):
+    B=1, 16x16, T=2 -- picked by the kink-margin search of tests/test_gpu_backward.py::test_csmri_solver_gradients
+    (try k=1: no LeakyReLU / max-pool / clamp decision of either denoiser call within 1e-5 of its kink, re-checked by
+    tests/test_oracle_golden.py), so that fp32 evaluations agree to rounding."""
+    B, H, W, T = 1, 16, 16, 2
+    data_seed, action_seed, wts_seed = 171, 172, 73
+    # PnPEnv.forward reward gradient wrt policy logits (arbitrary inputs: kinks possible, loose bound)
+    env_B, env_H, env_W, env_data_seed, env_raw_seed = 2, 32, 32, 95, 96
+
+
+class _KinkProbe:
+    """Stands in for torch.nn.functional inside the oracle and records how close any LeakyReLU input or max-pool
+    decision comes to its kink, relative to the layer's mean magnitude."""
+
+    def __init__(self):
+        import torch.nn.functional as F
+        self.F, self.margin = F, float("inf")
+
+    def __getattr__(self, name):
+        return getattr(self.F, name)
+
+    def leaky_relu(self, x, slope):
+        self.margin = min(self.margin, float(x.abs().min() / x.abs().mean()))
+        return self.F.leaky_relu(x, slope)
+
+    def max_pool2d(self, x, k):
+        B, C, H, W = x.shape
+        win = x[:, :, :H // 2 * 2, :W // 2 * 2].reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5)
+        top = win.reshape(B, C, H // 2, W // 2, 4).topk(2, dim=-1).values
+        self.margin = min(self.margin, float((top[..., 0] - top[..., 1]).min() / x.abs().mean()))
+        return self.F.max_pool2d(x, k)
+
+
+
+def solver_kink_margin(run):
+    """Smallest distance of any LeakyReLU / max-pool / clamp decision from its kink over a whole fp64 oracle solver run
+    (every denoiser call of every inner iteration)."""
+    from oracle import pnp_oracle as O
+    probe, keep_f, keep_d = _KinkProbe(), O.F, O.denoise
+    clamp_margin = [float("inf")]
+
+    def denoise_probe(x, sigma, params):
+        N, _, H, W = x.shape
+        pre = O.unet_forward(torch.cat([x, torch.ones(N, 1, H, W, dtype=x.dtype) * sigma.view(N, 1, 1, 1)], 1), params)
+        clamp_margin[0] = min(clamp_margin[0], float(pre.abs().min()), float((pre - 1).abs().min()))
+        return torch.clamp(pre, 0, 1)
+
+    O.F, O.denoise = probe, denoise_probe
+    try:
+        with torch.no_grad():
+            run()
+    finally:
+        O.F, O.denoise = keep_f, keep_d
+    return min(probe.margin, clamp_margin[0])
+
+

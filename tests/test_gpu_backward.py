@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.golden_inputs import denoiser_inputs, csmri_actions
+from tests.golden_inputs import denoiser_inputs, csmri_actions, _KinkProbe, solver_kink_margin, GRAD_CASE
 from tfpnp_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -56,29 +56,6 @@ def oracle_grads(fn, inputs, wts, dtype):
     out = fn(*leaves)
     (out * t(wts).to(dtype)).sum().backward()
     return out.detach(), [l.grad for l in leaves]
-
-
-class _KinkProbe:
-    """Stands in for torch.nn.functional inside the oracle and records how close any LeakyReLU input or max-pool
-    decision comes to its kink, relative to the layer's mean magnitude."""
-
-    def __init__(self):
-        import torch.nn.functional as F
-        self.F, self.margin = F, float("inf")
-
-    def __getattr__(self, name):
-        return getattr(self.F, name)
-
-    def leaky_relu(self, x, slope):
-        self.margin = min(self.margin, float(x.abs().min() / x.abs().mean()))
-        return self.F.leaky_relu(x, slope)
-
-    def max_pool2d(self, x, k):
-        B, C, H, W = x.shape
-        win = x[:, :, :H // 2 * 2, :W // 2 * 2].reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5)
-        top = win.reshape(B, C, H // 2, W // 2, 4).topk(2, dim=-1).values
-        self.margin = min(self.margin, float((top[..., 0] - top[..., 1]).min() / x.abs().mean()))
-        return self.F.max_pool2d(x, k)
 
 
 def kink_margin(oden64, x, s):
@@ -155,28 +132,6 @@ def test_denoiser_vjp_is_linear_and_batch_independent(den):
     assert torch.equal(den(g(x), g(s)), ref)
 
 
-def solver_kink_margin(run):
-    """Smallest distance of any LeakyReLU / max-pool / clamp decision from its kink over a whole fp64 oracle solver run
-    (every denoiser call of every inner iteration)."""
-    from oracle import pnp_oracle as O
-    probe, keep_f, keep_d = _KinkProbe(), O.F, O.denoise
-    clamp_margin = [float("inf")]
-
-    def denoise_probe(x, sigma, params):
-        N, _, H, W = x.shape
-        pre = O.unet_forward(torch.cat([x, torch.ones(N, 1, H, W, dtype=x.dtype) * sigma.view(N, 1, 1, 1)], 1), params)
-        clamp_margin[0] = min(clamp_margin[0], float(pre.abs().min()), float((pre - 1).abs().min()))
-        return torch.clamp(pre, 0, 1)
-
-    O.F, O.denoise = probe, denoise_probe
-    try:
-        with torch.no_grad():
-            run()
-    finally:
-        O.F, O.denoise = keep_f, keep_d
-    return min(probe.margin, clamp_margin[0])
-
-
 def _check(names, got, want64, want32, floor=2e-2):   # floor: see test_denoiser_vjp_vs_oracle_autograd
     for n, a, b64, b32 in zip(names, got, want64, want32):
         e, y = rel(a, b64), rel(b32, b64)
@@ -241,6 +196,38 @@ def test_csmri_solver_gradients(den, oden32, oden64, name, keys):
     # (b) arbitrary inputs
     d, acts, v0 = case(2, 32, 32, 3, 0)
     compare(d, acts, v0, floor=0.25)
+
+
+def test_training_path_vs_reference_autograd_golden(den):
+    """The native training path against gradients computed by the REAL reference under torch.autograd
+    (tests/golden/csmri_grads.npz; generator: oracle/make_goldens.py::gradient_goldens): the fused ADMM VJP on the
+    kink-free case, and d reward / d policy logits through PnPEnv.forward."""
+    from tests.conftest import golden
+    from tfpnp_amd.tasks import csmri
+    C, gold = GRAD_CASE, golden("csmri_grads")
+    sol = csmri.ADMMSolver_CSMRI(den)
+    d = synth.make_csmri_batch(C.B, C.H, C.W, seed=C.data_seed)
+    a = csmri_actions(C.B, C.T, C.action_seed, ("sigma_d", "mu"))
+    v0 = sol.reset({"x0": g(d["x0"])})
+    wts = np.random.RandomState(C.wts_seed).standard_normal(tuple(v0.shape)).astype(np.float32)
+    leaves = [v0.clone().requires_grad_(True), g(a["sigma_d"], True), g(a["mu"], True)]
+    out = sol((leaves[0], (g(d["y0"]), g(d["mask"]))), tuple(leaves[1:]))
+    (out * g(wts)).sum().backward()
+    assert rel(out, t(gold["admm_out"])) < 1e-5
+    for leaf, key in zip(leaves, ("admm_grad_variables", "admm_grad_sigma_d", "admm_grad_mu")):
+        e = rel(leaf.grad, t(gold[key]))
+        print(f"  vs reference autograd {key}: {e:.2e}")
+        assert e < 1e-4, key
+    d2 = synth.make_csmri_batch(C.env_B, C.env_H, C.env_W, seed=C.env_data_seed)
+    env = csmri.CSMRIEnv(None, sol, max_episode_step=6)
+    ob = env.reset({k: g(v) for k, v in d2.items() if isinstance(v, np.ndarray)})
+    raw = g(np.random.RandomState(C.env_raw_seed).standard_normal((C.env_B, 10)).astype(np.float32), True)
+    _, reward = env.forward(ob, {"sigma_d": torch.sigmoid(raw[:, :5]) * 70 / 255, "mu": torch.sigmoid(raw[:, 5:])})
+    reward.sum().backward()
+    assert np.allclose(reward.detach().cpu().numpy(), gold["env_reward"], atol=5e-4)
+    e = rel(raw.grad, t(gold["env_grad_raw"]))
+    print(f"  vs reference autograd d reward / d logits: {e:.2e}")
+    assert e < 5e-3
 
 
 def test_csmri_admm_fused_vjp_vs_composed_autograd(den):

@@ -15,7 +15,7 @@ def t(a):
 
 
 def rel(a, b):
-    a = a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = np.asarray(b)
     return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
 
@@ -138,6 +138,40 @@ def test_env_step(den):
         assert np.array_equal(env.idx_left.numpy(), g[f"idx_left{s}"])
         assert rel(env.state["solver"], g[f"solver{s}"]) < 1e-5
         assert rel(env.state["output"], g[f"output{s}"]) < 1e-5
+
+
+def test_solver_gradients_vs_reference_autograd(den, unet_params):
+    """The oracle under torch.autograd reproduces the REAL reference's gradients through its solver and env
+    (tests/golden/csmri_grads.npz, written by oracle/make_goldens.py running /root/reference under autograd): this is
+    what pins the training-path tests of tests/test_gpu_backward.py, which differentiate the oracle."""
+    from tests.golden_inputs import GRAD_CASE as C, solver_kink_margin
+    g = golden("csmri_grads")
+    d = synth.make_csmri_batch(C.B, C.H, C.W, seed=C.data_seed)
+    a = csmri_actions(C.B, C.T, C.action_seed, ("sigma_d", "mu"))
+    v0 = O.admm_reset(t(d["x0"]))
+    wts = np.random.RandomState(C.wts_seed).standard_normal(tuple(v0.shape)).astype(np.float32)
+    d2 = synth.make_csmri_batch(C.env_B, C.env_H, C.env_W, seed=C.env_data_seed)
+    raw0 = np.random.RandomState(C.env_raw_seed).standard_normal((C.env_B, 10)).astype(np.float32)
+    assert (sha(d["y0"], d["mask"], d["x0"], a["sigma_d"], a["mu"], wts, d2["y0"], raw0) == g["in_sha"]).all()
+    # the case is differentiable with a margin (fp64 oracle): fp32 evaluations cannot disagree about a kink
+    den64 = O.Denoiser(unet_params, dtype=torch.float64)
+    margin = solver_kink_margin(lambda: O.csmri_admm(den64, v0.double(), t(d["y0"]).double(), t(d["mask"]),
+                                                     t(a["sigma_d"]).double(), t(a["mu"]).double()))
+    assert margin > 1e-5, margin
+    leaves = [v0.clone().requires_grad_(True), t(a["sigma_d"]).requires_grad_(True), t(a["mu"]).requires_grad_(True)]
+    out = O.csmri_admm(den, leaves[0], t(d["y0"]), t(d["mask"]), leaves[1], leaves[2])
+    (out * t(wts)).sum().backward()
+    assert rel(out, g["admm_out"]) < 5e-6
+    for leaf, key in zip(leaves, ("admm_grad_variables", "admm_grad_sigma_d", "admm_grad_mu")):
+        assert rel(leaf.grad, g[key]) < 2e-5, key
+    # env.forward: d sum(reward) / d policy logits (arbitrary inputs: a kink decision may flip between two fp32 runs)
+    raw = t(raw0).requires_grad_(True)
+    sg, mu = torch.sigmoid(raw[:, :5]) * 70 / 255, torch.sigmoid(raw[:, 5:])
+    st = O.csmri_admm(den, O.admm_reset(t(d2["x0"])), t(d2["y0"]), t(d2["mask"]), sg, mu)
+    reward = O.torch_psnr(O.complex2real(st[:, :1]), t(d2["gt"])) - O.torch_psnr(t(d2["output"]), t(d2["gt"]))
+    reward.sum().backward()
+    assert np.allclose(reward.detach().numpy(), g["env_reward"], atol=2e-4)
+    assert rel(raw.grad, g["env_grad_raw"]) < 5e-3
 
 
 POLICY_CASES = [("admm", 9, 10, False, (2, 64, 64)), ("admm_rect", 9, 10, False, (1, 96, 128)),

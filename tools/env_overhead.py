@@ -1,0 +1,47 @@
+"""How much of a bench episode is NOT the solver calls?  Times (a) the full env episode of bench.py (reset + 6 x env.step
+with reward all_gather disabled, world 1) and (b) the same 6 solver calls issued back to back on the same data.  GPU box only."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tfpnp_amd import synth
+from tfpnp_amd.pnp import UNetDenoiser2D
+from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI, CSMRIEnv
+
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(a)
+B, H = 48, 256
+den = UNetDenoiser2D(state_dict=synth.make_unet_params(0))
+solver = ADMMSolver_CSMRI(den)
+d = synth.make_csmri_batch(B, H, H, ratio=4, sigma_n=15.0, seed=1234)
+data = {k: t(v).to(dev) for k, v in d.items() if hasattr(v, "dtype")}
+actions = [{k: t(v).to(dev) for k, v in a.items()} for a in synth.make_actions(B, 6, 5)]
+for a in actions:
+    a["idx_stop"] = torch.zeros(B, dtype=torch.int64, device=dev)
+env = CSMRIEnv(None, solver, max_episode_step=6)
+
+
+def episode():
+    env.reset(data)
+    for a in actions:
+        env.step(a)
+
+
+def solver_only():
+    v = solver.reset({"x0": data["x0"]})
+    for a in actions:
+        v = solver((v, (data["y0"], data["mask"])), (a["sigma_d"], a["mu"]))
+    return v
+
+
+def timed(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+with torch.no_grad():
+    for rep in range(2):
+        a, b = timed(episode), timed(solver_only)
+        print(f"env episode {a:8.2f} ms   6 solver calls alone {b:8.2f} ms   env overhead {a - b:6.2f} ms = {100 * (a - b) / a:.2f} %")
