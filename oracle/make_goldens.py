@@ -64,7 +64,56 @@ def gradient_goldens(den):
     _, reward = env.forward(ob, action)
     reward.sum().backward()
     res.update(env_reward=reward.detach(), env_grad_raw=raw.grad)
-    save("csmri_grads", in_sha=sha(d["y0"], d["mask"], d["x0"], a["sigma_d"], a["mu"], wts, d2["y0"], raw0), **res)
+    # the other CS-MRI solvers on arbitrary inputs (B=2, 32x32, T=3: kink decisions may differ between fp32 evaluations)
+    d3 = synth.make_csmri_batch(2, 32, 32, seed=71)
+    for name, cls, keys in (("hqs", cs.HQSSolver_CSMRI, ("sigma_d", "mu")), ("pg", cs.PGSolver_CSMRI, ("sigma_d", "tau")),
+                            ("apg", cs.APGSolver_CSMRI, ("sigma_d", "tau", "beta")),
+                            ("redadmm", cs.REDADMMSolver_CSMRI, ("sigma_d", "mu", "lamda"))):
+        a3 = csmri_actions(2, 3, 72, keys)       # drawn per solver, as tests/test_gpu_backward.py does
+        if "beta" in a3:
+            a3["beta"] = (0.3 * a3["beta"]).astype(np.float32)
+        s_ = cls(den)
+        with torch.no_grad():
+            v = s_.reset({"x0": t(d3["x0"])})
+        w = np.random.RandomState(73).standard_normal(tuple(v.shape)).astype(np.float32)
+        lv = [v.clone().requires_grad_(True)] + [t(a3[k]).requires_grad_(True) for k in keys]
+        o = s_((lv[0], (t(d3["y0"]), t(d3["mask"]))), tuple(lv[1:]))
+        (o * t(w)).sum().backward()
+        res[f"{name}_out"] = o.detach()
+        for k_, l_ in zip(("variables",) + keys, lv):
+            res[f"{name}_grad_{k_}"] = l_.grad
+    # phase retrieval and single-photon imaging (inputs of tests/test_gpu_backward.py::test_pr_/test_spi_solver_gradients)
+    pr = ref_shim.load_task_module("pr", "solver")
+    dp = synth.make_pr_batch(2, 32, 32, S=4, alpha=9.0, seed=75)
+    ap = csmri_actions(2, 3, 76, ("sigma_d", "mu", "tau"))
+    ap["tau"] = (ap["tau"] * 0.5).astype(np.float32)
+    sp = pr.IADMMSolver_PR(den)
+    with torch.no_grad():
+        v = sp.reset({"x0": t(dp["x0"])})
+    w = np.random.RandomState(77).standard_normal(tuple(v.shape)).astype(np.float32)
+    lv = [v.clone().requires_grad_(True)] + [t(ap[k]).requires_grad_(True) for k in ("sigma_d", "mu", "tau")]
+    o = sp((lv[0], (t(dp["y0"]), t(dp["mask"]))), tuple(lv[1:]))
+    (o * t(w)).sum().backward()
+    res["pr_out"] = o.detach()
+    for k_, l_ in zip(("variables", "sigma_d", "mu", "tau"), lv):
+        res[f"pr_grad_{k_}"] = l_.grad
+    spi = ref_shim.load_task_module("spi", "solver")
+    ds = synth.make_spi_batch(2, 32, 32, K=6, seed=78)
+    rs = np.random.RandomState(79)
+    sg = rs.uniform(15 / 255.0, 70 / 255.0, (2, 1)).astype(np.float32)
+    m = rs.uniform(50, 120, (2, 1)).astype(np.float32)
+    ss = spi.ADMMSolver_SPI(den)
+    with torch.no_grad():
+        v = ss.reset({"x0": t(ds["x0"])}).numpy().copy()
+    v[:, 2] = 0.02 * rs.standard_normal(v[:, 2].shape).astype(np.float32)
+    w = rs.standard_normal(v.shape).astype(np.float32)
+    lv = [t(v).requires_grad_(True), t(sg).requires_grad_(True), t(m).requires_grad_(True)]
+    o = ss((lv[0], (t(ds["x0"]), t(ds["K"]))), (lv[1], lv[2]))
+    (o * t(w)).sum().backward()
+    res["spi_out"] = o.detach()
+    for k_, l_ in zip(("variables", "sigma_d", "mu"), lv):
+        res[f"spi_grad_{k_}"] = l_.grad if l_.grad is not None else torch.zeros_like(l_)
+    save("solver_grads", in_sha=sha(d["y0"], d["mask"], d["x0"], a["sigma_d"], a["mu"], wts, d2["y0"], raw0), **res)
 
 
 def main():

@@ -105,7 +105,7 @@ def ellipse_sinogram(ells, angles, det):
 
 # ------------------------------------------------------------------ gradient cases
 class GRAD_CASE:
-    """The CS-MRI ADMM case whose gradients are pinned to the real reference's autograd (tests/golden/csmri_grads.npz):
+    """The CS-MRI ADMM case whose gradients are pinned to the real reference's autograd (tests/golden/solver_grads.npz):
     B=1, 16x16, T=2 -- picked by the kink-margin search of tests/test_gpu_backward.py::test_csmri_solver_gradients
     (try k=1: no LeakyReLU / max-pool / clamp decision of either denoiser call within 1e-5 of its kink, re-checked by
     tests/test_oracle_golden.py), so that fp32 evaluations agree to rounding."""

@@ -196,15 +196,26 @@ def test_csmri_solver_gradients(den, oden32, oden64, name, keys):
     # (b) arbitrary inputs
     d, acts, v0 = case(2, 32, 32, 3, 0)
     compare(d, acts, v0, floor=0.25)
+    if name != "admm":    # (c) the same arbitrary case against the REAL reference's autograd (tests/golden/solver_grads.npz)
+        from tests.conftest import golden
+        gold = golden("solver_grads")
+        leaves = [g(v0, True)] + [g(p, True) for p in acts]
+        out = sol((leaves[0], (g(d["y0"]), g(d["mask"]))), tuple(leaves[1:]))
+        (out * g(np.random.RandomState(73).standard_normal(v0.shape).astype(np.float32))).sum().backward()
+        assert rel(out, t(gold[name + "_out"])) < 1e-4
+        for key, leaf in zip(("variables",) + tuple(keys), leaves):
+            e = rel(leaf.grad, t(gold[f"{name}_grad_{key}"]))
+            print(f"  {name} vs reference autograd d/d{key}: {e:.2e}")
+            assert e < 0.25, key          # kink-flip bound of (b); a structural error is O(1)
 
 
 def test_training_path_vs_reference_autograd_golden(den):
     """The native training path against gradients computed by the REAL reference under torch.autograd
-    (tests/golden/csmri_grads.npz; generator: oracle/make_goldens.py::gradient_goldens): the fused ADMM VJP on the
+    (tests/golden/solver_grads.npz; generator: oracle/make_goldens.py::gradient_goldens): the fused ADMM VJP on the
     kink-free case, and d reward / d policy logits through PnPEnv.forward."""
     from tests.conftest import golden
     from tfpnp_amd.tasks import csmri
-    C, gold = GRAD_CASE, golden("csmri_grads")
+    C, gold = GRAD_CASE, golden("solver_grads")
     sol = csmri.ADMMSolver_CSMRI(den)
     d = synth.make_csmri_batch(C.B, C.H, C.W, seed=C.data_seed)
     a = csmri_actions(C.B, C.T, C.action_seed, ("sigma_d", "mu"))
@@ -363,6 +374,13 @@ def test_pr_solver_gradients(den, oden32, oden64):
     assert rel(out, out64) < 1e-4
     (out * g(wts)).sum().backward()
     _check(["variables", "sigma_d", "mu", "tau"], [l.grad for l in leaves], g64, g32)
+    from tests.conftest import golden      # and against the REAL reference's autograd on the same inputs
+    gold = golden("solver_grads")
+    assert rel(out, t(gold["pr_out"])) < 1e-4
+    for key, leaf in zip(("variables", "sigma_d", "mu", "tau"), leaves):
+        e = rel(leaf.grad, t(gold[f"pr_grad_{key}"]))
+        print(f"  pr vs reference autograd d/d{key}: {e:.2e}")
+        assert e < 2e-2, key
 
 
 def test_spi_solver_gradients(den, oden32):
@@ -387,6 +405,16 @@ def test_spi_solver_gradients(den, oden32):
     for n, a_, b_ in zip(["variables", "sigma_d", "mu"], [l.grad for l in leaves], g32):
         print(f"  spi d/d{n}: {rel(a_, b_):.2e}")
         assert rel(a_, b_) < 2e-2, n
+    from tests.conftest import golden      # and against the REAL reference's autograd on the same inputs
+    gold = golden("solver_grads")
+    for n, leaf in zip(["variables", "sigma_d", "mu"], leaves):
+        ref = t(gold[f"spi_grad_{n}"])
+        if float(ref.abs().max()) == 0.0:      # the bisection prox carries no gradient wrt mu in the reference either
+            assert leaf.grad is None or float(leaf.grad.abs().max()) == 0.0, n
+            continue
+        e = rel(leaf.grad, ref)
+        print(f"  spi vs reference autograd d/d{n}: {e:.2e}")
+        assert e < 2e-2, n
 
 
 def test_ct_solver_gradients(den, oden32, oden64, monkeypatch):

@@ -142,10 +142,10 @@ def test_env_step(den):
 
 def test_solver_gradients_vs_reference_autograd(den, unet_params):
     """The oracle under torch.autograd reproduces the REAL reference's gradients through its solver and env
-    (tests/golden/csmri_grads.npz, written by oracle/make_goldens.py running /root/reference under autograd): this is
+    (tests/golden/solver_grads.npz, written by oracle/make_goldens.py running /root/reference under autograd): this is
     what pins the training-path tests of tests/test_gpu_backward.py, which differentiate the oracle."""
     from tests.golden_inputs import GRAD_CASE as C, solver_kink_margin
-    g = golden("csmri_grads")
+    g = golden("solver_grads")
     d = synth.make_csmri_batch(C.B, C.H, C.W, seed=C.data_seed)
     a = csmri_actions(C.B, C.T, C.action_seed, ("sigma_d", "mu"))
     v0 = O.admm_reset(t(d["x0"]))
@@ -172,6 +172,44 @@ def test_solver_gradients_vs_reference_autograd(den, unet_params):
     reward.sum().backward()
     assert np.allclose(reward.detach().numpy(), g["env_reward"], atol=2e-4)
     assert rel(raw.grad, g["env_grad_raw"]) < 5e-3
+    # the other CS-MRI solvers, phase retrieval and single-photon imaging on arbitrary inputs: same fp32 CPU operations
+    # in the same order as the reference, so kink decisions coincide and the agreement is at rounding level
+    d3 = synth.make_csmri_batch(2, 32, 32, seed=71)
+    x0 = t(d3["x0"])
+    inits = {"hqs": torch.cat([x0, x0], 1), "pg": x0, "apg": torch.cat([x0, x0], 1), "redadmm": O.admm_reset(x0)}
+
+    def check(name, fn, v, params, keys, seed_or_w):
+        w = seed_or_w if isinstance(seed_or_w, np.ndarray) else \
+            np.random.RandomState(seed_or_w).standard_normal(tuple(v.shape)).astype(np.float32)
+        lv = [v.clone().requires_grad_(True)] + [t(p).requires_grad_(True) for p in params]
+        o = fn(*lv)
+        (o * t(w)).sum().backward()
+        assert rel(o, g[name + "_out"]) < 5e-6, name
+        for k, l in zip(("variables",) + keys, lv):
+            ref = g[f"{name}_grad_{k}"]
+            got = l.grad if l.grad is not None else torch.zeros_like(l)
+            assert rel(got, ref) < 1e-5 or float(np.abs(ref).max()) == 0.0 == float(got.abs().max()), (name, k)
+
+    for name, keys in (("hqs", ("sigma_d", "mu")), ("pg", ("sigma_d", "tau")), ("apg", ("sigma_d", "tau", "beta")),
+                       ("redadmm", ("sigma_d", "mu", "lamda"))):
+        a3 = csmri_actions(2, 3, 72, keys)
+        if "beta" in a3:
+            a3["beta"] = (0.3 * a3["beta"]).astype(np.float32)
+        check(name, lambda v, *p, n=name: getattr(O, "csmri_" + n)(den, v, t(d3["y0"]), t(d3["mask"]), *p), inits[name],
+              [a3[k] for k in keys], keys, 73)
+    dp = synth.make_pr_batch(2, 32, 32, S=4, alpha=9.0, seed=75)
+    ap = csmri_actions(2, 3, 76, ("sigma_d", "mu", "tau"))
+    ap["tau"] = (ap["tau"] * 0.5).astype(np.float32)
+    check("pr", lambda v, *p: O.pr_iadmm(den, v, t(dp["y0"]), t(dp["mask"]), *p), O.pr_reset(t(dp["x0"])),
+          [ap[k] for k in ("sigma_d", "mu", "tau")], ("sigma_d", "mu", "tau"), 77)
+    ds = synth.make_spi_batch(2, 32, 32, K=6, seed=78)
+    rs = np.random.RandomState(79)
+    sg = rs.uniform(15 / 255.0, 70 / 255.0, (2, 1)).astype(np.float32)
+    m = rs.uniform(50, 120, (2, 1)).astype(np.float32)
+    v = O.spi_reset(t(ds["x0"])).numpy().copy() if hasattr(O, "spi_reset") else O.admm_reset(t(ds["x0"])).numpy().copy()
+    v[:, 2] = 0.02 * rs.standard_normal(v[:, 2].shape).astype(np.float32)
+    w = rs.standard_normal(v.shape).astype(np.float32)
+    check("spi", lambda v_, s_, m_: O.spi_admm(den, v_, t(ds["x0"]), t(ds["K"]), s_, m_), t(v), [sg, m], ("sigma_d", "mu"), w)
 
 
 POLICY_CASES = [("admm", 9, 10, False, (2, 64, 64)), ("admm_rect", 9, 10, False, (1, 96, 128)),
