@@ -35,6 +35,42 @@ def save(name, **kw):
     print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KB)")
 
 
+def env_goldens(den):
+    """(10) the other task environments (tasks/pr/env.py, tasks/spi/env.py, tasks/ct/env.py) run by the real reference:
+    reset -> policy observation -> two env steps with one item stopping (PR, SPI); CT: reset + observation layout only
+    (its solver needs torch_radon, which is not installed -- the environment class itself does not)."""
+    from tests.golden_inputs import env_case
+    out = {}
+    with torch.no_grad():
+        for task, solver_cls in (("pr", "IADMMSolver_PR"), ("spi", "ADMMSolver_SPI")):
+            sol_mod = ref_shim.load_task_module(task, "solver")
+            env_mod = ref_shim.load_task_module(task, "env")
+            data, acts = env_case(task)
+            env = getattr(env_mod, {"pr": "PREnv", "spi": "SPIEnv"}[task])(None, getattr(sol_mod, solver_cls)(den),
+                                                                             max_episode_step=3)
+            ob = env.reset(data={k: t(v).clone() for k, v in data.items()})
+            out[f"{task}_policy_ob_reset"] = env.get_policy_ob(ob)
+            for s, a in enumerate(acts):
+                action = {k: (torch.from_numpy(v) if k == "idx_stop" else t(v)) for k, v in a.items()}
+                ob, ob_masked, reward, all_done, info = env.step(action)
+                out[f"{task}_policy_ob{s}"] = env.get_policy_ob(ob)
+                out[f"{task}_policy_ob_masked_shape{s}"] = np.array(env.get_policy_ob(ob_masked).shape)
+                out[f"{task}_reward{s}"] = reward
+                out[f"{task}_done{s}"] = info["done"]
+                out[f"{task}_solver{s}"] = env.state["solver"].clone()
+                out[f"{task}_output{s}"] = env.state["output"].clone()
+                out[f"{task}_idx_left{s}"] = env.idx_left.clone()
+        # CT: observation packing of a freshly reset environment, with the solver-independent IADMM state packing
+        from tfpnp.pnp.solver.base import IADMMSolver
+        env_mod = ref_shim.load_task_module("ct", "env")
+        data, _ = env_case("ct")
+        env = env_mod.CTEnv(None, IADMMSolver(den), max_episode_step=3)
+        ob = env.reset(data={k: t(v).clone() for k, v in data.items()})
+        out["ct_policy_ob_reset"] = env.get_policy_ob(ob)
+        out["ct_variables_reset"] = ob.variables
+    save("env_other_tasks", **out)
+
+
 def gradient_goldens(den):
     """(9) the reference's OWN autograd through its solver and env (the training path, tfpnp/env/base.py:193-206 called
     from trainer/mddpg/trainer.py:171-192): d sum(out * wts) / d (variables, sigma_d, mu) of ADMMSolver_CSMRI.forward on
@@ -121,10 +157,14 @@ def main():
     ref_shim.install()
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    if "--only-grads" in sys.argv:
+    if "--only-grads" in sys.argv or "--only-envs" in sys.argv:
         den = ref_shim.make_denoiser(synth.make_unet_params(WEIGHT_SEED), tempfile.mkdtemp())
-        print("[9] gradients")
-        gradient_goldens(den)
+        if "--only-grads" in sys.argv:
+            print("[9] gradients")
+            gradient_goldens(den)
+        if "--only-envs" in sys.argv:
+            print("[10] PR / SPI / CT environments")
+            env_goldens(den)
         return
     from tfpnp.utils import transforms as T
     from tfpnp.pnp.denoiser.models.unet import UNet
@@ -307,6 +347,8 @@ def main():
         save("policy_rollout_csmri", **ro)
     print("[9] gradients")
     gradient_goldens(den)
+    print("[10] PR / SPI / CT environments")
+    env_goldens(den)
     print("done")
 
 

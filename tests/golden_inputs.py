@@ -161,3 +161,40 @@ def solver_kink_margin(run):
     return min(probe.margin, clamp_margin[0])
 
 
+
+
+def env_case(task):
+    """Inputs of the PR / SPI / CT environment fixtures (tests/golden/env_other_tasks.npz): (data dict, list of actions).
+    3 items, max_episode_step 3; step 0 stops item 1, step 1 stops the first of the two remaining items."""
+    B, H, W = 3, 32, 32
+    rs = np.random.RandomState({"pr": 401, "spi": 402, "ct": 403}[task])
+    stops = [np.array([0, 1, 0]), np.array([1, 0])]
+    if task == "pr":
+        d = synth.make_pr_batch(B, H, W, S=4, alpha=9.0, seed=411)
+        d["sigma_n"] = (np.ones((B, 1, H, W)) * rs.uniform(0.02, 0.2, (B, 1, 1, 1))).astype(np.float32)
+        acts = []
+        for s, stop in enumerate(stops):
+            a = csmri_actions(len(stop), 2, 412 + s, ("sigma_d", "mu", "tau"))
+            a["tau"] = (0.5 * a["tau"]).astype(np.float32)
+            a["idx_stop"] = stop
+            acts.append(a)
+        return d, acts
+    if task == "spi":
+        d = synth.make_spi_batch(B, H, W, K=6, seed=421)
+        acts = []
+        for s, stop in enumerate(stops):
+            n = len(stop)
+            acts.append({"sigma_d": rs.uniform(15 / 255.0, 70 / 255.0, (n, 1)).astype(np.float32),
+                         "mu": rs.uniform(50, 120, (n, 1)).astype(np.float32), "idx_stop": stop})
+        return d, acts
+    if task == "ct":
+        V, det = 20, 47
+        d = {"gt": rs.uniform(0, 1, (B, 1, H, W)).astype(np.float32),
+             "y0": rs.uniform(0, 5, (B, 1, V, det)).astype(np.float32),
+             "ATy0": rs.uniform(0, 1, (B, 1, H, W)).astype(np.float32),
+             "view": np.full((B, 1, H, W), V / 120.0, np.float32),
+             "sigma_n": (np.ones((B, 1, H, W)) * rs.uniform(0.01, 0.1, (B, 1, 1, 1))).astype(np.float32)}
+        d["x0"] = d["ATy0"].copy()
+        d["output"] = d["ATy0"].copy()
+        return d, []
+    raise KeyError(task)

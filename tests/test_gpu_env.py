@@ -100,3 +100,45 @@ def test_env_step_has_one_host_read(unet_params):
         assert ob.variables.shape[0] == n and ob_masked.variables.shape[0] == len(live) and pol.shape[0] == len(live)
         assert isinstance(all_done, bool) and all_done == (len(live) == 0 or s == 3)
         assert reward.shape == (B, 1) and torch.isfinite(reward).all()
+
+
+@pytest.mark.parametrize("task", ["pr", "spi", "ct"])
+def test_other_task_envs_vs_reference_golden(unet_params, task):
+    """PREnv / SPIEnv / CTEnv (tasks/{pr,spi,ct}/env.py) against the REAL reference's environments on the same inputs
+    (tests/golden/env_other_tasks.npz, oracle/make_goldens.py::env_goldens): observation packing after reset and, for PR
+    and SPI, two env steps in which items stop -- policy observation of the rows that were live, reward, done flags,
+    written-back solver state / output and the surviving row list."""
+    from tests.conftest import golden
+    from tests.golden_inputs import env_case
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.pnp.solver.base import IADMMSolver
+    from tfpnp_amd.tasks import pr, spi, ct
+    gold = golden("env_other_tasks")
+    den = UNetDenoiser2D(state_dict=unet_params)
+    data, acts = env_case(task)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    rel = lambda a, b: float((a.double().cpu() - torch.from_numpy(b).double()).norm() / max(float(torch.from_numpy(b).double().norm()), 1e-30))
+    env = {"pr": lambda: pr.PREnv(None, pr.IADMMSolver_PR(den), max_episode_step=3),
+           "spi": lambda: spi.SPIEnv(None, spi.ADMMSolver_SPI(den), max_episode_step=3),
+           "ct": lambda: ct.CTEnv(None, IADMMSolver(den), max_episode_step=3)}[task]()
+    ob = env.reset({k: t(v) for k, v in data.items()})
+    pob = env.get_policy_ob(ob)
+    assert tuple(pob.shape) == gold[f"{task}_policy_ob_reset"].shape
+    assert rel(pob, gold[f"{task}_policy_ob_reset"]) < 1e-6
+    if task == "ct":
+        assert rel(ob.variables, gold["ct_variables_reset"]) == 0.0
+        return
+    # SPI: the 10-step Poisson bisection is discontinuous (one quantum = 1.1 / 2**10 per flipped bracket), see
+    # test_gpu_parity.py::test_spi_golden; PR is smooth
+    tol_state, tol_ob, tol_reward = (1e-4, 1e-4, 2e-3) if task == "pr" else (5e-3, 5e-3, 5e-2)
+    for s, a in enumerate(acts):
+        action = {k: (torch.from_numpy(v).to(dev()) if k == "idx_stop" else t(v)) for k, v in a.items()}
+        ob, ob_masked, reward, all_done, info = env.step(action)
+        assert rel(env.get_policy_ob(ob), gold[f"{task}_policy_ob{s}"]) < tol_ob
+        assert tuple(env.get_policy_ob(ob_masked).shape) == tuple(gold[f"{task}_policy_ob_masked_shape{s}"])
+        assert np.allclose(reward.cpu().numpy(), gold[f"{task}_reward{s}"], atol=tol_reward)
+        assert np.array_equal(info["done"].cpu().numpy(), gold[f"{task}_done{s}"])
+        assert rel(env.state["solver"], gold[f"{task}_solver{s}"]) < tol_state
+        assert rel(env.state["output"], gold[f"{task}_output{s}"]) < tol_state
+        assert np.array_equal(env.idx_left.cpu().numpy(), gold[f"{task}_idx_left{s}"])
+        assert not all_done
