@@ -349,3 +349,51 @@ def test_solver_call_is_hipgraph_capturable(den):
         torch.cuda.synchronize()
         assert torch.equal(out, sol((v0, (y0, m)), (sg, mu)))
     den.context(dev()).status()
+
+
+@pytest.mark.parametrize("B,H,W,S,T", [(3, 48, 80, 3, 2), (1, 50, 39, 5, 2), (5, 16, 16, 1, 3)])
+def test_pr_ragged_sizes_vs_oracle(den, oden, B, H, W, S, T):
+    """IADMMSolver_PR on non-square / non-power-of-two images and mask counts other than 4 (mixed-radix FFT passes,
+    arbitrary S in the CDP reductions), every item against the CPU oracle."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import pr
+    d = synth.make_pr_batch(B, H, W, S=S, alpha=9.0, seed=500 + H)
+    a = csmri_actions(B, T, 501 + H, ("sigma_d", "mu", "tau"))
+    a["tau"] = (0.5 * a["tau"]).astype(np.float32)
+    sol = pr.IADMMSolver_PR(den)
+    st = sol((sol.reset({"x0": g(d["x0"])}), (g(d["y0"]), g(d["mask"]))), (g(a["sigma_d"]), g(a["mu"]), g(a["tau"])))
+    ref = O.pr_iadmm(oden, O.pr_reset(t(d["x0"])), t(d["y0"]), t(d["mask"]), t(a["sigma_d"]), t(a["mu"]), t(a["tau"]))
+    assert st.shape == ref.shape and rel(st, ref) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,K", [(3, 48, 80, 4), (2, 64, 40, 8), (1, 18, 30, 6)])
+def test_spi_ragged_sizes_and_K_vs_oracle(den, oden, B, H, W, K):
+    """ADMMSolver_SPI with K in {4, 6, 8} on non-square images: one iteration (the bisection prox is discontinuous, see
+    test_spi_golden), every item against the CPU oracle."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import spi
+    d = synth.make_spi_batch(B, H, W, K=K, seed=600 + K)
+    rs = np.random.RandomState(601 + K)
+    sg = rs.uniform(15 / 255.0, 70 / 255.0, (B, 1)).astype(np.float32)
+    m = rs.uniform(50, 120, (B, 1)).astype(np.float32)
+    sol = spi.ADMMSolver_SPI(den)
+    st = sol((sol.reset({"x0": g(d["x0"])}), (g(d["x0"]), g(d["K"]))), (g(sg), g(m)))
+    ref = O.spi_admm(oden, O.admm_reset(t(d["x0"])), t(d["x0"]), t(d["K"]), t(sg), t(m))
+    assert st.shape == ref.shape and rel(st, ref) < 5e-4
+
+
+@pytest.mark.parametrize("name,keys", [("hqs", ("sigma_d", "mu")), ("pg", ("sigma_d", "tau")),
+                                       ("apg", ("sigma_d", "tau", "beta")), ("redadmm", ("sigma_d", "mu", "lamda"))])
+def test_csmri_other_solvers_ragged_vs_oracle(den, oden, name, keys):
+    """HQS / PG / APG / RED-ADMM on a non-power-of-two rectangle with iter_num < action_pack, against the CPU oracle."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.tasks import csmri
+    B, H, W, T = 3, 48, 80, 4
+    d = synth.make_csmri_batch(B, H, W, seed=700)
+    a = csmri_actions(B, T + 1, 701, keys)
+    sol = {"hqs": csmri.HQSSolver_CSMRI, "pg": csmri.PGSolver_CSMRI, "apg": csmri.APGSolver_CSMRI,
+           "redadmm": csmri.REDADMMSolver_CSMRI}[name](den)
+    v0 = sol.reset({"x0": g(d["x0"])})
+    st = sol((v0, (g(d["y0"]), g(d["mask"]))), tuple(g(a[k]) for k in keys), iter_num=T)
+    ref = getattr(O, "csmri_" + name)(oden, t(v0.cpu().numpy()), t(d["y0"]), t(d["mask"]), *[t(a[k][:, :T]) for k in keys])
+    assert rel(st, ref) < 1e-4
