@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-batch-table", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="KEY=VALUE",
+                    help="pnpx_ctx_set_option on the denoiser context (A/B experiments, e.g. fuse_up=0)")
     args = ap.parse_args()
 
     rank, world, local_rank = D.init_from_env()
@@ -99,6 +101,8 @@ def main():
     actions = [{k: t(v).to(dev) for k, v in a.items()} for a in synth.make_actions(B, N_POLICY_STEPS, ACTION_PACK)]
     for a in actions:
         a["idx_stop"] = torch.zeros(B, dtype=torch.int64, device=dev)
+    for kv in args.ctx_option:
+        den.context(dev).set_option(kv.split("=")[0], int(kv.split("=")[1]))
     den.context(dev).reserve(B, H, W)
     env = CSMRIEnv(None, solver, max_episode_step=N_POLICY_STEPS)
 

@@ -60,6 +60,10 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *      0: off.
  *  "train_cache_gb" (default 96): device-memory budget of the training path's activation cache (see
  *      pnpx_csmri_admm_train); 0 releases it and makes every backward re-compute.
+ *  "fuse_up" (default 0): 1 = the full-resolution decoder entry (96 -> 32 channels) up-samples its low-resolution source
+ *      inside the convolution kernel (four producer waves per workgroup interpolate each K-chunk's halo into LDS), so the
+ *      largest up-sampled tensor never exists in HBM.  Same arithmetic (per-call difference 1.4e-7), +1.7 % iterations/s;
+ *      off by default because it moves the up-sampling time into the convolution launches the roofline is quoted on.
  *  "subbatch" (images per level-0 sub-batch, 0 = whole batch), "fuse_pool", "fuse_outc" (0/1): diagnostics. */
 int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value);
 int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value);

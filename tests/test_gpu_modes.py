@@ -99,6 +99,40 @@ def test_csmri_episode_drift_not_worse_than_fp32(unet_params):
         assert e < 1e-4 and e < 2.0 * e_cpu32 + 1e-5
 
 
+def test_fused_upsample_option_matches_separate_kernel(unet_params):
+    """Option fuse_up = 1 (producer waves of the conv kernel interpolate the full-resolution decoder entry's second source
+    on the fly, conv_hs_kernel.h UPS): same arithmetic as the separate up-sampling kernel -- per call and over a
+    5-iteration solver call -- at even sizes, silently the separate kernel at sizes the fused instance does not cover,
+    deterministic, and within the golden tolerance of the oracle."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
+    den = UNetDenoiser2D(state_dict=unet_params)
+    ctx = den.context(dev())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    try:
+        for (B, H, W) in [(2, 64, 64), (3, 48, 80), (2, 256, 256), (2, 50, 39), (5, 128, 96)]:
+            x = torch.rand(B, 1, H, W, device=dev(), generator=torch.Generator(dev()).manual_seed(H + W))
+            s = torch.full((B,), 0.08, device=dev())
+            ctx.set_option("fuse_up", 0)
+            ref = den(x, s).clone()
+            ctx.set_option("fuse_up", 1)
+            out = den(x, s).clone()
+            assert rel(out, ref) < 1e-6 and torch.equal(out, den(x, s))
+        oden = O.Denoiser(unet_params)
+        d = synth.make_csmri_batch(2, 64, 64, ratio=4, seed=41)
+        a = synth.make_actions(2)[0]
+        sol = ADMMSolver_CSMRI(den)
+        v0 = sol.reset({"x0": t(d["x0"])})
+        got = sol((v0, (t(d["y0"]), t(d["mask"]))), (t(a["sigma_d"]), t(a["mu"])))
+        c = lambda k: torch.from_numpy(np.ascontiguousarray(d[k]))
+        want = O.csmri_admm(oden, O.admm_reset(c("x0")), c("y0"), c("mask"), torch.from_numpy(a["sigma_d"]),
+                            torch.from_numpy(a["mu"]))
+        assert rel(got.cpu(), want) < 1e-5
+    finally:
+        ctx.set_option("fuse_up", 0)
+
+
 def _hot_params(unet_params, scale=3e3):
     """The synthetic UNet with its first convolution scaled up so that activations leave the f16 hi/lo range (|v| >= 4095)."""
     p = {k: np.array(v, copy=True) for k, v in unet_params.items()}

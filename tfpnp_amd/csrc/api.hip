@@ -194,6 +194,10 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_fuse_first = value;
     return PNPX_OK;
   }
+  if (is("fuse_up") && (value == 0 || value == 1)) {
+    ctx->opt_fuse_up = value;
+    return PNPX_OK;
+  }
   if (is("range_guard") && value >= 0 && value <= 2) {   // also re-arms a tripped guard
     PNPX_HIP(hipDeviceSynchronize());
     ctx->opt_range_guard = value;
@@ -223,6 +227,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fuse_pool")) *value = ctx->opt_fuse_pool;
   else if (is("fuse_outc")) *value = ctx->opt_fuse_outc;
   else if (is("fuse_first")) *value = ctx->opt_fuse_first;
+  else if (is("fuse_up")) *value = ctx->opt_fuse_up;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
   else if (is("train_cache_gb")) *value = ctx->opt_train_cache_gb;
   else {

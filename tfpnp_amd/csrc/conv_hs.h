@@ -55,6 +55,9 @@ struct ConvHsArgs {
   unsigned long long* trace;   // HS_TRACE builds: s_memtime stamps of workgroup 0 / wave 0 (null otherwise)
   int abl;                     // PNPX_TUNING builds: ablation bits (1 = drop the record stores, 2 = skip the epilogue, 4 / 8 = planar-layout addressing of loads / stores)
   int w_mt;                    // cout tile the weights were PACKED for (64 while a 32-cout instance runs: "half tiles")
+  // fused bilinear x2 (UPS instance): in1 is the low-resolution tensor [B][G1][ups_h+2][ups_w+2], H = 2*ups_h, W = 2*ups_w
+  int ups_h, ups_w;
+  float ups_sy, ups_sx;        // (h-1)/(2h-1), (w-1)/(2w-1): align_corners=True source step
 };
 
 int conv_hs_mt(int cout);
@@ -70,7 +73,11 @@ struct ConvHsFuse {       // optional fused work
   float slope = 0.2f;           // in [0, 1]: 1.0 = linear epilogue, 0.0 = ReLU
   const char* res = nullptr;    // out = act(conv + bias + res)
   unsigned* range_flag = nullptr;   // set to 1 by the kernel when a stored value leaves the f16 range (|v| >= 4095) or is NaN
+  // fused bilinear x2: `in1` of launch_conv_hs is the LOW-resolution tensor (ups_h x ups_w) and is up-sampled on the fly
+  // (cout == 32 layers with G0 >= 4 only: conv_hs_can_fuse_upsample)
+  int ups_h = 0, ups_w = 0;
 };
+bool conv_hs_can_fuse_upsample(const ConvLayerHs& L, int G0, int G1, int H, int W);
 // true when launch_conv_hs will honour ConvHsFuse::pool_out for this geometry
 bool conv_hs_can_pool(int H, int W);
 int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in1, int G1, char* out, int B, int H,

@@ -130,6 +130,21 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
 #endif
   a.tilesX = a.tilesY = 0;
   a.B = B;
+  a.ups_h = a.ups_w = 0;
+  a.ups_sy = a.ups_sx = 0.f;
+  if (fuse.ups_h) {   // fused bilinear x2 of the second source: one instance, picked here
+    if (!conv_hs_can_fuse_upsample(L, G0, G1, H, W) || fuse.ups_h * 2 != H || fuse.ups_w * 2 != W || !in1 || fuse.pool_out ||
+        fuse.outc_w || fuse.dmask || fuse.res) {
+      set_error("conv_hs: fused up-sampling is not available for this layer / geometry");
+      return PNPX_ERR_SHAPE;
+    }
+    a.pool_out = nullptr;
+    a.ups_h = fuse.ups_h;
+    a.ups_w = fuse.ups_w;
+    a.ups_sy = (H > 1) ? (float)(fuse.ups_h - 1) / (float)(H - 1) : 0.f;
+    a.ups_sx = (W > 1) ? (float)(fuse.ups_w - 1) / (float)(W - 1) : 0.f;
+    return launch_hs_cfg<32, 2, 32, 8, EPI_ACT, 1>(a, B, s);
+  }
   if (L.mt != 64 && L.mt != 32) {
     set_error("conv_hs: no kernel for mt=%d", L.mt);
     return PNPX_ERR_SHAPE;
@@ -153,6 +168,11 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   if (a.outc_w) return launch_hs_mt<32, EPI_OUTC>(a, B, s);
   if (mt_run == 64) return launch_hs_mt<64, EPI_ACT>(a, B, s);
   return launch_hs_mt<32, EPI_ACT>(a, B, s);
+}
+
+// The fused bilinear x2 instance: 32 output channels, 32-pixel-wide blocks, the first two K-chunks from the skip source.
+bool conv_hs_can_fuse_upsample(const ConvLayerHs& L, int G0, int G1, int H, int W) {
+  return L.mt == 32 && L.cout == 32 && G0 >= 4 && !(G0 & 1) && G1 >= 2 && !(G1 & 1) && W >= 32 && !(H & 1) && !(W & 1);
 }
 
 // ---- host-side weight packing -------------------------------------------------------------------------

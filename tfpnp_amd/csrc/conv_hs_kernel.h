@@ -10,6 +10,7 @@
 
 #include "common.h"
 #include "conv_hs.h"
+#include "hs_rec.h"
 
 namespace pnpx {
 
@@ -91,9 +92,34 @@ __device__ __forceinline__ void wait_vmcnt() {
 // a finished tile are never waited for: the wait in front of a step's barrier is a COUNTED vmcnt that covers only
 // the LDS-DMA of that step (issued before the stores; the counter retires in order), so the stores drain while the
 // next tile is multiplied.
-template <int MT, int NBW, int MBW, int NW, int EPI>
-__global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) {
+//
+// UPS = 1 ("fused bilinear x2"): the second source `in1` is the LOW-resolution tensor (a.ups_h x a.ups_w) and the
+// workgroup carries four extra PRODUCER waves (one per SIMD, VALU only) that interpolate the halo of every K-chunk taken
+// from it straight into the LDS stage (align_corners=True, ATen's association -- what upsample2x_hs_kernel writes to
+// memory otherwise): the up-sampled tensor is never written to or read from HBM.  Three low-resolution windows LR[3] are
+// in flight; in step s the producers (A) start the LDS-DMA of the window of step s+3 into LR[s % 3], (B) convert the
+// window of step s+2 (landed: every wave waits for its own DMA in front of the step's barrier) from hi/lo records to
+// fp32 IN PLACE (32 bytes either way: each source record is unpacked once instead of once per output pixel that
+// touches it, ~4x), and (C) interpolate the window of step s+1 into the halo planes of stage (s+1) & 1 -- while the
+// MFMA waves multiply stage s & 1 and DMA only the weights of step s+1.  The first two chunks of a tile come from `in0`
+// (G0 >= 4), so the only producer work that looks into the next tile is (A) in a tile's last step.  Every wave executes
+// the same barrier sequence.
+constexpr int HS_UPS_WAVES = 4;
+template <int MBW, int NBLK>
+struct HsUpsGeom {   // low-resolution window feeding one (TH+2) x (TW+2) halo
+  static constexpr int TW = MBW, TH = NBLK * (32 / MBW);
+  static constexpr int LRW = TW / 2 + 3, LRH = TH / 2 + 3;
+  static constexpr int RECS = LRW * LRH;                       // records per channel group
+  static constexpr int PIECES = 2 * RECS * 2;                  // 2 groups x 16-byte halves
+  static constexpr int INSTR = (PIECES + 63) / 64;
+  static constexpr int BYTES = INSTR * 1024;
+};
+
+template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0>
+__global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES * UPS) / 4) void conv_hs_kernel(ConvHsArgs a) {
   using G = HsGeom<MT, NBW, MBW, NW>;
+  using U = HsUpsGeom<MBW, NW * NBW>;
+  constexpr int NT = (NW + HS_UPS_WAVES * UPS) * 64;
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
   const int tid = threadIdx.x;
@@ -117,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
   // the epilogue would make the compiler drain the in-flight LDS-DMA queue in front of it)
   if constexpr (EPI != EPI_DMASK) {
     float* lbias = reinterpret_cast<float*>(lds + G::BIAS_OFF);
-    for (int i = tid; i < a.nct * MT; i += NW * 64) lbias[i] = a.bias[i] * HS_ASCALE;
+    for (int i = tid; i < a.nct * MT; i += NT) lbias[i] = a.bias[i] * HS_ASCALE;
     __syncthreads();
   }
 
@@ -172,9 +198,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
     if (half_tiles) return a.wpk + ((size_t)(T.ct >> 1) * nch + chunk) * (2 * G::W_BYTES) + (T.ct & 1) * 512;
     return a.wpk + ((size_t)T.ct * nch + chunk) * G::W_BYTES;
   };
+  bool next_halo_by_dma = true;   // UPS: false while the next step's chunk comes from the low-resolution source
   auto issue_slot = [&](int slot, const char* src, const char* wsrc, char* lstage) {
     // the (wave-uniform) guards are compile-time true except on the last slot of each kind
     if (slot < G::NI) {
+      if (UPS && !next_halo_by_dma) return;
       const int instr = wave + NW * slot;
       if (NW * slot + NW - 1 < G::IN_INSTR || instr < G::IN_INSTR) glds16b(src + ioff[slot], lstage + instr * 1024);
     } else {
@@ -469,15 +497,122 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
 #else
   auto mark = [](int) {};
 #endif
+  // ---- UPS: producer waves (see the kernel comment)
+  const bool producer = UPS && wave >= NW;
+  if (UPS && producer) __builtin_amdgcn_s_setprio(3);   // little work, but on the critical path of every barrier
+  const int pw = wave - NW;                                   // producer wave 0..3
+  char* const lr_base = lds + G::BIAS_OFF + HS_BIAS_BYTES;    // LR[3], U::BYTES each
+  auto chunk_is_up = [&](int c) { return UPS && 2 * c >= a.G0; };
+  auto lr_origin = [&](const Tile& T, int& r_lo, int& c_lo) {
+    r_lo = (int)(a.ups_sy * (float)max(T.y0 - 1, 0));
+    c_lo = (int)(a.ups_sx * (float)max(T.x0 - 1, 0));
+  };
+  // LDS-DMA of the low-resolution window of chunk c (2 groups x U::RECS records x 32 B)
+  auto lr_issue = [&](const Tile& T, int c, char* dst) {
+    int r_lo, c_lo;
+    lr_origin(T, r_lo, c_lo);
+    const int lw2 = a.ups_w + 2;
+    const char* base = a.in1 + ((size_t)T.b * a.G1 + (2 * c - a.G0)) * (size_t)(a.ups_h + 2) * lw2 * 32;
+#pragma unroll
+    for (int k = 0; k < (U::INSTR + HS_UPS_WAVES - 1) / HS_UPS_WAVES; ++k) {
+      const int instr = pw + HS_UPS_WAVES * k;
+      if (instr < U::INSTR) {
+        int piece = instr * 64 + lane;
+        if (piece >= U::PIECES) piece = 0;                    // tail lanes re-read piece 0 into the padding of the buffer
+        // LDS layout [group][half][record] x 16 B (planar: neighbouring records 16 B apart -> conflict-free reads)
+        const int pl = piece / U::RECS;                       // plane = group * 2 + half
+        const int rec = piece - pl * U::RECS;
+        const int g = pl >> 1;
+        const int rr = rec / U::LRW, cc = rec - rr * U::LRW;
+        const int yy = min(r_lo + rr, a.ups_h - 1), xx = min(c_lo + cc, a.ups_w - 1);
+        glds16b(base + (((size_t)g * (a.ups_h + 2) + (yy + 1)) * lw2 + (xx + 1)) * 32 + (pl & 1) * 16, dst + instr * 1024);
+      }
+    }
+  };
+  // (B) hi/lo records -> 8 fp32 values, in place (same 32 bytes)
+  auto lr_convert = [&](char* lr) {
+    for (int r = pw * 64 + lane; r < 2 * U::RECS; r += HS_UPS_WAVES * 64) {
+      const int g = r / U::RECS, rec = r - g * U::RECS;
+      char* p0 = lr + ((g * 2 + 0) * U::RECS + rec) * 16;     // hi plane -> channels 0..3
+      char* p1 = lr + ((g * 2 + 1) * U::RECS + rec) * 16;     // lo plane -> channels 4..7
+      HsRec rc;
+      rc.hi = *reinterpret_cast<const h8v*>(p0);
+      rc.lo = *reinterpret_cast<const h8v*>(p1);
+      float v[8];
+      hs_unpack(rc, v);
+      *reinterpret_cast<f32x4*>(p0) = (f32x4){v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(p1) = (f32x4){v[4], v[5], v[6], v[7]};
+    }
+  };
+  // (C) interpolate the (TH+2) x (TW+2) halo of one up-sampled chunk from the fp32 window into the hi / lo planes of a
+  // stage: per halo pixel four source offsets and two weights, then loads + packed-fp32 FMAs + the hi/lo split.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  auto lr_interpolate = [&](const Tile& T, const char* lr, char* lstage) {
+    int r_lo, c_lo;
+    lr_origin(T, r_lo, c_lo);
+    for (int p = pw * 64 + lane; p < G::PLANE; p += HS_UPS_WAVES * 64) {
+      const int hy_ = p / G::LW, hx_ = p - hy_ * G::LW;
+      const int y = T.y0 - 1 + hy_, x = T.x0 - 1 + hx_;
+      const bool inside = (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
+      int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
+      float ly = 0.f, lx = 0.f, hy = 0.f, hx = 0.f;          // outside the image: all weights zero (the zero border)
+      if (inside) {
+        const float fy = a.ups_sy * y, fx = a.ups_sx * x;
+        const int yq0 = (int)fy, xq0 = (int)fx;
+        const int yq1 = yq0 + (yq0 < a.ups_h - 1 ? 1 : 0), xq1 = xq0 + (xq0 < a.ups_w - 1 ? 1 : 0);
+        ly = fy - yq0;
+        lx = fx - xq0;
+        hy = 1.f - ly;
+        hx = 1.f - lx;
+        o00 = ((yq0 - r_lo) * U::LRW + (xq0 - c_lo)) * 16;
+        o01 = ((yq0 - r_lo) * U::LRW + (xq1 - c_lo)) * 16;
+        o10 = ((yq1 - r_lo) * U::LRW + (xq0 - c_lo)) * 16;
+        o11 = ((yq1 - r_lo) * U::LRW + (xq1 - c_lo)) * 16;
+      }
+      const f32x2 wy0 = {hy, hy}, wy1 = {ly, ly}, wx0 = {hx, hx}, wx1 = {lx, lx};
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {   // 4 channels at a time, two packed-fp32 lanes each
+          const char* tg = lr + (g * 2 + q) * U::RECS * 16;
+          const f32x4 v00 = *reinterpret_cast<const f32x4*>(tg + o00);
+          const f32x4 v01 = *reinterpret_cast<const f32x4*>(tg + o01);
+          const f32x4 v10 = *reinterpret_cast<const f32x4*>(tg + o10);
+          const f32x4 v11 = *reinterpret_cast<const f32x4*>(tg + o11);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const f32x2 a00 = {v00[2 * e], v00[2 * e + 1]}, a01 = {v01[2 * e], v01[2 * e + 1]};
+            const f32x2 a10 = {v10[2 * e], v10[2 * e + 1]}, a11 = {v11[2 * e], v11[2 * e + 1]};
+            // ATen's association: hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11)
+            const f32x2 top = wx0 * a00 + wx1 * a01;
+            const f32x2 bot = wx0 * a10 + wx1 * a11;
+            const f32x2 o = wy0 * top + wy1 * bot;
+            const h2 hh = {(_Float16)o[0], (_Float16)o[1]};
+            hi[q * 2 + e] = __builtin_bit_cast(unsigned, hh);
+            lo[q * 2 + e] = hs_lo_pair(hi[q * 2 + e], a.neg_one, o[0], o[1]);
+          }
+        }
+        *reinterpret_cast<u32x4*>(lstage + ((g * 2 + 0) * G::PLANE + p) * 16) = (u32x4){hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(lstage + ((g * 2 + 1) * G::PLANE + p) * 16) = (u32x4){lo[0], lo[1], lo[2], lo[3]};
+      }
+    }
+  };
+  // which (tile, chunk) runs k steps ahead of (cur, ch); false if none / not an up-sampled chunk.  Only k = 3 in a tile's
+  // last step reaches the next tile's first up-sampled chunk (chunks 0 and 1 of a tile come from in0).
+  int lr_i = 0;   // step index mod 3
+
   int tile = blockIdx.x / nx;   // j of this workgroup's first step
   if (!valid(tile)) return;
   Tile cur = decode(tile);
   int ch = 0, stage = 0;
-  {
+  if (!producer) {
     const char* src = chunk_src(cur, 0);
     const char* w = chunk_w(cur, 0);
 #pragma unroll
     for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, w, lds);
+  } else if (2 < nch && chunk_is_up(2)) {
+    lr_issue(cur, 2, lr_base + 2 * U::BYTES);   // the window of step 2 (its (A) would have been in step -1)
   }
   bool stores_behind = false;   // the last VMEM operations of this wave are the record stores of a finished tile
   const bool pool_on = (EPI == EPI_ACT) && (MBW == 32) && (NBW >= 2) && (a.pool_out != nullptr);
@@ -505,6 +640,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_hs_kernel(ConvHsArgs a) 
     mark(2);
     __builtin_amdgcn_s_barrier();
     mark(3);
+    if (producer) {
+      const int i0 = lr_i, i1 = lr_i == 2 ? 0 : lr_i + 1, i2 = lr_i == 0 ? 2 : lr_i - 1;   // s % 3, (s+1) % 3, (s+2) % 3
+      // (A) window of step s+3
+      if (ch + 3 < nch) {
+        if (chunk_is_up(ch + 3)) lr_issue(cur, ch + 3, lr_base + i0 * U::BYTES);
+      } else if (ch == nch - 1 && has_next && 2 < nch && chunk_is_up(2)) {
+        lr_issue(nxt, 2, lr_base + i0 * U::BYTES);
+      }
+      // (B) window of step s+2: chunk ch+2 of this tile (chunks 0 / 1 of the next tile are not up-sampled)
+      if (ch + 2 < nch && chunk_is_up(ch + 2)) lr_convert(lr_base + i2 * U::BYTES);
+      // (C) halo of step s+1
+      if (ch + 1 < nch && chunk_is_up(ch + 1)) lr_interpolate(cur, lr_base + i1 * U::BYTES, lds + (stage ^ 1) * G::STAGE);
+      if (!has_next) break;
+      tile = ntile;
+      ch = nchk;
+      cur = nxt;
+      stage ^= 1;
+      lr_i = i1;
+      continue;
+    }
+    next_halo_by_dma = !(has_next && chunk_is_up(nchk));
     if (!has_next) {
       body(std::integral_constant<int, 0>{}, stage, nullptr, nullptr);
     } else {
@@ -559,10 +715,12 @@ inline int ensure_dyn_lds(const void* func, int bytes) {
   return PNPX_OK;
 }
 
-template <int MT, int NBW, int MBW, int NW, int EPI>
+template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0>
 static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
   using G = HsGeom<MT, NBW, MBW, NW>;
-  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI>), G::LDS_BYTES));
+  constexpr int LDS_REQ = G::LDS_BYTES + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES;
+  static_assert(G::LDS_USED + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES <= 160 * 1024, "no LDS room for the low-resolution windows");
+  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS>), LDS_REQ));
   ConvHsArgs a = a0;
   a.tilesX = (a.W + G::TW - 1) / G::TW;
   a.tilesY = (a.H + G::TH - 1) / G::TH;
@@ -580,13 +738,13 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
   }
   // persistent: one workgroup per CU (the LDS request makes a second one impossible), each walks ntiles/grid tiles
   long long grid = 256;
-  int lds_req = G::LDS_BYTES;
+  int lds_req = LDS_REQ;
 #ifdef PNPX_TUNING   // co-residency experiments (tools/micro/coresident_check.py): PNPX_HS_PERCU=2 drops the LDS padding
   if (const char* e = getenv("PNPX_HS_PERCU")) {
     const int per_cu = atoi(e);
     if (per_cu > 1 && per_cu * G::LDS_USED <= 160 * 1024) {
       grid = 256LL * per_cu;
-      lds_req = G::LDS_USED;
+      lds_req = G::LDS_USED + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES;
     }
   }
 #endif
@@ -602,7 +760,8 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
     a.trace = tbuf;
   }
 #endif
-  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI>), dim3((unsigned)grid), dim3(NW * 64), lds_req, s, a);
+  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS>), dim3((unsigned)grid),
+                     dim3((NW + HS_UPS_WAVES * UPS) * 64), lds_req, s, a);
   PNPX_LAUNCH_CHECK();
 #ifdef HS_TRACE
   if (tfile) {

@@ -423,7 +423,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
     return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * nb);
   };
   auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o, int b0, int nb,
-                   const ConvHsFuse& fuse) -> int {
+                   const ConvHsFuse& fuse, const ConvHsFuse& first_fuse = ConvHsFuse()) -> int {
     const Act& ta = i1 ? P.da[lvl] : P.a[lvl];   // decoder blocks (two sources) have their own temporaries
     const Act& tb = i1 ? P.db[lvl] : P.b[lvl];
     if (li == 0 && first_fused) {
@@ -433,7 +433,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
       PNPX_LAUNCH_CHECK();
       PNPX_TRY(rec.mark("conv3x3", 2.0 * 9.0 * 2 * 32 * (double)H * W * nb));
     } else
-    PNPX_TRY(conv(li, i0, i1, ta, b0, nb, ConvHsFuse()));
+    PNPX_TRY(conv(li, i0, i1, ta, b0, nb, first_fuse));
     PNPX_TRY(conv(li + 1, ta, nullptr, tb, b0, nb, ConvHsFuse()));
     return conv(li + 2, tb, nullptr, o, b0, nb, fuse);
   };
@@ -468,7 +468,23 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
     for (int b0 = 0; b0 < B; b0 += sb) {
       const int nb = (B - b0 < sb) ? (B - b0) : sb;
       ConvHsFuse f;
-      {
+      // the decoder entry with 32 output channels up-samples its second source on the fly (producer waves in the conv
+      // kernel, conv_hs_kernel.h UPS): no up-sampled tensor in HBM
+      ConvHsFuse f_first;
+      bool ups_fused = false;
+      if (ctx->opt_fuse_up) {
+        const ConvLayerHsDev& D0 = ctx->conv_hs[15 + 3 * (3 - l)];
+        ConvLayerHs L0;
+        L0.cout = D0.cout;
+        L0.mt = D0.mt;
+        // (odd sizes: the up-sampled 2h x 2w image sits inside a larger zero-padded tensor -- separate kernel)
+        ups_fused = P.u[l].H == 2 * h && P.u[l].W == 2 * w && P.x[l].H == 2 * h && P.x[l].W == 2 * w &&
+                    conv_hs_can_fuse_upsample(L0, P.x[l].C / 8, below->C / 8, 2 * h, 2 * w);
+      }
+      if (ups_fused) {
+        f_first.ups_h = h;
+        f_first.ups_w = w;
+      } else {
         const unsigned nbg = (unsigned)(nb * (below->C / 8));
         const int Wo = 2 * w, Ho = 2 * h;
         if (Wo > 128) {
@@ -491,7 +507,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
         f.out_img = out + (size_t)b0 * H * W;
         f.out_pre = out_pre ? out_pre + (size_t)b0 * H * W : nullptr;
       }
-      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l], b0, nb, f));
+      PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], ups_fused ? below : &P.u[l], l, P.y[l], b0, nb, f, f_first));
     }
     below = &P.y[l];
   }

@@ -1,6 +1,6 @@
 """Per-launch table of one denoiser forward (HIP events): name, ms, TFLOP/s.  GPU box only.
 
-usage: profile_layers.py [B] [H] [conv_mode] [--brief]
+usage: profile_layers.py [B] [H] [conv_mode] [--brief] [--set=option:value ...]
 PNPX_LIB selects an A/B build of the library (tools only); with libpnpx_tune.so the launch table can be overridden
 through PNPX_HS_<MT>_<W>="nbw,nw" (see csrc/conv_hs.hip)."""
 import os, sys
@@ -20,6 +20,8 @@ g = torch.Generator().manual_seed(1)
 x = torch.rand(B, 1, H, H, generator=g).to(dev)
 s = torch.full((B,), 0.1, device=dev)
 ctx = den.context(dev)
+for kv in [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--set=")]:      # --set=key:value context options
+    ctx.set_option(kv.split(":")[0], int(kv.split(":")[1]))
 y = den(x, s)
 abl = [a for a in sys.argv[1:] if a.startswith("--abl=")]
 if abl:   # tuning builds: ablation bits take effect AFTER a real forward has filled the arena with real activations
