@@ -83,12 +83,27 @@ class _StubSolver(torch.nn.Module):
         return x + mu.view(-1, 1, 1, 1) * (gt - x)
 
 
+def _count_collectives():
+    """Wrap every torch.distributed collective entry point with a counter (this process only)."""
+    counts = {}
+    for name in ("all_gather", "all_gather_into_tensor", "all_reduce", "broadcast", "reduce", "gather", "scatter",
+                 "all_to_all", "all_gather_object", "reduce_scatter", "barrier"):
+        orig = getattr(dist, name)
+
+        def wrapped(*a, _orig=orig, _name=name, **k):
+            counts[_name] = counts.get(_name, 0) + 1
+            return _orig(*a, **k)
+        setattr(dist, name, wrapped)
+    return counts
+
+
 def _episode_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from tfpnp_amd import dist as D
     from tfpnp_amd.env.base import PnPEnv
     D.init_from_env(backend="gloo")
+    counts = _count_collectives()
 
     class StubEnv(PnPEnv):
         ob_keys = ()
@@ -108,10 +123,14 @@ def _episode_worker(rank, world, port, q):
     for step in range(1, 5):
         live = env.idx_left.clone() if not senv._local_done else torch.empty(0, dtype=torch.long)
         action = {'mu': torch.full((len(live),), 0.5), 'idx_stop': (stop_at[lo:hi][live] <= step).long()}
+        before = dict(counts)
         ob, rewards, finished, info = senv.step(action)
+        made = {k: v - before.get(k, 0) for k, v in counts.items() if v != before.get(k, 0)}
+        assert made == {"all_gather_into_tensor": 1}, made       # ONE small collective per env step
         log.append((rewards.view(-1).tolist(), info['done'].tolist(), finished))
         if finished:
             break
+    assert senv.exchange.posted == len(log)
     q.put((rank, log))
     dist.destroy_process_group()
 
@@ -139,6 +158,55 @@ def test_sharded_env_episode_world2():
     assert done2 == [False, True, False, True, True]
     rew3, done3, _ = log[2]
     assert rew3[1] == 0.0 and rew3[0] > 0 and done3 == [True] * 5
+
+
+def _pipelined_worker(rank, world, port, q):
+    """StepExchange used the way bench.py uses it: post step k, resolve it after step k+1 has been posted."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from tfpnp_amd import dist as D
+    D.init_from_env(backend="gloo")
+    counts = _count_collectives()
+    n_global = 7                                         # uneven: 4 + 3
+    ex = D.StepExchange(n_global, torch.device("cpu"))
+    lo, hi = D.shard_bounds(n_global, world, rank)
+    items = torch.arange(n_global, dtype=torch.float32)
+    got, pending = [], None
+    for step in range(5):
+        reward = (items[lo:hi] * 10 + step).view(-1, 1)
+        done = (items[lo:hi] <= step)
+        nxt = ex.post(reward, done, rank_finished=bool(done.all()))
+        if pending is not None:
+            got.append(pending.result())
+        pending = nxt
+    got.append(pending.result())
+    assert counts == {"all_gather_into_tensor": 5}, counts
+    q.put((rank, [(r.view(-1).tolist(), d.tolist(), f) for r, d, f in got]))
+    dist.destroy_process_group()
+
+
+def test_step_exchange_pipelined_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]
+    for step, (rew, done, fin) in enumerate(res[0]):
+        assert rew == [10.0 * i + step for i in range(7)]
+        assert done == [i <= step for i in range(7)]
+        assert fin == (step >= 6)          # never within 5 steps: rank 1 holds item 6
+    # single process: the exchange degenerates to a local view, no process group needed
+    from tfpnp_amd import dist as D
+    ex = D.StepExchange(3, torch.device("cpu"))
+    r, d, f = ex.post(torch.tensor([[1.0], [2.0], [3.0]]), torch.tensor([1, 0, 1]), True).result()
+    assert r.view(-1).tolist() == [1.0, 2.0, 3.0] and d.tolist() == [True, False, True] and f is True
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
 """GPU tests of the denoiser's execution options: conv kernel family, sub-batching, workspace reuse."""
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -200,3 +201,34 @@ def test_range_guard_default_reports_clean_error(unet_params):
         v = sol.reset({"x0": g(d["x0"])})
         sols[mode] = sol((v, (g(d["y0"]), g(d["mask"]))), (g(acts["sigma_d"]), g(acts["mu"])))
     assert torch.isfinite(sols[1]).all() and torch.equal(sols[0], sols[1])
+
+
+def test_env_step_redoes_a_tripped_step_in_exact_fp32(unet_params):
+    """with the default (non-synchronising) range guard a tripped call used to return invalid state and reward
+    from PnPEnv.step without anyone noticing.  The step now looks at the guard right after its one host read and, if it
+    tripped, repeats itself with the exact-fp32 convolutions: state, reward and observation equal a conv_mode-0 run."""
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI, CSMRIEnv
+    hot = _hot_params(unet_params)
+    d = synth.make_csmri_batch(3, 64, 64, ratio=4, seed=8)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    data = {k: g(v) for k, v in d.items()}
+    acts = [{k: g(v) for k, v in a.items()} for a in synth.make_actions(3)[:2]]
+    for a in acts:
+        a["idx_stop"] = torch.zeros(3, dtype=torch.int64, device=dev())
+    got = {}
+    for mode in (0, 1):
+        den = UNetDenoiser2D(state_dict=hot, conv_mode=mode)
+        env = CSMRIEnv(None, ADMMSolver_CSMRI(den), max_episode_step=6)
+        env.reset(data)
+        rows = []
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            for a in acts:
+                ob, _, reward, _, _ = env.step(a)
+                rows.append((ob.variables.clone(), reward.clone()))
+        got[mode] = (rows, env.range_redone_steps, [str(x.message) for x in w], den.context(dev()).get_option("conv_mode"))
+    assert got[0][1] == 0 and got[1][1] == 1                 # the first hot step tripped, was redone; the second ran exact
+    assert any("range guard" in m for m in got[1][2]) and got[1][3] == 0
+    for (v0, r0), (v1, r1) in zip(got[0][0], got[1][0]):
+        assert torch.isfinite(v1).all() and torch.equal(v0, v1) and torch.equal(r0, r1)

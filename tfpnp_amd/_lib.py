@@ -23,6 +23,9 @@ class PnpxError(RuntimeError):
     pass
 
 
+PNPX_ERR_RANGE = 6      # include/pnpx.h: half-split range guard tripped (pnpx_ctx_status)
+
+
 # name -> (restype, argtypes); mirrors include/pnpx.h one to one
 _P = c_void_p  # device pointers travel as integers
 _SIGNATURES = {
@@ -90,15 +93,21 @@ def lib():
                         f"{LIB_PATH} not found: the HIP library has not been built "
                         "(run `make -C tfpnp_amd/csrc` or __graft_entry__.build()). There is no CPU fallback.")
                 l = C.CDLL(LIB_PATH)
+                missing = []
                 for name, (res, args) in _SIGNATURES.items():
                     try:
                         fn = getattr(l, name)  # AttributeError if the .so lacks a declared symbol
                     except AttributeError:
                         if "PNPX_LIB" in os.environ:   # A/B run against an older build of the ABI (tools/ only)
+                            missing.append(name)
                             continue
                         raise
                     fn.restype = res
                     fn.argtypes = args
+                if missing:
+                    import warnings
+                    warnings.warn(f"PNPX_LIB={LIB_PATH} lacks {len(missing)} symbol(s) of include/pnpx.h: "
+                                  + ", ".join(missing) + " -- calls to them will fail with AttributeError")
                 _lib = l
     return _lib
 

@@ -205,10 +205,17 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     *ctx->range_flag_host = 0;
     return PNPX_OK;
   }
-  if (is("train_cache_gb") && value >= 0) {   // shrinking to 0 also releases what is held
+  if (is("train_cache_gb") && value >= -1) {   // -1 = automatic budget; shrinking to 0 also releases what is held
     ctx->opt_train_cache_gb = value;
     ctx->train_alloc_failed = false;
+    ctx->train_budget_bytes = 0;
     if (value == 0) pnpx::train_cache_free(ctx);
+    return PNPX_OK;
+  }
+  if (is("train_cache_release")) {   // give the ring's memory back now (budget unchanged; it re-grows on the next
+    pnpx::train_cache_free(ctx);     // forward under autograd).  Outstanding tickets fall back to re-computation.
+    ctx->train_alloc_failed = false;
+    ctx->train_budget_bytes = 0;
     return PNPX_OK;
   }
   set_error("pnpx_ctx_set_option: unknown option '%s' or bad value %d", key ? key : "(null)", value);

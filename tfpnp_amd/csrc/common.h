@@ -123,8 +123,10 @@ struct pnpx_ctx {
   int opt_fuse_up = 0;             // opt-in: bilinear x2 of the full-resolution decoder entry inside the conv kernel
                                    // (producer waves; +1.7 % iterations/s)
   int opt_range_guard = 1;         // 0 off, 1 sticky flag + latch to conv_mode 0, 2 strict (sync + transparent re-run)
-  int opt_train_cache_gb = 96;     // training path: keep the activations of up to this many GiB of denoiser forwards for
-                                   // the backward pass instead of re-computing them (0 = always re-compute)
+  int opt_train_cache_gb = -1;     // training path: keep the activations of up to this many GiB of denoiser forwards for
+                                   // the backward pass instead of re-computing them (0 = always re-compute; -1 = auto:
+                                   // a quarter of the device memory free when the ring is first laid out, <= 96 GiB)
+  size_t train_budget_bytes = 0;   // the automatic budget once measured (reset by set_option / train_cache_release)
   // --- half-split range guard: host-mapped word the conv_hs epilogues set when a stored value leaves the f16 range
   unsigned* range_flag_host = nullptr;   // pinned host allocation
   unsigned* range_flag_dev = nullptr;    // its device address

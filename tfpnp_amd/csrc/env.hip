@@ -181,7 +181,10 @@ int pnpx_rows_scatter(pnpx_ctx* ctx, int n_tensors, const void* const* src_host,
 
 int pnpx_live_compact(pnpx_ctx* ctx, const int64_t* idx_left, const int64_t* idx_stop, int n, int64_t* idx_out,
                       int* n_live_host, void* stream) {
-  LOCK_CTX(ctx);
+  if (!ctx) {
+    set_error("null context");
+    return PNPX_ERR_ARG;
+  }
   if (n < 0 || !n_live_host || (n > 0 && (!idx_left || !idx_stop || !idx_out))) {
     set_error("pnpx_live_compact: bad arguments");
     return PNPX_ERR_ARG;
@@ -191,13 +194,33 @@ int pnpx_live_compact(pnpx_ctx* ctx, const int64_t* idx_left, const int64_t* idx
     return PNPX_OK;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int* word_host = reinterpret_cast<int*>(ctx->range_flag_host) + 1;   // second word of the pinned, host-mapped block
-  int* word_dev = reinterpret_cast<int*>(ctx->range_flag_dev) + 1;
+  // Result slot: one pinned, host-mapped word per (calling thread, device) -- NOT a field of the (possibly shared,
+  // e.g. default) context -- so the context mutex is not needed at all and other threads' stateless ops on the same
+  // context never queue behind this call's stream synchronisation.
+  struct Slot {
+    int* host = nullptr;
+    int* dev = nullptr;
+  };
+  thread_local std::map<int, Slot> slots;
+  PNPX_HIP(hipSetDevice(ctx->device));
+  Slot& sl = slots[ctx->device];
+  if (!sl.host) {
+    void* h = nullptr;
+    void* d = nullptr;
+    PNPX_HIP(hipHostMalloc(&h, 64, hipHostMallocMapped));
+    hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) {
+      (void)hipHostFree(h);
+      return hip_fail(e, "hipHostGetDevicePointer(live count)", __FILE__, __LINE__);
+    }
+    sl.host = static_cast<int*>(h);
+    sl.dev = static_cast<int*>(d);
+  }
   hipLaunchKernelGGL(live_compact_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const long long*>(idx_left),
-                     reinterpret_cast<const long long*>(idx_stop), n, reinterpret_cast<long long*>(idx_out), word_dev);
+                     reinterpret_cast<const long long*>(idx_stop), n, reinterpret_cast<long long*>(idx_out), sl.dev);
   PNPX_LAUNCH_CHECK();
   PNPX_HIP(hipStreamSynchronize(s));   // the one host read of an env step: `all_done` is a Python bool in the contract
-  *n_live_host = *static_cast<volatile int*>(word_host);
+  *n_live_host = *static_cast<volatile int*>(sl.host);
   return PNPX_OK;
 }
 

@@ -281,12 +281,26 @@ void train_cache_free(pnpx_ctx* ctx) {
 // memory).  The ring serves one geometry / kernel family at a time and is re-laid out when that changes; its length is
 // what the "train_cache_gb" budget buys at the largest batch seen (at most 64 slots).
 static pnpx_ctx::TrainSlot* train_slot_acquire(pnpx_ctx* ctx, int B, int H, int W) {
-  if (ctx->opt_train_cache_gb <= 0 || ctx->train_alloc_failed) return nullptr;
+  if (ctx->opt_train_cache_gb == 0 || ctx->train_alloc_failed) return nullptr;
   const int mode = ctx->conv_mode;
   int capB = B;
   for (const auto& sl : ctx->train_ring) capB = sl.arena.capB > capB ? sl.arena.capB : capB;
   const size_t per = unet_arena_bytes(mode, capB, H, W) + sizeof(float) * (size_t)capB * H * W;
-  size_t n = ((size_t)ctx->opt_train_cache_gb << 30) / per;
+  if (ctx->opt_train_cache_gb < 0 && ctx->train_budget_bytes == 0) {
+    // automatic budget, fixed when the ring is first laid out: a quarter of what is free on the device right now (the
+    // ring is raw hipMalloc memory PyTorch's caching allocator cannot reclaim), at most 96 GiB
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+      (void)hipGetLastError();
+      free_b = 0;
+    }
+    size_t held = 0;
+    for (const auto& sl : ctx->train_ring) held += sl.arena.buf.bytes + sl.pre.bytes;
+    ctx->train_budget_bytes = std::min<size_t>((free_b + held) / 4, (size_t)96 << 30);
+    if (ctx->train_budget_bytes == 0) ctx->train_budget_bytes = 1;   // "measured, nothing to spare"
+  }
+  const size_t budget = ctx->opt_train_cache_gb < 0 ? ctx->train_budget_bytes : ((size_t)ctx->opt_train_cache_gb << 30);
+  size_t n = budget / per;
   if (n == 0) return nullptr;
   if (n > 64) n = 64;
   if (H != ctx->train_H || W != ctx->train_W || mode != ctx->train_mode || n != ctx->train_ring.size()) {

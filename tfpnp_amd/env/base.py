@@ -83,6 +83,7 @@ class PnPEnv:
         self._n_live = 0
         self.last_metric = 0
         self.metric_fn = torch_psnr
+        self.range_redone_steps = 0     # steps repeated in exact fp32 because the half-split range guard tripped
 
     @property
     def idx_left(self):
@@ -152,18 +153,43 @@ class PnPEnv:
         self.last_metric = self._compute_metric()
         return self._observation()
 
+    def _native_context(self, like):
+        """The denoiser's native context for the device of `like` (None for CPU stubs / foreign solvers)."""
+        den = getattr(self.solver, 'denoiser', None)
+        if like is None or not like.is_cuda or not hasattr(den, 'context'):
+            return None
+        return den.context(like.device)
+
     def step(self, action):
         self.cur_step += 1
         st, rows, n = self.state, self._rows, self._n_live
         with torch.no_grad():
             live = _take_rows([st['solver'], *self.solver.filter_aux_inputs(st)], rows, n)
-            solver_state = self.solver((live[0], tuple(live[1:])), self.solver.filter_hyperparameter(action))
-            st['T'].fill_(self.cur_step / self.max_episode_step)
-            _put_rows([self.solver.get_output(solver_state), solver_state], [st['output'], st['solver']], rows, n)
-            reward = self._compute_reward()
-            ob = self._observation()                      # rows that were live during this step
+            hyper = self.solver.filter_hyperparameter(action)
+            prev_metric = self.last_metric
+
+            def advance():
+                solver_state = self.solver((live[0], tuple(live[1:])), hyper)
+                st['T'].fill_(self.cur_step / self.max_episode_step)
+                _put_rows([self.solver.get_output(solver_state), solver_state], [st['output'], st['solver']], rows, n)
+                self.last_metric = prev_metric
+                return self._compute_reward(), self._observation()   # observation: rows that were live during this step
+
+            reward, ob = advance()
             idx_stop = action['idx_stop']
             self._rows, self._n_live = _surviving_rows(rows, idx_stop, n)
+            # The compaction above is the step's one host read: the stream has drained, so the half-split range guard's
+            # host-mapped flag is final for this step.  If an activation left the f16 hi/lo range the context has just
+            # latched itself to the exact-fp32 convolutions; the solver call is functional (its gathered inputs are still
+            # here), so the step is simply run again -- nothing invalid ever leaves step().
+            ctx = self._native_context(rows) if n else None
+            if ctx is not None and ctx.get_option('conv_mode') == 1 and ctx.range_tripped():
+                import warnings
+                warnings.warn('half-split range guard tripped in PnPEnv.step: the step was repeated with the exact-fp32 '
+                              'convolutions and the denoiser context stays in conv_mode 0 (re-arm with '
+                              "context.set_option('range_guard', 1) + set_option('conv_mode', 1))")
+                self.range_redone_steps += 1
+                reward, ob = advance()
             done = idx_stop.detach()
             all_done = self._n_live == 0
             if self.cur_step == self.max_episode_step:

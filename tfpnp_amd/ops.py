@@ -97,6 +97,20 @@ class Context:
         e.g. right after reading a result back.  Re-arm with set_option('range_guard', 1)."""
         check(_lib.lib().pnpx_ctx_status(self.handle))
 
+    def range_tripped(self):
+        """True once the half-split range guard has tripped (see status()); other failures raise.  Like status() it does
+        not synchronise -- ask after a point where the stream has drained (PnPEnv.step does, after its one host read)."""
+        st = _lib.lib().pnpx_ctx_status(self.handle)
+        if st == _lib.PNPX_ERR_RANGE:
+            return True
+        check(st)
+        return False
+
+    def release_train_cache(self):
+        """Give the training path's activation ring (raw device memory outside PyTorch's caching allocator) back to the
+        device now; it re-grows on the next denoiser forward under autograd.  Outstanding tickets re-compute."""
+        check(_lib.lib().pnpx_ctx_set_option(self.handle, b"train_cache_release", 1))
+
     def reserve(self, B, H, W):
         check(_lib.lib().pnpx_ctx_reserve(self.handle, B, H, W))
 

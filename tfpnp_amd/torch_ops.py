@@ -24,6 +24,13 @@ def _ctx(cid, t):
     return ops.default_context(t.device) if cid == 0 else ops.context_by_id(cid)
 
 
+def _pin(node, cid, t):
+    """setup_context helper: the autograd node keeps the native context ALIVE until its backward has run (the id -> context
+    table holds weak references only; a denoiser collected between forward and backward must not strand the node)."""
+    node.cid = cid
+    node.native = _ctx(cid, t)
+
+
 def _it(iter_num):
     return None if iter_num < 0 else iter_num
 
@@ -67,7 +74,7 @@ def _(x, sigma, grad_out, ctx):
 def _denoise_setup(ctx, inputs, output):
     x, sigma, cid = inputs
     ctx.save_for_backward(x, sigma)
-    ctx.cid = cid
+    _pin(ctx, cid, x)
 
 
 def _denoise_bwd(ctx, g):
@@ -105,7 +112,8 @@ def _(x, sigma, grad_out, ticket, ctx):
 
 
 def _denoise_train_setup(ctx, inputs, output):
-    x, sigma, ctx.cid = inputs
+    x, sigma, cid = inputs
+    _pin(ctx, cid, x)
     ctx.save_for_backward(x, sigma, output[1])
 
 
@@ -299,7 +307,8 @@ def _(y0, mask, sigma_d, mu, saved, ticket, grad_out, iter_num, ctx):
 
 
 def _admm_train_setup(ctx, inputs, output):
-    _, y0, mask, sigma_d, mu, ctx.iter_num, ctx.cid = inputs
+    _, y0, mask, sigma_d, mu, ctx.iter_num, cid = inputs
+    _pin(ctx, cid, y0)
     ctx.save_for_backward(y0, mask, sigma_d, mu, output[1], output[2])
 
 
