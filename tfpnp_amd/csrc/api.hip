@@ -138,6 +138,9 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx) {
     if (t.second) (void)hipFree(t.second);
   for (auto e : ctx->events) (void)hipEventDestroy(e);
   if (ctx->range_flag_host) (void)hipHostFree(ctx->range_flag_host);
+  for (hipStream_t st : ctx->side_streams) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : ctx->side_joins) (void)hipEventDestroy(ev);
+  if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
   delete ctx;
   return PNPX_OK;
 }
@@ -194,6 +197,14 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_fuse_first = value;
     return PNPX_OK;
   }
+  if (is("chains") && value >= 0 && value <= 8) {
+    ctx->opt_chains = value;
+    return PNPX_OK;
+  }
+  if (is("wreg") && value >= 0 && value <= 2) {
+    ctx->opt_wreg = value;
+    return PNPX_OK;
+  }
   if (is("fuse_up") && (value == 0 || value == 1)) {
     ctx->opt_fuse_up = value;
     return PNPX_OK;
@@ -235,6 +246,8 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fuse_outc")) *value = ctx->opt_fuse_outc;
   else if (is("fuse_first")) *value = ctx->opt_fuse_first;
   else if (is("fuse_up")) *value = ctx->opt_fuse_up;
+  else if (is("wreg")) *value = ctx->opt_wreg;
+  else if (is("chains")) *value = ctx->opt_chains;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
   else if (is("train_cache_gb")) *value = ctx->opt_train_cache_gb;
   else {

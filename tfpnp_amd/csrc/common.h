@@ -122,6 +122,11 @@ struct pnpx_ctx {
   int opt_fuse_first = 1;          // VALU first convolution straight from the fp32 image (no padded-input tensor)
   int opt_fuse_up = 0;             // opt-in: bilinear x2 of the full-resolution decoder entry inside the conv kernel
                                    // (producer waves; +1.7 % iterations/s)
+  int opt_chains = 0;              // denoiser forward as n independent launch chains over slices of the batch (0 = auto)
+  std::vector<hipStream_t> side_streams;
+  std::vector<hipEvent_t> side_joins;
+  hipEvent_t side_fork = nullptr;
+  int opt_wreg = 2;                // weights-in-registers instances for the 32 -> 32 channel layers (0 off, 1 / 2 = shape)
   int opt_range_guard = 1;         // 0 off, 1 sticky flag + latch to conv_mode 0, 2 strict (sync + transparent re-run)
   int opt_train_cache_gb = -1;     // training path: keep the activations of up to this many GiB of denoiser forwards for
                                    // the backward pass instead of re-computing them (0 = always re-compute; -1 = auto:

@@ -53,6 +53,7 @@ struct ConvHsArgs {
   float neg_one;           // -1.0f (kept in a scalar register: selects the fused f16 fma-mix forms in the hi/lo split)
   unsigned* range_flag;    // sticky half-split range guard (host-mapped word) or null
   unsigned long long* trace;   // HS_TRACE builds: s_memtime stamps of workgroup 0 / wave 0 (null otherwise)
+  unsigned long long* wgt;     // PNPX_TUNING builds: per-workgroup {start, end} wall-clock stamps (100 MHz) or null
   int abl;                     // PNPX_TUNING builds: ablation bits (1 = drop the record stores, 2 = skip the epilogue, 4 / 8 = planar-layout addressing of loads / stores)
   int w_mt;                    // cout tile the weights were PACKED for (64 while a 32-cout instance runs: "half tiles")
   // fused bilinear x2 (UPS instance): in1 is the low-resolution tensor [B][G1][ups_h+2][ups_w+2], H = 2*ups_h, W = 2*ups_w
@@ -76,6 +77,9 @@ struct ConvHsFuse {       // optional fused work
   // fused bilinear x2: `in1` of launch_conv_hs is the LOW-resolution tensor (ups_h x ups_w) and is up-sampled on the fly
   // (cout == 32 layers with G0 >= 4 only: conv_hs_can_fuse_upsample)
   int ups_h = 0, ups_w = 0;
+  // cin = cout = 32 single-source layers: weights in registers, one pipeline step per tile (conv_hs_kernel.h WREG):
+  // 0 = generic kernel, 1 = four waves x four pixel blocks, 2 = eight waves x two pixel blocks.  Same K order: same bits.
+  int wreg = 2;
 };
 bool conv_hs_can_fuse_upsample(const ConvLayerHs& L, int G0, int G1, int H, int W);
 // true when launch_conv_hs will honour ConvHsFuse::pool_out for this geometry

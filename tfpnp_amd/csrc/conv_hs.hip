@@ -124,6 +124,7 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.neg_one = -1.0f;
   a.range_flag = fuse.range_flag;
   a.trace = nullptr;
+  a.wgt = nullptr;
   a.abl = 0;
 #ifdef PNPX_TUNING
   if (const char* e = getenv("PNPX_HS_ABL")) a.abl = atoi(e);
@@ -165,6 +166,15 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   }
   if (a.dmask) return launch_conv_hs_dmask(a, mt_run, B, s);
   if (a.res) return launch_conv_hs_res(a, mt_run, B, s);
+  // weights-in-registers instances: 32 -> 32 channels from one source, 32-pixel-wide blocks, enough tiles to fill the chip
+  if (fuse.wreg && L.mt == 32 && L.cout == 32 && G0 == 4 && G1 == 0 && W >= 32) {
+    const bool w8 = fuse.wreg == 2;
+    const long long tiles = (long long)((W + 31) / 32) * ((H + 15) / 16) * B;   // both shapes: 16-row tiles
+    if (tiles >= 256) {
+      if (a.outc_w) return w8 ? launch_hs_cfg<32, 2, 32, 8, EPI_OUTC, 0, 1>(a, B, s) : launch_hs_cfg<32, 4, 32, 4, EPI_OUTC, 0, 1>(a, B, s);
+      return w8 ? launch_hs_cfg<32, 2, 32, 8, EPI_ACT, 0, 1>(a, B, s) : launch_hs_cfg<32, 4, 32, 4, EPI_ACT, 0, 1>(a, B, s);
+    }
+  }
   if (a.outc_w) return launch_hs_mt<32, EPI_OUTC>(a, B, s);
   if (mt_run == 64) return launch_hs_mt<64, EPI_ACT>(a, B, s);
   return launch_hs_mt<32, EPI_ACT>(a, B, s);

@@ -40,8 +40,13 @@ enum HsEpi {
 #endif
 constexpr int HS_BIAS_BYTES = 4096;   // LDS copy of the layer's (pre-scaled) bias vector, cout <= 1024
 
-template <int MT, int NBW, int MBW, int NW>
+// WREG = 1 ("weights in registers", the cin = cout = 32 layers): the layer's whole weight slice (2 K-chunks x 9 taps x
+// hi/lo = 36 fragments of 16 B per lane) is loaded into registers once per workgroup, a pipeline step is a whole TILE
+// (CPS = 2 chunks: both halo planes sets in one stage, one barrier per tile instead of two, no weight DMA, no A-fragment
+// ds_reads), and the LDS stage holds halos only.
+template <int MT, int NBW, int MBW, int NW, int WREG = 0>
 struct HsGeom {
+  static constexpr int CPS = WREG ? 2 : 1;              // K-chunks per pipeline step
   static constexpr int MBH = 32 / MBW;
   static constexpr int NBLK = NW * NBW;
   static constexpr int TW = MBW;
@@ -50,15 +55,19 @@ struct HsGeom {
   static constexpr int LH = TH + 2;
   static constexpr int PLANE = LW * LH;                 // pixels per LDS plane
   static constexpr int IN_LOADS = 4 * PLANE;            // 16-byte lane loads per chunk (2 groups x hi/lo)
-  static constexpr int IN_INSTR = (IN_LOADS + 63) / 64; // wave-level DMA instructions (1 KiB each)
+  static constexpr int IN_INSTR_C = (IN_LOADS + 63) / 64; // wave-level DMA instructions (1 KiB each) per chunk
+  static constexpr int IN_BYTES_C = IN_INSTR_C * 1024;
+  static constexpr int IN_INSTR = CPS * IN_INSTR_C;
   static constexpr int NI = (IN_INSTR + NW - 1) / NW;   // DMA slots per wave
   static constexpr int IN_BYTES = IN_INSTR * 1024;
-  static constexpr int W_BYTES = 9 * 2 * 2 * MT * 16;   // [tap][hi,lo][kg][MT] x 16 B (multiple of 1 KiB)
+  static constexpr int W_BYTES_FULL = 9 * 2 * 2 * MT * 16;   // [tap][hi,lo][kg][MT] x 16 B (multiple of 1 KiB)
+  static constexpr int W_BYTES = WREG ? 0 : W_BYTES_FULL;    // ... staged through LDS
   static constexpr int W_INSTR = W_BYTES / 1024;
   static constexpr int NWJ = (W_INSTR + NW - 1) / NW;
   static constexpr int STAGE = IN_BYTES + W_BYTES;
   static constexpr int BIAS_OFF = 2 * STAGE;
-  static constexpr int LDS_USED = 2 * STAGE + HS_BIAS_BYTES;
+  static constexpr int BIAS_BYTES = WREG ? 256 : HS_BIAS_BYTES;   // WREG: one 32-cout tile
+  static constexpr int LDS_USED = 2 * STAGE + BIAS_BYTES;
   // One workgroup per CU BY CONSTRUCTION: the request is padded past half of the 160 KiB so that two workgroups can
   // never be co-resident (see DESIGN.md "co-residency"); the persistent grid is <= 256 workgroups.
   static constexpr int LDS_BYTES = LDS_USED > 82 * 1024 ? LDS_USED : 82 * 1024;
@@ -115,9 +124,10 @@ struct HsUpsGeom {   // low-resolution window feeding one (TH+2) x (TW+2) halo
   static constexpr int BYTES = INSTR * 1024;
 };
 
-template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0>
+template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0>
 __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES * UPS) / 4) void conv_hs_kernel(ConvHsArgs a) {
-  using G = HsGeom<MT, NBW, MBW, NW>;
+  using G = HsGeom<MT, NBW, MBW, NW, WREG>;
+  static_assert(!(WREG && UPS) && (!WREG || MT == 32), "WREG: 32-cout single-source layers only");
   using U = HsUpsGeom<MBW, NW * NBW>;
   constexpr int NT = (NW + HS_UPS_WAVES * UPS) * 64;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -125,8 +135,11 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PNPX_TUNING
+  if (a.wgt && tid == 0) a.wgt[2 * blockIdx.x] = wall_clock64();
+#endif
   const int HpWp = a.Hp * a.Wp;
-  const int nch = (a.G0 + a.G1) / 2;
+  const int nch = (a.G0 + a.G1) / 2 / G::CPS;   // pipeline steps per tile
   // XCD-aware tile walk.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own
   // L2.  The nct cout-tiles of one pixel region read the same input halo, so they are given to workgroups of the
   // SAME XCD that run at the same time (consecutive "slots"): step k of workgroup (xcd, slot) handles
@@ -151,12 +164,14 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   int ioff[G::NI];
 #pragma unroll
   for (int k = 0; k < G::NI; ++k) {
-    const int idx = (wave + NW * k) * 64 + lane;
+    const int instr = wave + NW * k;
+    const int cc = instr / G::IN_INSTR_C;       // chunk within the step (always 0 unless WREG)
+    const int idx = (instr - cc * G::IN_INSTR_C) * 64 + lane;
     const int q = idx / G::PLANE;               // plane: group = q >> 1, half = q & 1
     const int r = idx - q * G::PLANE;
     const int hy = r / G::LW;
     const int hx = r - hy * G::LW;
-    ioff[k] = (idx < G::IN_LOADS) ? (((q >> 1) * HpWp + hy * a.Wp + hx) * 32 + (q & 1) * 16) : 0;
+    ioff[k] = (idx < G::IN_LOADS) ? (((2 * cc + (q >> 1)) * HpWp + hy * a.Wp + hx) * 32 + (q & 1) * 16) : 0;
 #ifdef PNPX_TUNING   // ablation 4 (invalid results): address the halo as if hi / lo were separate dense planes
     if ((a.abl & 4) && idx < G::IN_LOADS) ioff[k] = (q * HpWp + hy * a.Wp + hx) * 16;
 #endif
@@ -181,12 +196,13 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     T.y0 = ty * G::TH;
     return T;
   };
-  auto chunk_src = [&](const Tile& T, int chunk) -> const char* {
-    const int g0 = chunk * 2;
+  auto chunk_src = [&](const Tile& T, int chunk) -> const char* {   // chunk = pipeline step (CPS K-chunks)
+    const int g0 = chunk * 2 * G::CPS;
     const char* src = (g0 < a.G0) ? a.in0 + ((size_t)T.b * a.G0 + g0) * HpWp * 32
                                   : a.in1 + ((size_t)T.b * a.G1 + (g0 - a.G0)) * HpWp * 32;
 #ifdef PNPX_TUNING
     if (a.abl & 4) return src + ((size_t)T.y0 * a.Wp + T.x0) * 16;
+    if (a.abl & 16) return a.in0 + (size_t)g0 * HpWp * 32 + (size_t)(blockIdx.x & 7) * a.Wp * 32;   // ablation 16 (invalid results): every tile reads the same cache-resident halo
 #endif
     return src + ((size_t)T.y0 * a.Wp + T.x0) * 32;
   };
@@ -195,6 +211,7 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   // its slice is then every other 512-byte run of the 64-cout slice, gathered by the DMA's per-lane source address.
   const bool half_tiles = (MT == 32) && (a.w_mt == 64);
   auto chunk_w = [&](const Tile& T, int chunk) -> const char* {
+    if constexpr (WREG) return a.wpk;   // unused: no weight DMA
     if (half_tiles) return a.wpk + ((size_t)(T.ct >> 1) * nch + chunk) * (2 * G::W_BYTES) + (T.ct & 1) * 512;
     return a.wpk + ((size_t)T.ct * nch + chunk) * G::W_BYTES;
   };
@@ -230,6 +247,18 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   // LDS byte offsets of this lane's operand fragments (tap / tile / hi-lo shifts are compile-time immediates)
   const int b_lane = (kg * 2 * G::PLANE + (wave * NBW * G::MBH + py) * G::LW + px) * 16;
   const int a_lane = G::IN_BYTES + (kg * MT + l31) * 16;
+  // WREG: this lane's A fragments of the whole layer (cout tile 0; the launcher guarantees nct == 1, w_mt == 32)
+  [[maybe_unused]] h8 areg[WREG ? 2 : 1][WREG ? 9 : 1][2];
+  if constexpr (WREG) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          areg[cc][tap][h] = *reinterpret_cast<const h8*>(a.wpk + (size_t)cc * G::W_BYTES_FULL +
+                                                           ((tap * 2 + h) * 2 * MT + kg * MT + l31) * 16);
+  }
 
   // one K-chunk of multiply; MORE: also issue the next step's DMA slots.  Explicit software pipeline over the
   // 9 taps: the fragments of tap t+1 are read from LDS before the MFMAs of tap t are issued, and the DMA slots of
@@ -238,17 +267,24 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   struct Frags {
     h8 ah[G::MTB], al[G::MTB], bh[NBW], bl[NBW];
   };
-  auto load_frags = [&](Frags& f, const char* la, const char* lb, int tap) {
+  // `tap` runs over the CPS * 9 (chunk, tap) pairs of a step
+  auto load_frags = [&](Frags& f, const char* la, const char* lb, int tapx) {
+    const int cc = tapx / 9, tap = tapx % 9;
     const int dy = tap / 3, dx = tap % 3;
+    if constexpr (WREG) {
+      f.ah[0] = areg[cc][tap][0];
+      f.al[0] = areg[cc][tap][1];
+    } else {
 #pragma unroll
-    for (int m = 0; m < G::MTB; ++m) {
-      f.ah[m] = *reinterpret_cast<const h8*>(la + ((tap * 2 + 0) * 2 * MT + m * 32) * 16);
-      f.al[m] = *reinterpret_cast<const h8*>(la + ((tap * 2 + 1) * 2 * MT + m * 32) * 16);
+      for (int m = 0; m < G::MTB; ++m) {
+        f.ah[m] = *reinterpret_cast<const h8*>(la + ((tap * 2 + 0) * 2 * MT + m * 32) * 16);
+        f.al[m] = *reinterpret_cast<const h8*>(la + ((tap * 2 + 1) * 2 * MT + m * 32) * 16);
+      }
     }
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
-      f.bh[n] = *reinterpret_cast<const h8*>(lb + ((n * G::MBH + dy) * G::LW + dx) * 16);
-      f.bl[n] = *reinterpret_cast<const h8*>(lb + (G::PLANE + (n * G::MBH + dy) * G::LW + dx) * 16);
+      f.bh[n] = *reinterpret_cast<const h8*>(lb + cc * G::IN_BYTES_C + ((n * G::MBH + dy) * G::LW + dx) * 16);
+      f.bl[n] = *reinterpret_cast<const h8*>(lb + cc * G::IN_BYTES_C + (G::PLANE + (n * G::MBH + dy) * G::LW + dx) * 16);
     }
   };
   // KIND: 0 = nothing follows, 1 = the next step's halo + weights come by DMA
@@ -258,12 +294,14 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     char* nstage = lds + (stage ^ 1) * G::STAGE;
     const char* lb = lds + stage * G::STAGE + b_lane;
     const char* la = lds + stage * G::STAGE + a_lane;
+    constexpr int NTAP = 9 * G::CPS;                              // (chunk, tap) pairs of one step
+    constexpr int DMA_TAPS = WREG ? NTAP : HS_DMA_TAPS;           // taps the next step's DMA slots are spread over
     Frags fr[2];
     load_frags(fr[0], la, lb, 0);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < NTAP; ++tap) {
       const Frags& f = fr[tap & 1];
-      if (tap + 1 < 9) load_frags(fr[(tap + 1) & 1], la, lb, tap + 1);
+      if (tap + 1 < NTAP) load_frags(fr[(tap + 1) & 1], la, lb, tap + 1);
       if constexpr (NBW == 1) __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads up front
 #pragma unroll
       for (int m = 0; m < G::MTB; ++m)
@@ -271,10 +309,10 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
         for (int n = 0; n < NBW; ++n)
           acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[m], f.bh[n], acc[m][n], 0, 0, 0);
       if constexpr (MORE) {
-        // the next step's DMA slots are spread over the first HS_DMA_TAPS taps of this step
-        if (tap < HS_DMA_TAPS) {
+        // the next step's DMA slots are spread over the first DMA_TAPS taps of this step
+        if (tap < DMA_TAPS) {
 #pragma unroll
-          for (int sl = tap; sl < G::NS; sl += HS_DMA_TAPS) issue_slot(sl, nsrc, nw, nstage);
+          for (int sl = tap; sl < G::NS; sl += DMA_TAPS) issue_slot(sl, nsrc, nw, nstage);
         }
       }
 #pragma unroll
@@ -290,16 +328,16 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
       // schedule of this tap: the next tap's fragment reads are drip-fed between this tap's MFMAs (one ds_read per
       // MFMA) instead of being issued as one burst that lets the matrix pipe run dry
       if constexpr (NBW >= 2) {
-        constexpr int NRD = 2 * G::MTB + 2 * NBW;   // ds_read_b128 per tap
+        constexpr int NRD = (WREG ? 0 : 2 * G::MTB) + 2 * NBW;   // ds_read_b128 per tap
         constexpr int NMF = 3 * G::MTB * NBW;
-        if (tap + 1 < 9) {
+        if (tap + 1 < NTAP) {
 #pragma unroll
           for (int i = 0; i < NRD; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
           }
-          if (MORE && tap < HS_DMA_TAPS)
-            __builtin_amdgcn_sched_group_barrier(0x020, (G::NS + HS_DMA_TAPS - 1) / HS_DMA_TAPS, 0);   // this tap's DMA slots
+          if (MORE && tap < DMA_TAPS)
+            __builtin_amdgcn_sched_group_barrier(0x020, (G::NS + DMA_TAPS - 1) / DMA_TAPS, 0);   // this tap's DMA slots
           __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
         }
       }
@@ -692,6 +730,12 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     cur = nxt;
     stage ^= 1;
   }
+#ifdef PNPX_TUNING
+  if (a.wgt && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    a.wgt[2 * blockIdx.x + 1] = wall_clock64();
+  }
+#endif
   // half-split range guard: a stored hi half overflowed f16 (|value| >= 4095) or was NaN
   if constexpr (EPI != EPI_OUTC) {
     if (a.range_flag) {
@@ -715,12 +759,12 @@ inline int ensure_dyn_lds(const void* func, int bytes) {
   return PNPX_OK;
 }
 
-template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0>
+template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0>
 static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
-  using G = HsGeom<MT, NBW, MBW, NW>;
+  using G = HsGeom<MT, NBW, MBW, NW, WREG>;
   constexpr int LDS_REQ = G::LDS_BYTES + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES;
   static_assert(G::LDS_USED + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES <= 160 * 1024, "no LDS room for the low-resolution windows");
-  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS>), LDS_REQ));
+  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG>), LDS_REQ));
   ConvHsArgs a = a0;
   a.tilesX = (a.W + G::TW - 1) / G::TW;
   a.tilesY = (a.H + G::TH - 1) / G::TH;
@@ -751,6 +795,19 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
   if (grid > ntiles) grid = ntiles;
   if (grid >= 8) grid -= grid % 8;          // whole XCD groups (the kernel falls back to a plain walk otherwise)
   if (a.nct > 1 && (grid / 8) % a.nct != 0 && grid >= 8 * a.nct) grid -= grid % (8 * a.nct);
+#ifdef PNPX_TUNING   // PNPX_HS_WGT=<file>: per-workgroup start / end stamps of every launch (tools/wg_spread.py)
+  static unsigned long long* wbuf = nullptr;
+  const char* wfile = getenv("PNPX_HS_WGT");
+  hipEvent_t wev0 = nullptr, wev1 = nullptr;
+  if (wfile) {
+    if (!wbuf) PNPX_HIP(hipMalloc(&wbuf, 2 * 256 * 8));
+    PNPX_HIP(hipMemsetAsync(wbuf, 0, 2 * 256 * 8, s));
+    a.wgt = wbuf;
+    PNPX_HIP(hipEventCreate(&wev0));
+    PNPX_HIP(hipEventCreate(&wev1));
+    PNPX_HIP(hipEventRecord(wev0, s));
+  }
+#endif
 #ifdef HS_TRACE
   static unsigned long long* tbuf = nullptr;
   const char* tfile = getenv("PNPX_HS_TRACE");
@@ -760,9 +817,28 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
     a.trace = tbuf;
   }
 #endif
-  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS>), dim3((unsigned)grid),
+  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG>), dim3((unsigned)grid),
                      dim3((NW + HS_UPS_WAVES * UPS) * 64), lds_req, s, a);
   PNPX_LAUNCH_CHECK();
+#ifdef PNPX_TUNING
+  if (wfile) {
+    PNPX_HIP(hipEventRecord(wev1, s));
+    std::vector<unsigned long long> host(512);
+    PNPX_HIP(hipStreamSynchronize(s));
+    PNPX_HIP(hipMemcpy(host.data(), wbuf, 512 * 8, hipMemcpyDeviceToHost));
+    float evms = 0.f;
+    PNPX_HIP(hipEventElapsedTime(&evms, wev0, wev1));
+    (void)hipEventDestroy(wev0);
+    (void)hipEventDestroy(wev1);
+    if (FILE* f = fopen(wfile, "a")) {
+      fprintf(f, "conv_hs<%d,%d,%d,%d,e%d> W=%d H=%d B=%d G=%d nct=%d grid=%lld tiles=%lld event_us=%.1f |", MT, NBW, MBW, NW, EPI,
+              a.W, a.H, B, a.G0 + a.G1, a.nct, grid, ntiles, evms * 1e3);
+      for (long long i = 0; i < grid; ++i) fprintf(f, " %llu:%llu", host[2 * i], host[2 * i + 1]);
+      fprintf(f, "\n");
+      fclose(f);
+    }
+  }
+#endif
 #ifdef HS_TRACE
   if (tfile) {
     static std::vector<unsigned long long> host(4096);

@@ -173,10 +173,12 @@ __global__ __launch_bounds__(256) void maxpool2_hs_kernel(const HsRec* __restric
 // are staged once in LDS with dense, coalesced 32-byte loads, so every source record is fetched once per tile instead
 // of once per output pixel through the L1 (4 x), and the index arithmetic is per tile, not per pixel.  Same
 // association as ATen's kernel: (1-ly) * ((1-lx) * v00 + lx * v01) + ly * ((1-lx) * v10 + lx * v11).
-template <int TX>
+template <int TX, int R>
 __global__ __launch_bounds__(256) void upsample2x_hs_kernel(const HsRec* __restrict__ src, HsRec* __restrict__ dst, int h,
                                                             int w, int Ht, int Wt, float sy, float sx) {
-  constexpr int TY = 256 / TX;
+  // one workgroup = TX x TY output records, TY = R passes of 256 / TX rows: the taller the tile, the fewer times a source
+  // row is fetched (a one-row tile reads two source rows per output row = 4x the source tensor; 16 rows: 1.3x)
+  constexpr int TYP = 256 / TX, TY = TYP * R;
   constexpr int SW = TX / 2 + 2, SH = TY / 2 + 2;
   __shared__ uint4 tile[SH * SW * 2];
   const int H = 2 * h, W = 2 * w;
@@ -191,23 +193,33 @@ __global__ __launch_bounds__(256) void upsample2x_hs_kernel(const HsRec* __restr
     tile[k] = s[((size_t)(yy + 1) * (w + 2) + xx) * 2 + piece];
   }
   __syncthreads();
-  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-  const int x = X0 + tx, y = Y0 + ty;
-  if (x >= W || y >= H) return;
-  const float fy = sy * y, fx = sx * x;
-  const int y0 = (int)fy, x0 = (int)fx;
-  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-  const float ly = fy - y0, lx = fx - x0;
-  const float hy = 1.f - ly, hx = 1.f - lx;
+  const int tx = threadIdx.x % TX, ty0 = threadIdx.x / TX;
+  const int x = X0 + tx;
+  if (x >= W) return;
+  const float fx = sx * x;
+  const int x0 = (int)fx;
+  const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float lx = fx - x0;
+  const float hx = 1.f - lx;
   const HsRec* t = reinterpret_cast<const HsRec*>(tile);
-  float v00[8], v01[8], v10[8], v11[8], o[8];
-  hs_unpack(t[(y0 - r_lo) * SW + (x0 - c_lo)], v00);
-  hs_unpack(t[(y0 - r_lo) * SW + (x1 - c_lo)], v01);
-  hs_unpack(t[(y1 - r_lo) * SW + (x0 - c_lo)], v10);
-  hs_unpack(t[(y1 - r_lo) * SW + (x1 - c_lo)], v11);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
-  dst[(bg * (Ht + 2) + (y + 1)) * (Wt + 2) + x + 1] = hs_pack(o);
+  for (int r = 0; r < R; ++r) {
+    const int y = Y0 + ty0 + r * TYP;
+    if (y >= H) return;
+    const float fy = sy * y;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = fy - y0;
+    const float hy = 1.f - ly;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    hs_unpack(t[(y0 - r_lo) * SW + (x0 - c_lo)], v00);
+    hs_unpack(t[(y0 - r_lo) * SW + (x1 - c_lo)], v01);
+    hs_unpack(t[(y1 - r_lo) * SW + (x0 - c_lo)], v10);
+    hs_unpack(t[(y1 - r_lo) * SW + (x1 - c_lo)], v11);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = hy * (hx * v00[k] + lx * v01[k]) + ly * (hx * v10[k] + lx * v11[k]);
+    dst[(bg * (Ht + 2) + (y + 1)) * (Wt + 2) + x + 1] = hs_pack(o);
+  }
 }
 
 __global__ __launch_bounds__(256) void outc_residual_hs_kernel(const HsRec* __restrict__ feat, const float* __restrict__ x,
@@ -392,10 +404,12 @@ inline dim3 g1d(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 // gain is small; 24 is the default.  Deeper levels always run the whole batch.
 static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, const float* x, const float* sigma,
                            int sigma_stride, float* out, float* out_pre, int B, int H, int W, hipStream_t s,
-                           Recorder& rec, bool keep_all) {
+                           Recorder& rec, bool keep_all, int b_base = 0) {
+  // b_base: the B images of this call are images b_base .. b_base + B - 1 of the arena (x / sigma / out already point at
+  // the first of them): two halves of a batch can run as independent launch chains on two streams (dual_stream)
   char* A = static_cast<char*>(ar.buf.p);
   auto bpi = [&](const Act& d) { return act_bytes_per_image(CONV_HS, d.C, d.H, d.W); };
-  auto at = [&](const Act& d, int b0) { return A + d.off + (size_t)b0 * bpi(d); };
+  auto at = [&](const Act& d, int b0) { return A + d.off + (size_t)(b0 + b_base) * bpi(d); };
   auto rat = [&](const Act& d, int b0) { return reinterpret_cast<HsRec*>(at(d, b0)); };
   const bool no_pool_fuse = !ctx->opt_fuse_pool, no_outc_fuse = keep_all || !ctx->opt_fuse_outc;
   unsigned* const range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
@@ -432,6 +446,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
     Lh.inv_scale = D.inv_scale;
     ConvHsFuse fz = fuse;
     fz.range_flag = range_flag;
+    fz.wreg = ctx->opt_wreg;
     PNPX_TRY(launch_conv_hs(Lh, at(i0, b0), i0.C / 8, i1 ? at(*i1, b0) : nullptr, i1 ? i1->C / 8 : 0, at(o, b0), nb, o.H,
                             o.W, fz, s));
     return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * nb);
@@ -501,14 +516,11 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
       } else {
         const unsigned nbg = (unsigned)(nb * (below->C / 8));
         const int Wo = 2 * w, Ho = 2 * h;
-        if (Wo > 128) {
-          hipLaunchKernelGGL(upsample2x_hs_kernel<256>, dim3((Wo + 255) / 256, Ho, nbg), dim3(256), 0, s, rat(*below, b0),
-                             rat(P.u[l], b0), h, w, P.u[l].H, P.u[l].W, sy, sx);
-        } else if (Wo > 32) {
-          hipLaunchKernelGGL(upsample2x_hs_kernel<64>, dim3((Wo + 63) / 64, (Ho + 3) / 4, nbg), dim3(256), 0, s,
+        if (Wo > 32) {   // 64 x 16 output tiles
+          hipLaunchKernelGGL((upsample2x_hs_kernel<64, 4>), dim3((Wo + 63) / 64, (Ho + 15) / 16, nbg), dim3(256), 0, s,
                              rat(*below, b0), rat(P.u[l], b0), h, w, P.u[l].H, P.u[l].W, sy, sx);
-        } else {
-          hipLaunchKernelGGL(upsample2x_hs_kernel<32>, dim3((Wo + 31) / 32, (Ho + 7) / 8, nbg), dim3(256), 0, s,
+        } else {         // 32 x 16
+          hipLaunchKernelGGL((upsample2x_hs_kernel<32, 2>), dim3((Wo + 31) / 32, (Ho + 15) / 16, nbg), dim3(256), 0, s,
                              rat(*below, b0), rat(P.u[l], b0), h, w, P.u[l].H, P.u[l].W, sy, sx);
         }
         PNPX_LAUNCH_CHECK();
@@ -534,6 +546,19 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
   return PNPX_OK;
 }
 
+// Number of independent launch chains for a B-image forward: option "chains" (0 = automatic, n = exactly n when B >= n).
+static int launch_chains(const pnpx_ctx* ctx, int B, int H, int W) {
+  int n = ctx->opt_chains;
+  if (n == 0) {
+    // automatic: two chains where it was measured to pay (tools/ab_wall.py, 256^2: B = 6 1.155 -> 1.069 ms, B = 24
+    // 3.17 -> 3.07 ms per forward; B = 4 / 12 / 48: no gain or a loss) -- the per-GPU shards of an 8- and 2-way split
+    const long long q = (long long)B * H * W / (256 * 256);
+    n = ((q >= 5 && q <= 8) || (q >= 20 && q <= 28)) ? 2 : 1;
+  }
+  if (n > 8) n = 8;
+  return n > B ? B : (n < 1 ? 1 : n);
+}
+
 int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
                  int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena, int mode, bool keep_all) {
   if (!ctx->has_weights) {
@@ -551,6 +576,36 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
   const UNetPlan P = make_plan(mode, ar.capB, H, W);
   Recorder rec{prof, s};
   if (prof) PNPX_HIP(hipEventRecord((*prof->events)[0], s));
+  const int chains = hs && !prof ? launch_chains(ctx, B, H, W) : 1;
+  if (chains > 1) {
+    // Independent launch chains (contiguous slices of the batch) on the caller's stream + side streams.  Every kernel is
+    // a persistent grid of <= 256 one-per-CU workgroups; for SMALL batches most launches cannot fill the chip (48-200
+    // tiles at the deep levels) and each costs ~10 us of fill / drain, so slices that run side by side keep more CUs
+    // busy.  (At B = 48 the chip sits at its power cap for the whole forward and overlap buys nothing: measured 5.90 vs
+    // 5.90 ms)  Per-image results do not depend on the slicing (bit-identical, tested).
+    while ((int)ctx->side_streams.size() < chains - 1) {
+      hipStream_t st = nullptr;
+      hipEvent_t ev = nullptr;
+      PNPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      ctx->side_streams.push_back(st);
+      PNPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      ctx->side_joins.push_back(ev);
+    }
+    if (!ctx->side_fork) PNPX_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+    const size_t px = (size_t)H * W;
+    PNPX_HIP(hipEventRecord(ctx->side_fork, s));
+    for (int c = chains - 1; c >= 0; --c) {       // the caller's stream takes slice 0 last: its host-side issue overlaps
+      const int lo = (int)((long long)B * c / chains), hi = (int)((long long)B * (c + 1) / chains);
+      hipStream_t st = c ? ctx->side_streams[c - 1] : s;
+      if (c) PNPX_HIP(hipStreamWaitEvent(st, ctx->side_fork, 0));
+      Recorder none{nullptr, st};
+      PNPX_TRY(unet_forward_hs(ctx, ar, P, x + lo * px, sigma + (size_t)lo * sigma_stride, sigma_stride, out + lo * px,
+                               out_pre ? out_pre + lo * px : nullptr, hi - lo, H, W, st, none, keep_all, lo));
+      if (c) PNPX_HIP(hipEventRecord(ctx->side_joins[c - 1], st));
+    }
+    for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, ctx->side_joins[c - 1], 0));
+    return PNPX_OK;
+  }
   if (hs) return unet_forward_hs(ctx, ar, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec, keep_all);
 
   // ---- plain-fp32 path (conv_mode 0): padded planar fp32 activations, whole batch per launch
