@@ -86,6 +86,17 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params);
  * Any H, W >= 16; odd level sizes follow the reference's floor-pool / zero-pad rule (models/unet.py:82-85,109-113). */
 int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* out, float* out_preclamp,
                       int B, int H, int W, void* stream);
+/* ---- DRUNet denoiser (BASELINE config #5).  The reference ships only the KAIR building blocks
+ * (tfpnp/pnp/denoiser/models/basicblock.py: conv :61-101, ResBlock :211-227, upsample_convtranspose :413-419,
+ * downsample_strideconv :437-446); the topology is KAIR's UNetRes: bias-free, channels 64-128-256-512, nb ResBlocks per
+ * scale each way, strided / transposed 2x2 convolutions, additive skips, input = cat[x, sigma*1], 1 output channel.
+ * params_host: the state_dict's tensors concatenated in state_dict order (m_head.weight, m_down1.0.res.0.weight, ...,
+ * m_tail.weight; key list: tfpnp_amd/synth.py::drunet_param_specs), native PyTorch layouts.
+ * A context holds ONE denoiser: after pnpx_drunet_load every denoiser prox -- pnpx_unet_denoise and the denoiser call
+ * inside every solver entry below -- runs the DRUNet (out = clamp(net(cat[x, sigma*1]), 0, 1), H and W multiples of 8);
+ * pnpx_unet_load switches back.  Forward only: the *_backward / *_train entries return PNPX_ERR_ARG. */
+size_t pnpx_drunet_num_params(int nb);
+int pnpx_drunet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params, int nb);
 /* Vector-Jacobian product of pnpx_unet_denoise wrt x and sigma (weights are frozen): given grad_out [B,1,H,W] returns
  * grad_x [B,1,H,W] and grad_sigma [B].  This is what autograd computes through UNetDenoiser2D.forward when the
  * reference differentiates the solver for policy training (tfpnp/env/base.py:193-206, trainer/mddpg/trainer.py:171-192).

@@ -152,11 +152,49 @@ def gradient_goldens(den):
     save("solver_grads", in_sha=sha(d["y0"], d["mask"], d["x0"], a["sigma_d"], a["mu"], wts, d2["y0"], raw0), **res)
 
 
+def drunet_goldens():
+    """(11) DRUNet: the model assembled from the reference's own basicblock.py parts (ref_shim.make_drunet) on seeded inputs:
+    pre-clamp network output and the clamped denoiser output, plus one SPI ADMM call that uses it as the prox."""
+    from tests.golden_inputs import DRUNET_CASES, drunet_spi_case
+    params = synth.make_drunet_params(WEIGHT_SEED)
+    net = ref_shim.make_drunet(params)
+    assert [k for k, _ in synth.drunet_param_specs()] == list(net.state_dict().keys())
+
+    class Den(torch.nn.Module):          # tfpnp/pnp/denoiser/base.py:23-32 with the network swapped
+        def forward(self, x, sigma):
+            N, C, H, W = x.shape
+            sigma = sigma.view(N, 1, 1, 1)
+            noise_map = torch.ones(N, 1, H, W) * sigma
+            return torch.clamp(net(torch.cat([x, noise_map], dim=1)), 0, 1)
+
+    den = Den()
+    with torch.no_grad():
+        for (B, H, W, seed) in DRUNET_CASES:
+            x, sigma = denoiser_inputs(B, H, W, seed)
+            xin = torch.cat([t(x), torch.ones(B, 1, H, W) * t(sigma).view(B, 1, 1, 1)], 1)
+            save(f"drunet_B{B}_{H}x{W}", pre=net(xin), post=den(t(x), t(sigma)), in_sha=sha(x, sigma))
+        # the reference's SPI ADMM loop (tasks/spi/solver.py:17-52) with the DRUNet prox: the state after every single
+        # iteration (teacher-forcing fixtures, as for the UNet: the bisection prox is discontinuous)
+        spi = ref_shim.load_task_module("spi", "solver")
+        sol = spi.ADMMSolver_SPI(den)
+        d, sg, m = drunet_spi_case()
+        v = sol.reset({"x0": t(d["x0"])})
+        steps = {}
+        for i in range(sg.shape[1]):
+            v = sol((v, (t(d["x0"]), t(d["K"]))), (t(sg[:, i:i + 1]), t(m[:, i:i + 1])))
+            steps[f"admm_step{i + 1}"] = v
+        save("drunet_spi_B2_64x64", in_sha=sha(d["x0"], sg, m), **steps)
+
+
 def main():
     assert ref_shim.available(), "reference not mounted"
     ref_shim.install()
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--only-drunet" in sys.argv:
+        print("[11] DRUNet")
+        drunet_goldens()
+        return
     if "--only-grads" in sys.argv or "--only-envs" in sys.argv:
         den = ref_shim.make_denoiser(synth.make_unet_params(WEIGHT_SEED), tempfile.mkdtemp())
         if "--only-grads" in sys.argv:

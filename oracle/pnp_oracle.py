@@ -164,6 +164,49 @@ def denoise(x, sigma, params):
     return torch.clamp(unet_forward(torch.cat([x, noise_map], dim=1), params), 0, 1)
 
 
+def drunet_forward(x, params):
+    """DRUNet (KAIR UNetRes) on a [B, 2, H, W] input (image + noise-level map); returns the PRE-clamp output.
+    Parts as in tfpnp/pnp/denoiser/models/basicblock.py: bias-free Conv2d 3x3 pad 1 (conv :61-66), ResBlock =
+    x + conv(relu(conv(x))) (:211-227), strided Conv2d k2 s2 p0 (downsample_strideconv :437-446), ConvTranspose2d k2 s2 p0
+    (upsample_convtranspose :413-419); additive skips; H, W multiples of 8."""
+    p = _to_t(params)
+    nb = sum(1 for k in p if k.startswith("m_body.") and k.endswith(".res.0.weight"))
+
+    def resblocks(v, prefix, first):
+        for i in range(first, first + nb):
+            r = F.conv2d(F.relu(F.conv2d(v, p[f"{prefix}.{i}.res.0.weight"], padding=1)), p[f"{prefix}.{i}.res.2.weight"], padding=1)
+            v = v + r
+        return v
+
+    x1 = F.conv2d(x, p["m_head.weight"], padding=1)
+    x2 = F.conv2d(resblocks(x1, "m_down1", 0), p[f"m_down1.{nb}.weight"], stride=2)
+    x3 = F.conv2d(resblocks(x2, "m_down2", 0), p[f"m_down2.{nb}.weight"], stride=2)
+    x4 = F.conv2d(resblocks(x3, "m_down3", 0), p[f"m_down3.{nb}.weight"], stride=2)
+    v = resblocks(x4, "m_body", 0)
+    v = resblocks(F.conv_transpose2d(v + x4, p["m_up3.0.weight"], stride=2), "m_up3", 1)
+    v = resblocks(F.conv_transpose2d(v + x3, p["m_up2.0.weight"], stride=2), "m_up2", 1)
+    v = resblocks(F.conv_transpose2d(v + x2, p["m_up1.0.weight"], stride=2), "m_up1", 1)
+    return F.conv2d(v + x1, p["m_tail.weight"], padding=1)
+
+
+def drunet_denoise(x, sigma, params):
+    """DRUNet behind the denoiser contract of UNetDenoiser2D.forward (tfpnp/pnp/denoiser/base.py:23-32): noise-level map
+    concatenated as a second channel, output clamped to [0, 1]."""
+    N, C, H, W = x.shape
+    noise_map = torch.ones(N, 1, H, W, dtype=x.dtype) * sigma.view(N, 1, 1, 1)
+    return torch.clamp(drunet_forward(torch.cat([x, noise_map], dim=1), params), 0, 1)
+
+
+class DRUNetDenoiser:
+    def __init__(self, params, dtype=None):
+        self.params = _to_t(params)
+        if dtype is not None:
+            self.params = {k: v.to(dtype) for k, v in self.params.items()}
+
+    def __call__(self, x, sigma):
+        return drunet_denoise(x, sigma, self.params)
+
+
 class Denoiser:
     def __init__(self, params, dtype=None):
         """dtype=torch.float64 gives the double-precision yardstick used by the drift tests."""

@@ -72,3 +72,45 @@ def make_denoiser(params, tmpdir):
     path = os.path.join(tmpdir, "unet-synth.pt")
     torch.save(sd, path)
     return UNetDenoiser2D(ckpt_path=path)
+
+
+def make_drunet(params, in_nc=2, out_nc=1, nc=(64, 128, 256, 512), nb=4):
+    """DRUNet assembled from the REFERENCE'S OWN building blocks (tfpnp/pnp/denoiser/models/basicblock.py: conv :61-101,
+    ResBlock :211-227, upsample_convtranspose :413-419, downsample_strideconv :437-446, sequential :15-36), following the
+    published topology of KAIR's UNetRes (the reference ships the blocks but no model that uses them).  The synthetic
+    weights go in through load_state_dict(strict=True) under KAIR's key names."""
+    install()
+    import torch.nn as nn
+    from tfpnp.pnp.denoiser.models import basicblock as B
+
+    class UNetRes(nn.Module):
+        def __init__(self):
+            super().__init__()
+            rb = lambda c: B.ResBlock(c, c, bias=False, mode="CRC")
+            self.m_head = B.conv(in_nc, nc[0], bias=False, mode="C")
+            self.m_down1 = B.sequential(*[rb(nc[0]) for _ in range(nb)], B.downsample_strideconv(nc[0], nc[1], bias=False, mode="2"))
+            self.m_down2 = B.sequential(*[rb(nc[1]) for _ in range(nb)], B.downsample_strideconv(nc[1], nc[2], bias=False, mode="2"))
+            self.m_down3 = B.sequential(*[rb(nc[2]) for _ in range(nb)], B.downsample_strideconv(nc[2], nc[3], bias=False, mode="2"))
+            self.m_body = B.sequential(*[rb(nc[3]) for _ in range(nb)])
+            self.m_up3 = B.sequential(B.upsample_convtranspose(nc[3], nc[2], bias=False, mode="2"), *[rb(nc[2]) for _ in range(nb)])
+            self.m_up2 = B.sequential(B.upsample_convtranspose(nc[2], nc[1], bias=False, mode="2"), *[rb(nc[1]) for _ in range(nb)])
+            self.m_up1 = B.sequential(B.upsample_convtranspose(nc[1], nc[0], bias=False, mode="2"), *[rb(nc[0]) for _ in range(nb)])
+            self.m_tail = B.conv(nc[0], out_nc, bias=False, mode="C")
+
+        def forward(self, x0):
+            x1 = self.m_head(x0)
+            x2 = self.m_down1(x1)
+            x3 = self.m_down2(x2)
+            x4 = self.m_down3(x3)
+            x = self.m_body(x4)
+            x = self.m_up3(x + x4)
+            x = self.m_up2(x + x3)
+            x = self.m_up1(x + x2)
+            return self.m_tail(x + x1)
+
+    net = UNetRes()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    net.eval()
+    for prm in net.parameters():
+        prm.requires_grad_(False)
+    return net

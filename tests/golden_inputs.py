@@ -49,6 +49,19 @@ def spi_grid(seed=3):
     return zt, K1, K, mu
 
 
+# DRUNet fixtures (oracle/make_goldens.py::drunet_goldens): (B, H, W, seed); H, W multiples of 8, one non-square
+DRUNET_CASES = [(2, 32, 32, 61), (2, 64, 64, 62), (1, 128, 128, 63), (2, 48, 80, 64)]
+
+
+def drunet_spi_case():
+    B, H, W, seed = 2, 64, 64, 71
+    d = synth.make_spi_batch(B, H, W, K=6, seed=seed)
+    rs = np.random.RandomState(seed + 1)
+    sg = rs.uniform(15 / 255.0, 70 / 255.0, (B, 3)).astype(np.float32)
+    m = rs.uniform(50, 120, (B, 3)).astype(np.float32)
+    return d, sg, m
+
+
 POLICY_SEED = 4242
 ROLLOUT_CONTINUE_BIAS = 3.0   # added to the "continue" logit of the rollout actor so that the episode runs > 1 step
 

@@ -280,3 +280,34 @@ def test_radon_forward_vs_analytic_ellipses_full_geometry():
     lhs, rhs = float((O.radon_forward(xn, angles, det) * yn).sum()), float((xn * O.radon_backprojection(yn, angles, R)).sum())
     print(f"adjoint mismatch on white noise: {abs(lhs - rhs) / max(abs(lhs), abs(rhs)):.3e}")
     assert abs(lhs - rhs) < 0.1 * max(abs(lhs), abs(rhs))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# DRUNet: fixtures written by the model assembled from the reference's own basicblock.py parts (oracle/ref_shim.py)
+@pytest.mark.parametrize("B,H,W,seed", __import__("tests.golden_inputs", fromlist=["DRUNET_CASES"]).DRUNET_CASES)
+def test_drunet(B, H, W, seed):
+    g = golden(f"drunet_B{B}_{H}x{W}")
+    params = synth.make_drunet_params(0)
+    x, sigma = denoiser_inputs(B, H, W, seed)
+    assert (sha(x, sigma) == g["in_sha"]).all()
+    xin = torch.cat([t(x), torch.ones(B, 1, H, W) * t(sigma).view(B, 1, 1, 1)], 1)
+    with torch.no_grad():
+        assert rel(O.drunet_forward(xin, params), g["pre"]) < TOL
+        post = O.drunet_denoise(t(x), t(sigma), params)
+    assert rel(post, g["post"]) < TOL
+    frac_inside = float(((g["pre"] > 0) & (g["pre"] < 1)).mean())
+    assert 0.2 < frac_inside < 0.95          # the synthetic net neither saturates nor bypasses the clamp
+
+
+def test_drunet_spi_admm():
+    from tests.golden_inputs import drunet_spi_case
+    g = golden("drunet_spi_B2_64x64")
+    d, sg, m = drunet_spi_case()
+    assert (sha(d["x0"], sg, m) == g["in_sha"]).all()
+    den = O.DRUNetDenoiser(synth.make_drunet_params(0))
+    x0 = t(d["x0"])
+    v = O.admm_reset(x0)
+    with torch.no_grad():
+        for i in range(sg.shape[1]):
+            v = O.spi_admm(den, v, x0, t(d["K"]), t(sg[:, i:i + 1]), t(m[:, i:i + 1]))
+            assert rel(v, g[f"admm_step{i + 1}"]) < 5e-6

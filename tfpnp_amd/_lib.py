@@ -40,6 +40,8 @@ _SIGNATURES = {
     "pnpx_ctx_bytes": (C.c_size_t, [c_void_p]),
     "pnpx_unet_num_params": (C.c_size_t, []),
     "pnpx_unet_load": (C.c_int, [c_void_p, c_void_p, C.c_size_t]),
+    "pnpx_drunet_num_params": (C.c_size_t, [C.c_int]),
+    "pnpx_drunet_load": (C.c_int, [c_void_p, c_void_p, C.c_size_t, C.c_int]),
     "pnpx_unet_denoise": (C.c_int, [c_void_p, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, c_void_p]),
     "pnpx_unet_denoise_backward": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, c_void_p]),
     "pnpx_unet_denoise_train": (C.c_int, [c_void_p, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), c_void_p]),

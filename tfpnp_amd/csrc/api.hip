@@ -132,6 +132,7 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx) {
   for (pnpx::UNetArena* a : {&ctx->arena, &ctx->arena_grad})
     if (a->buf.p) (void)hipFree(a->buf.p);
   policy_free(ctx);
+  pnpx::drunet_free(ctx);
   pnpx::train_cache_free(ctx);
   if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
   for (auto& t : ctx->twiddle)
@@ -271,7 +272,8 @@ int pnpx_ctx_status(pnpx_ctx* ctx) {
 
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
   if (!ctx) return 0;
-  size_t n = ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_grad.buf.bytes + ctx->scratch.bytes;
+  size_t n = ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_grad.buf.bytes + ctx->scratch.bytes +
+             ctx->drunet.weights.bytes + ctx->drunet.arena.bytes;
   for (const auto& sl : ctx->train_ring) n += sl.arena.buf.bytes + sl.pre.bytes;
   return n;
 }
@@ -284,8 +286,16 @@ size_t pnpx_unet_num_params(void) {
   return n + 32 + 1;
 }
 
+size_t pnpx_drunet_num_params(int nb) { return (nb >= 1 && nb <= 8) ? pnpx::drunet_num_params(nb) : 0; }
+
+int pnpx_drunet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params, int nb) {
+  LOCK_CTX(ctx);
+  return pnpx::drunet_load(ctx, params_host, n_params, nb);
+}
+
 int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
   LOCK_CTX(ctx);
+  pnpx::drunet_free(ctx);   // a context holds ONE denoiser
   if (!params_host || n_params != pnpx_unet_num_params()) {
     set_error("pnpx_unet_load: expected %zu parameters, got %zu", pnpx_unet_num_params(), n_params);
     return PNPX_ERR_ARG;

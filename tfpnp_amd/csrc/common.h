@@ -105,6 +105,18 @@ struct PolicyNet {
   int capB = 0, capH = 0, capW = 0;
 };
 
+// DRUNet denoiser (drunet.hip): packed weights per MFMA launch in state_dict order + its own activation arena
+struct DruNet {
+  bool loaded = false;
+  int nb = 0;
+  std::vector<ConvLayerHsDev> layers;
+  const float* head_w = nullptr;   // [64][2][3][3] native (VALU head convolution)
+  const float* zero = nullptr;     // [1024] zeros: the bias operand of the bias-free network
+  const float* e0 = nullptr;       // [32] = (1, 0, ...): channel selector of the fused tail epilogue, followed by zeros
+  DeviceBuf weights, arena;
+  int capB = 0, capH = 0, capW = 0;
+};
+
 }  // namespace pnpx
 
 struct pnpx_ctx {
@@ -162,6 +174,8 @@ struct pnpx_ctx {
   bool train_alloc_failed = false;                 // stop retrying after an out-of-memory until the option is set again
   // --- policy actor
   pnpx::PolicyNet policy;
+  // --- DRUNet denoiser (when loaded it IS the context's denoiser: every prox call of every solver runs it)
+  pnpx::DruNet drunet;
   // --- solver scratch (complex fields etc.), grown on demand
   pnpx::DeviceBuf scratch;
   // --- FFT twiddle tables e^{-2 pi i m / N}, one per transform length: device float2[N]
@@ -223,6 +237,13 @@ int unet_denoise_train(pnpx_ctx* ctx, const float* x, const float* sigma, int si
 int unet_denoise_backward_ticket(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride,
                                  const float* grad_out, float* grad_x, float* grad_sigma, int B, int H, int W,
                                  hipStream_t s, unsigned long long ticket);
+
+// DRUNet denoiser (drunet.hip)
+size_t drunet_num_params(int nb);
+int drunet_load(pnpx_ctx* ctx, const float* params, size_t n, int nb);
+int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre, int B,
+                   int H, int W, hipStream_t s);
+void drunet_free(pnpx_ctx* ctx);
 
 // Policy actor (policy.hip)
 size_t policy_num_params(int num_inputs, int n_det, int spi_head);

@@ -1,0 +1,393 @@
+// DRUNet denoiser forward on gfx950 (BASELINE config #5: "Poisson prox + DRUNet denoiser").
+//
+// The reference ships the KAIR building blocks but no model (tfpnp/pnp/denoiser/models/basicblock.py: conv :61-101,
+// ResBlock :211-227, upsample_convtranspose :413-419, downsample_strideconv :437-446); the topology is KAIR's UNetRes
+// (DRUNet, Zhang et al. 2021): bias-free, 4 scales of 64-128-256-512 channels, nb ResBlocks per scale each way,
+//   x1 = head(cat[x, sigma]);  x2 = down1(x1) = strided2x2(ResBlocks(x1));  x3, x4 likewise;  v = body(x4);
+//   v = up3(v + x4) = ResBlocks(convT2x2(v + x4));  up2(v + x3);  up1(v + x2);  out = tail(v + x1),
+// behind the denoiser contract of UNetDenoiser2D.forward (denoiser/base.py:23-32): noise-level map as second input
+// channel, output clamped to [0, 1].
+//
+// Everything runs on the half-split f16x3 MFMA convolution of the UNet (conv_hs.hip) over HS8 tensors:
+//   * ResBlock = conv3x3 + ReLU (EPI_ACT, slope 0), then conv3x3 + residual add in the epilogue (EPI_RES, linear);
+//   * strided 2x2 conv = space-to-depth re-layout (record copies) + a 1x1 convolution over 4*Cin channels;
+//   * transposed 2x2 conv = a 1x1 convolution to 4*Cout channels + depth-to-space re-layout;
+//     (1x1 convolutions run as 3x3 launches whose weights are zero outside the centre tap -- 6 of the 64 launches);
+//   * head (K = 18) on the vector ALU straight from the fp32 image (conv_first_hs_kernel, as the UNet's first layer);
+//   * tail (64 -> 1) as a 32-cout launch with the fused "1x1 + residual + clamp" epilogue (EPI_OUTC) selecting channel 0.
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "conv_first.h"
+#include "conv_hs.h"
+#include "hs_rec.h"
+
+namespace pnpx {
+
+namespace {
+
+constexpr int DRU_NC[4] = {64, 128, 256, 512};
+
+// [B][G][H+2][W+2] -> [B][4G][H/2+2][W/2+2]; output group = (dy*2+dx)*G + g holds input pixel (2y+dy, 2x+dx)
+__global__ __launch_bounds__(256) void dru_s2d_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int G, int H,
+                                                      int W, size_t n) {   // n = B*4G*(H/2)*(W/2)*2 16-byte pieces
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int piece = (int)(i & 1);
+  size_t t = i >> 1;
+  const int Wo = W / 2, Ho = H / 2;
+  const int x = (int)(t % Wo);
+  t /= Wo;
+  const int y = (int)(t % Ho);
+  t /= Ho;
+  const int go = (int)(t % (4 * G));
+  const size_t b = t / (4 * G);
+  const int ph = go / G, g = go - ph * G;
+  const size_t s = ((b * G + g) * (H + 2) + (2 * y + (ph >> 1) + 1)) * (W + 2) + 2 * x + (ph & 1) + 1;
+  const size_t d = ((b * 4 * G + go) * (Ho + 2) + (y + 1)) * (Wo + 2) + x + 1;
+  dst[d * 2 + piece] = src[s * 2 + piece];
+}
+
+// [B][4G][h+2][w+2] -> [B][G][2h+2][2w+2]; input group (dy*2+dx)*G + g at (y, x) lands at (2y+dy, 2x+dx) of group g
+__global__ __launch_bounds__(256) void dru_d2s_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int G, int h,
+                                                      int w, size_t n) {   // n = B*G*(2h)*(2w)*2 pieces
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int piece = (int)(i & 1);
+  size_t t = i >> 1;
+  const int W = 2 * w, H = 2 * h;
+  const int X = (int)(t % W);
+  t /= W;
+  const int Y = (int)(t % H);
+  t /= H;
+  const int g = (int)(t % G);
+  const size_t b = t / G;
+  const int ph = (Y & 1) * 2 + (X & 1);
+  const size_t s = ((b * 4 * G + ph * G + g) * (h + 2) + (Y / 2 + 1)) * (w + 2) + X / 2 + 1;
+  const size_t d = ((b * G + g) * (H + 2) + (Y + 1)) * (W + 2) + X + 1;
+  dst[d * 2 + piece] = src[s * 2 + piece];
+}
+
+// out = a + b on interior records (fp32 add of the recombined halves, re-split)
+__global__ __launch_bounds__(256) void dru_add_kernel(const HsRec* __restrict__ a, const HsRec* __restrict__ b,
+                                                      HsRec* __restrict__ out, int H, int W, size_t n) {   // n = B*G*H*W
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W);
+  size_t t = i / W;
+  const int y = (int)(t % H);
+  const size_t bg = t / H;
+  const size_t r = (bg * (H + 2) + (y + 1)) * (W + 2) + x + 1;
+  float va[8], vb[8];
+  hs_unpack(a[r], va);
+  hs_unpack(b[r], vb);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) va[k] += vb[k];
+  out[r] = hs_pack(va);
+}
+
+inline dim3 g1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+struct LayerDesc {
+  int kind;   // 0 head, 1 res conv a (ReLU), 2 res conv b (+res), 3 strided 2x2, 4 transposed 2x2, 5 tail
+  int cin, cout;
+};
+// state_dict order (KAIR UNetRes): head; down1..3 = nb x (res.0, res.2) + strided conv; body; up3..1 = convT + nb x (..); tail
+std::vector<LayerDesc> dru_layers(int nb) {
+  std::vector<LayerDesc> L;
+  L.push_back({0, 2, DRU_NC[0]});
+  auto res = [&](int c) {
+    for (int i = 0; i < nb; ++i) {
+      L.push_back({1, c, c});
+      L.push_back({2, c, c});
+    }
+  };
+  for (int l = 0; l < 3; ++l) {
+    res(DRU_NC[l]);
+    L.push_back({3, DRU_NC[l], DRU_NC[l + 1]});
+  }
+  res(DRU_NC[3]);
+  for (int l = 2; l >= 0; --l) {
+    L.push_back({4, DRU_NC[l + 1], DRU_NC[l]});
+    res(DRU_NC[l]);
+  }
+  L.push_back({5, DRU_NC[0], 1});
+  return L;
+}
+size_t layer_params(const LayerDesc& d) {
+  const int k = (d.kind == 3 || d.kind == 4) ? 4 : 9;
+  return (size_t)d.cin * d.cout * k;
+}
+
+}  // namespace
+
+size_t drunet_num_params(int nb) {
+  size_t n = 0;
+  for (const LayerDesc& d : dru_layers(nb)) n += layer_params(d);
+  return n;
+}
+
+void drunet_free(pnpx_ctx* ctx) {
+  DruNet& N = ctx->drunet;
+  (void)hipDeviceSynchronize();
+  if (N.weights.p) (void)hipFree(N.weights.p);
+  if (N.arena.p) (void)hipFree(N.arena.p);
+  N = DruNet();
+}
+
+int drunet_load(pnpx_ctx* ctx, const float* params, size_t n, int nb) {
+  if (nb < 1 || nb > 8 || !params || n != drunet_num_params(nb)) {
+    set_error("pnpx_drunet_load: expected %zu parameters for nb=%d (1..8), got %zu", nb >= 1 && nb <= 8 ? drunet_num_params(nb) : (size_t)0, nb, n);
+    return PNPX_ERR_ARG;
+  }
+  const std::vector<LayerDesc> L = dru_layers(nb);
+  std::vector<float> host;   // blob: packed HS weights per MFMA layer, head weights (native), zero bias, e0, 0
+  auto align = [&]() { host.resize((host.size() + 255) & ~(size_t)255, 0.f); };
+  std::vector<size_t> off(L.size(), 0);
+  std::vector<ConvLayerHsDev> dev(L.size());
+  const float* src = params;
+  std::vector<float> w3;
+  size_t head_off = 0;
+  for (size_t i = 0; i < L.size(); ++i) {
+    const LayerDesc& d = L[i];
+    const float* w = src;
+    src += layer_params(d);
+    if (d.kind == 0) {   // head: native [64][2][3][3] for the VALU kernel
+      align();
+      head_off = host.size();
+      host.insert(host.end(), w, w + layer_params(d));
+      continue;
+    }
+    int cin = d.cin, cout = d.cout;
+    const float* wp = w;
+    if (d.kind == 3) {          // Conv2d k2 s2 [cout][cin][2][2] -> 1x1 over the space-to-depth input (phase-major channels)
+      cin = 4 * d.cin;
+      w3.assign((size_t)cout * cin * 9, 0.f);
+      for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < d.cin; ++ci)
+          for (int ph = 0; ph < 4; ++ph) w3[((size_t)co * cin + ph * d.cin + ci) * 9 + 4] = w[((size_t)co * d.cin + ci) * 4 + ph];
+      wp = w3.data();
+    } else if (d.kind == 4) {   // ConvTranspose2d k2 s2 [cin][cout][2][2] -> 1x1 to 4*cout phase-major channels
+      cout = 4 * d.cout;
+      w3.assign((size_t)cout * cin * 9, 0.f);
+      for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < d.cout; ++co)
+          for (int ph = 0; ph < 4; ++ph) w3[((size_t)(ph * d.cout + co) * cin + ci) * 9 + 4] = w[((size_t)ci * d.cout + co) * 4 + ph];
+      wp = w3.data();
+    } else if (d.kind == 5) {   // tail [1][64][3][3] -> 32 couts, rows 1..31 zero
+      cout = 32;
+      w3.assign((size_t)cout * cin * 9, 0.f);
+      std::memcpy(w3.data(), w, sizeof(float) * (size_t)cin * 9);
+      wp = w3.data();
+    }
+    const int mt = conv_hs_mt(cout);
+    const int cin_pad = (cin + 15) / 16 * 16;
+    align();
+    off[i] = host.size();
+    const size_t n16 = (size_t)cout * cin_pad * 9 * 2;
+    host.resize(host.size() + (n16 + 1) / 2, 0.f);
+    const float scale = pack_conv_weights_hs(wp, cout, cin, mt, reinterpret_cast<uint16_t*>(host.data() + off[i]));
+    dev[i].cin = cin;
+    dev[i].cout = cout;
+    dev[i].cin_pad = cin_pad;
+    dev[i].mt = mt;
+    dev[i].inv_scale = 1.0f / (scale * HS_ASCALE);
+  }
+  align();
+  const size_t zoff = host.size();
+  host.resize(host.size() + 1024, 0.f);          // zero bias (largest cout: 1024)
+  align();
+  const size_t eoff = host.size();
+  host.resize(host.size() + 32, 0.f);            // e0: the fused tail epilogue's 1x1 weights select channel 0
+  host[eoff] = 1.0f;
+  host.resize(host.size() + 1024, 0.f);          // + a zero scalar (outc bias) and DMA over-read slack
+  drunet_free(ctx);
+  if (ctx->weights.p) {           // a context holds ONE denoiser: loading a DRUNet unloads the UNet
+    (void)hipFree(ctx->weights.p);
+    ctx->weights = DeviceBuf();
+    ctx->has_weights = false;
+    train_cache_free(ctx);
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, host.size() * sizeof(float));
+  if (e != hipSuccess) {
+    set_error("DRUNet weight allocation of %zu bytes failed: %s", host.size() * sizeof(float), hipGetErrorString(e));
+    return PNPX_ERR_ALLOC;
+  }
+  PNPX_HIP(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  DruNet& N = ctx->drunet;
+  float* d = static_cast<float*>(p);
+  for (size_t i = 0; i < L.size(); ++i) dev[i].w = reinterpret_cast<char*>(d + off[i]);
+  N.layers = dev;
+  N.head_w = d + head_off;
+  N.zero = d + zoff;
+  N.e0 = d + eoff;
+  N.nb = nb;
+  N.weights.p = p;
+  N.weights.bytes = host.size() * sizeof(float);
+  N.loaded = true;
+  return PNPX_OK;
+}
+
+namespace {
+
+struct DruPlan {
+  // per level l: S (skip / level input), P, Q (ResBlock outputs, alternating), M (ResBlock middle; skip sums), U (decoder
+  // level input, l <= 2), DT (space-to-depth input of the strided conv / output of the transposed conv, l >= 1: 2*C_l ch)
+  size_t S[4], P[4], Q[4], M[4], U[4], DT[4];
+  size_t zimg;     // [B][H][W] fp32 zeros (residual operand of the fused tail epilogue)
+  size_t total;
+};
+size_t rec_bytes(int C, int h, int w) { return (size_t)(C / 8) * (h + 2) * (w + 2) * 32; }
+DruPlan dru_plan(int capB, int H, int W) {
+  DruPlan P{};
+  size_t off = 0;
+  auto add = [&](size_t& o, size_t bytes_per_image) {
+    o = off;
+    off += bytes_per_image * capB;
+    off = (off + 255) & ~(size_t)255;
+  };
+  for (int l = 0; l < 4; ++l) {
+    const int h = H >> l, w = W >> l, c = DRU_NC[l];
+    add(P.S[l], rec_bytes(c, h, w));
+    add(P.P[l], rec_bytes(c, h, w));
+    add(P.Q[l], rec_bytes(c, h, w));
+    add(P.M[l], rec_bytes(c, h, w));
+    if (l <= 2) add(P.U[l], rec_bytes(c, h, w));
+    if (l >= 1) add(P.DT[l], rec_bytes(2 * c, h, w));
+  }
+  add(P.zimg, sizeof(float) * (size_t)H * W);
+  P.total = off + (1u << 20);
+  return P;
+}
+
+}  // namespace
+
+int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
+                   int B, int H, int W, hipStream_t s) {
+  DruNet& N = ctx->drunet;
+  if (!N.loaded) {
+    set_error("DRUNet denoiser called before pnpx_drunet_load");
+    return PNPX_ERR_NO_WEIGHTS;
+  }
+  if (B <= 0 || H < 8 || W < 8 || (H & 7) || (W & 7)) {
+    set_error("DRUNet: need B > 0 and H, W positive multiples of 8 (three 2x2 strided convolutions; got B=%d H=%d W=%d)", B, H, W);
+    return PNPX_ERR_SHAPE;
+  }
+  if (B > N.capB || H != N.capH || W != N.capW) {     // (re)lay the arena out: zero borders are written here, once
+    const int nb_img = (H == N.capH && W == N.capW && N.capB > B) ? N.capB : B;
+    const DruPlan Pl = dru_plan(nb_img, H, W);
+    PNPX_HIP(hipDeviceSynchronize());
+    if (N.arena.bytes < Pl.total) {
+      if (N.arena.p) PNPX_HIP(hipFree(N.arena.p));
+      N.arena = DeviceBuf();
+      N.capB = N.capH = N.capW = 0;
+      void* p = nullptr;
+      hipError_t e = hipMalloc(&p, Pl.total);
+      if (e != hipSuccess) {
+        set_error("DRUNet arena allocation of %zu bytes failed: %s", Pl.total, hipGetErrorString(e));
+        return PNPX_ERR_ALLOC;
+      }
+      N.arena.p = p;
+      N.arena.bytes = Pl.total;
+    }
+    PNPX_HIP(hipMemset(N.arena.p, 0, N.arena.bytes));
+    N.capB = nb_img;
+    N.capH = H;
+    N.capW = W;
+  }
+  const DruPlan Pl = dru_plan(N.capB, H, W);
+  char* A = static_cast<char*>(N.arena.p);
+  unsigned* const range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
+  const std::vector<LayerDesc> L = dru_layers(N.nb);
+  size_t li = 0;
+
+  // one MFMA convolution launch: layer li, `in` (cin channels) -> `outp`
+  auto conv = [&](const char* in, char* outp, int lvl_h, int lvl_w, float slope, const char* res, bool tail) -> int {
+    const ConvLayerHsDev& D = N.layers[li];
+    ConvLayerHs Lh;
+    Lh.cin = D.cin;
+    Lh.cout = D.cout;
+    Lh.cin_pad = D.cin_pad;
+    Lh.mt = D.mt;
+    Lh.w = D.w;
+    Lh.b = N.zero;
+    Lh.inv_scale = D.inv_scale;
+    ConvHsFuse f;
+    f.slope = slope;
+    f.res = res;
+    f.range_flag = range_flag;
+    f.wreg = 0;
+    if (tail) {
+      f.outc_w = N.e0;
+      f.outc_b = N.e0 + 32;      // a zero
+      f.x_in = reinterpret_cast<const float*>(A + Pl.zimg);
+      f.out_img = out;
+      f.out_pre = out_pre;
+    }
+    ++li;
+    return launch_conv_hs(Lh, in, D.cin_pad / 8, nullptr, 0, outp, B, lvl_h, lvl_w, f, s);
+  };
+  auto resblocks = [&](int l, char* cur, char** result) -> int {
+    const int h = H >> l, w = W >> l;
+    char* pq[2] = {A + Pl.P[l], A + Pl.Q[l]};
+    int k = 0;
+    for (int i = 0; i < N.nb; ++i) {
+      char* mid = A + Pl.M[l];
+      PNPX_TRY(conv(cur, mid, h, w, 0.f, nullptr, false));       // conv + ReLU
+      char* dst = pq[k];
+      if (dst == cur) dst = pq[k ^= 1];
+      PNPX_TRY(conv(mid, dst, h, w, 1.f, cur, false));            // conv + x
+      cur = dst;
+      k ^= 1;
+    }
+    *result = cur;
+    return PNPX_OK;
+  };
+
+  // head: cat[x, sigma] -> 64 channels, linear (VALU, exact fp32 FMA chains)
+  hipLaunchKernelGGL(conv_first_hs_kernel, dim3((H * W + 255) / 256, DRU_NC[0] / 8, B), dim3(256), 0, s, x, sigma,
+                     sigma_stride, N.head_w, N.zero, reinterpret_cast<HsRec*>(A + Pl.S[0]), H, W, 1.0f);
+  PNPX_LAUNCH_CHECK();
+  li = 1;
+  char* cur = A + Pl.S[0];
+  for (int l = 0; l < 3; ++l) {
+    PNPX_TRY(resblocks(l, cur, &cur));
+    const int h = H >> l, w = W >> l, G = DRU_NC[l] / 8;
+    const size_t n = (size_t)B * 4 * G * (h / 2) * (w / 2) * 2;
+    hipLaunchKernelGGL(dru_s2d_kernel, g1(n), dim3(256), 0, s, reinterpret_cast<const uint4*>(cur),
+                       reinterpret_cast<uint4*>(A + Pl.DT[l + 1]), G, h, w, n);
+    PNPX_LAUNCH_CHECK();
+    PNPX_TRY(conv(A + Pl.DT[l + 1], A + Pl.S[l + 1], h / 2, w / 2, 1.f, nullptr, false));
+    cur = A + Pl.S[l + 1];
+  }
+  PNPX_TRY(resblocks(3, cur, &cur));
+  for (int l = 2; l >= 0; --l) {
+    const int h = H >> (l + 1), w = W >> (l + 1), Gin = DRU_NC[l + 1] / 8, Gout = DRU_NC[l] / 8;
+    const size_t na = (size_t)B * Gin * h * w;
+    hipLaunchKernelGGL(dru_add_kernel, g1(na), dim3(256), 0, s, reinterpret_cast<const HsRec*>(cur),
+                       reinterpret_cast<const HsRec*>(A + Pl.S[l + 1]), reinterpret_cast<HsRec*>(A + Pl.M[l + 1]), h, w, na);
+    PNPX_LAUNCH_CHECK();
+    PNPX_TRY(conv(A + Pl.M[l + 1], A + Pl.DT[l + 1], h, w, 1.f, nullptr, false));
+    const size_t nd = (size_t)B * Gout * (2 * h) * (2 * w) * 2;
+    hipLaunchKernelGGL(dru_d2s_kernel, g1(nd), dim3(256), 0, s, reinterpret_cast<const uint4*>(A + Pl.DT[l + 1]),
+                       reinterpret_cast<uint4*>(A + Pl.U[l]), Gout, h, w, nd);
+    PNPX_LAUNCH_CHECK();
+    PNPX_TRY(resblocks(l, A + Pl.U[l], &cur));
+  }
+  {
+    const size_t na = (size_t)B * (DRU_NC[0] / 8) * H * W;
+    hipLaunchKernelGGL(dru_add_kernel, g1(na), dim3(256), 0, s, reinterpret_cast<const HsRec*>(cur),
+                       reinterpret_cast<const HsRec*>(A + Pl.S[0]), reinterpret_cast<HsRec*>(A + Pl.M[0]), H, W, na);
+    PNPX_LAUNCH_CHECK();
+  }
+  PNPX_TRY(conv(A + Pl.M[0], A + Pl.P[0], H, W, 1.f, nullptr, true));   // tail -> out / out_pre (P[0] is not written)
+  if (li != L.size()) {
+    set_error("DRUNet: internal layer walk mismatch (%zu of %zu)", li, L.size());
+    return PNPX_ERR_ARG;
+  }
+  return PNPX_OK;
+}
+
+}  // namespace pnpx

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "conv3x3.h"
 #include "conv_hs.h"
+#include "conv_first.h"
 #include "hs_rec.h"
 #include "unet_plan.h"
 
@@ -111,43 +112,7 @@ __global__ __launch_bounds__(256) void prep_input_hs_kernel(const float* __restr
   dst[(b * 2 * (H + 2) + (y + 1)) * (W + 2) + xx + 1] = hs_pack(v);   // group 0 of 2; group 1 stays zero
 }
 
-// First convolution of the network, fused with the input preparation (denoiser/base.py:27-30 + inc.conv-0,
-// models/unet.py:8-18): out[c] = LeakyReLU(b[c] + sum_taps w[c][0][t] * x[t] + w[c][1][t] * sigma * [t inside the image]).
-// K is only 18, so padding it to the 16-channel chunks of the MFMA kernel wastes 8x the multiplies and a 100 MB
-// padded-input round trip; here each thread evaluates 8 output channels of one pixel as exact fp32 FMA chains straight
-// from the fp32 image (weights are wave-uniform: scalar loads) and stores one HS8 record.  HBM-write bound.
-__global__ __launch_bounds__(256) void conv_first_hs_kernel(const float* __restrict__ x, const float* __restrict__ sigma,
-                                                            int sigma_stride, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, HsRec* __restrict__ dst, int H,
-                                                            int W, float slope) {
-  const int g = blockIdx.y, b = blockIdx.z;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= H * W) return;
-  const int y = p / W, xx = p - y * W;
-  const float sg = sigma[(size_t)b * sigma_stride];
-  const float* xb = x + (size_t)b * H * W;
-  float xi[9], si[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int yy = y + t / 3 - 1, xc = xx + t % 3 - 1;
-    const bool in = (yy >= 0) && (yy < H) && (xc >= 0) && (xc < W);
-    xi[t] = in ? xb[(size_t)yy * W + xc] : 0.f;
-    si[t] = in ? sg : 0.f;
-  }
-  float v[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const float* wc = w + (size_t)(g * 8 + c) * 18;
-    float acc = bias[g * 8 + c];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc = fmaf(wc[t], xi[t], acc);
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc = fmaf(wc[9 + t], si[t], acc);
-    v[c] = fmaxf(acc, acc * slope) * HS_ASCALE;
-  }
-  dst[((size_t)(b * 4 + g) * (H + 2) + (y + 1)) * (W + 2) + xx + 1] = hs_pack(v);
-}
-
+// (conv_first_hs_kernel: conv_first.h, shared with drunet.hip)
 __global__ __launch_bounds__(256) void maxpool2_hs_kernel(const HsRec* __restrict__ src, HsRec* __restrict__ dst,
                                                           size_t n_out, int H, int W) {
   const int Ho = H / 2, Wo = W / 2;
@@ -561,6 +526,13 @@ static int launch_chains(const pnpx_ctx* ctx, int B, int H, int W) {
 
 int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
                  int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena, int mode, bool keep_all) {
+  if (ctx->drunet.loaded) {   // the context's denoiser is a DRUNet (drunet.hip): inference only
+    if (arena || keep_all || prof) {
+      set_error("the DRUNet denoiser has no training path / per-launch profile (forward only)");
+      return PNPX_ERR_ARG;
+    }
+    return drunet_denoise(ctx, x, sigma, sigma_stride, out, out_pre, B, H, W, s);
+  }
   if (!ctx->has_weights) {
     set_error("denoiser called before pnpx_unet_load");
     return PNPX_ERR_NO_WEIGHTS;

@@ -388,6 +388,10 @@ GradPlan make_grad_plan(int mode, int capB, int H, int W) {
 int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out,
                           float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s, UNetArena* cached,
                           const float* cached_pre) {
+  if (ctx->drunet.loaded) {
+    set_error("the DRUNet denoiser has no VJP (forward only)");
+    return PNPX_ERR_ARG;
+  }
   if (!ctx->has_weights) {
     set_error("denoiser backward called before pnpx_unet_load");
     return PNPX_ERR_NO_WEIGHTS;

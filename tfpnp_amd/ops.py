@@ -65,6 +65,22 @@ class Context:
         check(_lib.lib().pnpx_unet_load(self.handle, flat.ctypes.data_as(C.c_void_p), flat.size))
         self._has_weights = True
 
+    def load_drunet(self, state_dict, nb=4):
+        """state_dict with KAIR's UNetRes / DRUNet key names (synth.drunet_param_specs) -> the context's denoiser."""
+        from .synth import drunet_param_specs
+        chunks = []
+        for key, shape in drunet_param_specs(nb=nb):
+            if key not in state_dict:
+                raise PnpxError(f"DRUNet state_dict is missing '{key}'")
+            v = state_dict[key]
+            v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if tuple(v.shape) != tuple(shape):
+                raise PnpxError(f"'{key}' has shape {tuple(v.shape)}, expected {tuple(shape)}")
+            chunks.append(np.ascontiguousarray(v, dtype=np.float32).reshape(-1))
+        flat = np.concatenate(chunks)
+        check(_lib.lib().pnpx_drunet_load(self.handle, flat.ctypes.data_as(C.c_void_p), flat.size, int(nb)))
+        self._has_weights = True
+
     def load_policy(self, state_dict, num_inputs, n_det, spi_head=False):
         """state_dict with the reference's ResNetActor_* key names (tfpnp/policy/network.py) -> native actor."""
         from .synth import policy_param_specs

@@ -60,3 +60,40 @@ class UNetDenoiser2D(torch.nn.Module):
     def forward_preclamp(self, x, sigma):
         """(clamped, pre-clamp) outputs -- the pre-clamp UNet output is what the parity tests compare."""
         return T.call("unet_denoise_preclamp", x, sigma, self.context(x.device).cid)
+
+
+class DRUNetDenoiser2D(UNetDenoiser2D):
+    """DRUNet (KAIR UNetRes: bias-free, 64-128-256-512 channels, `nb` ResBlocks per scale, strided / transposed 2x2
+    convolutions) behind the same call surface as UNetDenoiser2D: `denoiser(x[B,1,H,W], sigma[B]) ->
+    clamp(DRUNet(cat[x, sigma*1]), 0, 1)`.  The reference ships only the building blocks
+    (tfpnp/pnp/denoiser/models/basicblock.py:61-101,211-227,413-419,437-446) and no checkpoint: a state_dict with KAIR's
+    key names (`m_head.weight`, `m_down1.0.res.0.weight`, ... -- what drunet_gray.pth holds) or a path to one is required.
+    H and W must be multiples of 8.  Forward only (no VJP): calling it under autograd raises."""
+
+    def __init__(self, ckpt_path=None, state_dict=None, nb=4):
+        torch.nn.Module.__init__(self)
+        self.conv_mode = None
+        self.nb = nb
+        if state_dict is None:
+            if ckpt_path is None:
+                raise ValueError('DRUNet: no default ckpt exists, you have to provide a ckpt path or a state_dict')
+            state_dict = torch.load(ckpt_path, map_location='cpu')
+        self._state = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else torch.as_tensor(v))
+                       for k, v in state_dict.items()}
+        self._ctx = {}
+
+    def context(self, device):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise PnpxError(f'DRUNetDenoiser2D runs on MI355X only (tensor on {device}); there is no CPU path')
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in self._ctx:
+            ctx = ops.Context(torch.device('cuda', idx))
+            ctx.load_drunet(self._state, nb=self.nb)
+            self._ctx[idx] = ctx
+        return self._ctx[idx]
+
+    def forward(self, x, sigma):
+        if torch.is_grad_enabled() and (x.requires_grad or sigma.requires_grad):
+            raise NotImplementedError('DRUNetDenoiser2D is forward-only (no native VJP); run it under torch.no_grad()')
+        return T.call("unet_denoise", x, sigma, self.context(x.device).cid)

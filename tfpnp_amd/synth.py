@@ -68,6 +68,63 @@ def flatten_params(params):
     return np.concatenate([params[k].reshape(-1) for k, _ in unet_param_specs()]).astype(np.float32)
 
 
+# --------------------------------------------------------------------------- DRUNet parameters
+# DRUNet (Zhang et al., "Plug-and-Play Image Restoration with Deep Denoiser Prior", KAIR models/network_unet.py::UNetRes):
+# the reference ships only its building blocks (tfpnp/pnp/denoiser/models/basicblock.py: conv :61-101, ResBlock
+# :211-227, upsample_convtranspose :413-419, downsample_strideconv :437-446) and no model or checkpoint.  Topology:
+# head conv3x3(in_nc+1 -> 64); three scales of [nb ResBlocks + strided 2x2 conv]; body of nb ResBlocks at 512 channels;
+# three scales of [transposed 2x2 conv + nb ResBlocks] with additive skips; tail conv3x3(64 -> 1); everything bias-free,
+# ReLU inside the ResBlocks only.  Key names are those of KAIR's released drunet_gray.pth.
+DRUNET_NC = (64, 128, 256, 512)
+DRUNET_NB = 4
+
+
+def drunet_param_specs(in_nc=2, out_nc=1, nc=DRUNET_NC, nb=DRUNET_NB):
+    """[(key, shape)] in state_dict order of UNetRes(in_nc, out_nc, nc, nb, act_mode='R', 'strideconv', 'convtranspose')."""
+    specs = [("m_head.weight", (nc[0], in_nc, 3, 3))]
+
+    def res(prefix, c):
+        return [(f"{prefix}.res.0.weight", (c, c, 3, 3)), (f"{prefix}.res.2.weight", (c, c, 3, 3))]
+
+    for lvl in range(3):
+        for i in range(nb):
+            specs += res(f"m_down{lvl + 1}.{i}", nc[lvl])
+        specs.append((f"m_down{lvl + 1}.{nb}.weight", (nc[lvl + 1], nc[lvl], 2, 2)))
+    for i in range(nb):
+        specs += res(f"m_body.{i}", nc[3])
+    for lvl in (2, 1, 0):
+        specs.append((f"m_up{lvl + 1}.0.weight", (nc[lvl + 1], nc[lvl], 2, 2)))      # ConvTranspose2d: [cin, cout, 2, 2]
+        for i in range(nb):
+            specs += res(f"m_up{lvl + 1}.{i + 1}", nc[lvl])
+    specs.append(("m_tail.weight", (out_nc, nc[0], 3, 3)))
+    return specs
+
+
+def drunet_num_params(**kw):
+    return sum(int(np.prod(s)) for _, s in drunet_param_specs(**kw))
+
+
+def make_drunet_params(seed=0, **kw):
+    """Synthetic DRUNet weights: N(0, 1/fan_in) convolutions (variance preserving through head / strided / transposed /
+    tail layers), He-normal first and 0.25 x second convolution inside every ResBlock (the residual branch adds ~6 % of
+    the trunk's variance per block, so 32 blocks stay O(1): activations of the synthetic net peak at a few units)."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for key, shape in drunet_param_specs(**kw):
+        if ".res.0." in key:
+            std = math.sqrt(2.0 / (shape[1] * 9))
+        elif ".res.2." in key:
+            std = 0.25 * math.sqrt(1.0 / (shape[1] * 9))
+        elif key.startswith("m_up"):           # ConvTranspose2d [cin, cout, 2, 2]: every output pixel sees cin inputs
+            std = math.sqrt(1.0 / shape[0])
+        elif key == "m_tail.weight":           # output of order 0.3: a fair share of pixels inside [0, 1] before the clamp
+            std = 0.25 * math.sqrt(1.0 / (shape[1] * 9))
+        else:
+            std = math.sqrt(1.0 / (shape[1] * shape[2] * shape[3]))
+        out[key] = (rs.standard_normal(shape) * std).astype(np.float32)
+    return out
+
+
 # --------------------------------------------------------------------------- policy actor parameters
 def policy_param_specs(num_inputs, n_det, spi_head=False):
     """(key, shape) of the fp32 entries of ResNetActorBase.state_dict() in registration order
