@@ -186,11 +186,74 @@ def drunet_goldens():
         save("drunet_spi_B2_64x64", in_sha=sha(d["x0"], sg, m), **steps)
 
 
+def synthesis_goldens():
+    """(12) measurement synthesis pinned to the reference's own code: tfpnp/utils/noise.py (seeded CPU draws) and
+    Dataset.__getitem__ of tasks/{csmri,pr,spi}/dataset.py driven from a temporary image folder + synthetic masks.
+    Fixtures store the outputs; the tests re-draw the same CPU random fields from the seed and inject them."""
+    from PIL import Image
+    from tests.golden_inputs import SYNTH_SEED, synthesis_images, synthesis_masks, noise_model_inputs
+    from tfpnp.utils import noise as N
+    out = {}
+    imgs = synthesis_images()
+    tmp = tempfile.mkdtemp()
+    for i, im in enumerate(imgs):
+        Image.fromarray(im).save(os.path.join(tmp, f"img{i}.png"))
+    fns = [f"img{i}.png" for i in range(len(imgs))]
+    mask, cdp = synthesis_masks()
+
+    def seed(k):
+        np.random.seed(SYNTH_SEED + k)
+        torch.manual_seed(SYNTH_SEED + k)
+
+    cs = ref_shim.load_task_module("csmri", "dataset")
+    ds = cs.CSMRIDataset(tmp, fns, [mask], noise_model=None)
+    for i in range(len(imgs)):
+        it = ds[i]
+        for k in ("y0", "x0", "ATy0", "output", "gt", "sigma_n", "mask"):
+            out[f"csmri_clean{i}_{k}"] = np.asarray(it[k])
+    seed(1)
+    it = cs.CSMRIDataset(tmp, fns, [mask], noise_model=N.GaussianModelD([5, 10, 15]))[1]
+    for k in ("y0", "x0", "ATy0", "output", "sigma_n"):
+        out[f"csmri_noisy1_{k}"] = np.asarray(it[k])
+    pr = ref_shim.load_task_module("pr", "dataset")
+    it = pr.PRDataset(tmp, fns, [cdp], noise_model=None)[0]
+    for k in ("y0", "x0", "output", "gt", "sigma_n"):
+        out[f"pr_clean0_{k}"] = np.asarray(it[k])
+    seed(2)
+    it = pr.PRDataset(tmp, fns, [cdp], noise_model=N.PoissonModel([9, 27, 81]))[1]
+    for k in ("y0", "sigma_n"):
+        out[f"pr_noisy1_{k}"] = np.asarray(it[k])
+    sp = ref_shim.load_task_module("spi", "dataset")
+    seed(3)
+    it = sp.SPIDataset(tmp, fns, [4, 6, 8])[0]
+    for k in ("x0", "output", "gt", "K"):
+        out[f"spi0_{k}"] = np.asarray(it[k])
+    # the noise models on their own
+    xk, xm, xs = (t(a) for a in noise_model_inputs())
+    seed(4)
+    y, s_ = N.GaussianModelC(0, 55)(xk)
+    out["noiseC_y"], out["noiseC_sigma"] = y, np.float64(s_)
+    seed(5)
+    y, s_ = N.GaussianModelD([5, 10, 15])(xk)
+    out["noiseD_y"], out["noiseD_sigma"] = y, np.float64(s_)
+    seed(6)
+    y, s_ = N.PoissonModel([9, 27, 81])(xm)
+    out["noisePo_y"], out["noisePo_sigma"] = y, s_
+    seed(7)
+    y, s_ = N.GaussianModelP([0.05, 0.075, 0.1], batch_mode=True)(xs)
+    out["noiseP_y"], out["noiseP_sigma"] = y, s_
+    save("synthesis_ref", in_sha=sha(imgs, mask, cdp, *noise_model_inputs()), **out)
+
+
 def main():
     assert ref_shim.available(), "reference not mounted"
     ref_shim.install()
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if "--only-synthesis" in sys.argv:
+        print("[12] measurement synthesis")
+        synthesis_goldens()
+        return
     if "--only-drunet" in sys.argv:
         print("[11] DRUNet")
         drunet_goldens()

@@ -211,3 +211,26 @@ def env_case(task):
         d["output"] = d["ATy0"].copy()
         return d, []
     raise KeyError(task)
+
+
+# ---- measurement-synthesis fixtures (oracle/make_goldens.py::synthesis_goldens) ---------------------------------------
+SYNTH_SEED = 9100
+
+
+def synthesis_images(n=2, H=64, W=64):
+    """uint8 grey images written to a temporary folder for the reference's Dataset classes / rebuilt by the tests."""
+    return np.round(synth.phantom_batch(n, H, W, 515)[:, 0] * 255).astype(np.uint8)
+
+
+def synthesis_masks(H=64, W=64):
+    """(CS-MRI radial mask [H,W] bool, CDP masks [S,H,W,2] unit modulus)"""
+    m = synth.make_csmri_batch(1, H, W, ratio=4, seed=516)["mask"][0, 0].astype(bool)
+    ph = np.random.RandomState(517).uniform(0, 2 * np.pi, (4, H, W)).astype(np.float32)
+    return m, np.stack([np.cos(ph), np.sin(ph)], -1).astype(np.float32)
+
+
+def noise_model_inputs():
+    rs = np.random.RandomState(518)
+    return (rs.standard_normal((3, 1, 16, 24, 2)).astype(np.float32),       # k-space-like (GaussianModelC / D)
+            rs.uniform(0, 2, (3, 4, 16, 24)).astype(np.float32),            # magnitudes (PoissonModel)
+            rs.uniform(0, 40, (3, 1, 30, 45)).astype(np.float32))           # sinogram-like (GaussianModelP)

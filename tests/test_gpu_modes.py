@@ -100,6 +100,43 @@ def test_csmri_episode_drift_not_worse_than_fp32(unet_params):
         assert e < 1e-4 and e < 2.0 * e_cpu32 + 1e-5
 
 
+@pytest.mark.parametrize("config", ["#1: B=1 128x128", "#2: B=48 256x256 (4 items checked)"])
+def test_default_scale_weights_30_iterations_within_1e5(config):
+    """VERDICT r2 'what's weak' #1 / next #3b: with the He-scaled synthetic UNet the 30-iteration figures sit at 7-8e-5 of
+    the 1e-4 bar only because that network is EXPANSIVE (round-off x1.5-2 per call).  On a denoiser-like, non-expansive
+    weight set (PyTorch's default init scale, what SURVEY section 6 probed) both convolution families must stay within
+    1e-5 of the CPU oracle after the full 6 x 5 = 30 iterations of BASELINE configs #1 and #2."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
+    params = synth.make_unet_params_default(0)
+    if config.startswith("#1"):
+        B, H, W, ncheck, seed = 1, 128, 128, 1, 99
+    else:
+        B, H, W, ncheck, seed = 48, 256, 256, 4, 1234
+    d = synth.make_csmri_batch(B, H, W, ratio=4, sigma_n=15.0, seed=seed)
+    acts = synth.make_actions(B)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    torch.set_num_threads(16)
+    oden = O.Denoiser(params)
+    with torch.no_grad():
+        v = O.admm_reset(t(d["x0"][:ncheck]))
+        for a in acts:
+            v = O.csmri_admm(oden, v, t(d["y0"][:ncheck]), t(d["mask"][:ncheck]), t(a["sigma_d"][:ncheck]),
+                             t(a["mu"][:ncheck]))
+    want = O.complex2real(v[:, :1])
+    assert float(want.std()) > 0.05                      # a real image came out, not a collapsed constant
+    for mode in (1, 0):
+        sol = ADMMSolver_CSMRI(UNetDenoiser2D(state_dict=params, conv_mode=mode))
+        g = lambda a: t(a).to(dev())
+        gv = sol.reset({"x0": g(d["x0"])})
+        for a in acts:
+            gv = sol((gv, (g(d["y0"]), g(d["mask"]))), (g(a["sigma_d"]), g(a["mu"])))
+        e = rel(sol.get_output(gv)[:ncheck].cpu(), want)
+        print(f"default-scale weights, config {config}, conv_mode {mode}: 30-iteration rel-L2 vs CPU oracle = {e:.2e}")
+        assert e <= 1e-5
+
+
 def test_fused_upsample_option_matches_separate_kernel(unet_params):
     """Option fuse_up = 1 (producer waves of the conv kernel interpolate the full-resolution decoder entry's second source
     on the fly, conv_hs_kernel.h UPS): same arithmetic as the separate up-sampling kernel -- per call and over a

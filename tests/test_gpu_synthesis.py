@@ -131,3 +131,93 @@ def test_ct_measure_and_fbp():
     for b in range(B):
         assert abs(float(r[b].std()) / (0.05 * float(sino[b].abs().mean())) - 1) < 0.05
     assert np.allclose(n['sigma_n'].cpu().numpy(), 0.05)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Pinned to the reference's own code: tests/golden/synthesis_ref.npz holds what tfpnp/utils/noise.py and
+# Dataset.__getitem__ of tasks/{csmri,pr,spi}/dataset.py produced from a temporary image folder under fixed seeds
+# (oracle/make_goldens.py::synthesis_goldens).  The CPU random fields are re-drawn here from the same seeds, in the order
+# the reference consumes them, and injected into the GPU synthesis: everything else must match to 1e-6.
+def _ref():
+    from tests.conftest import golden
+    from tests.golden_inputs import sha, synthesis_images, synthesis_masks, noise_model_inputs
+    gd = golden("synthesis_ref")
+    imgs = synthesis_images()
+    mask, cdp = synthesis_masks()
+    assert (sha(imgs, mask, cdp, *noise_model_inputs()) == gd["in_sha"]).all()
+    gt = (imgs.astype(np.float32) / 255.0)[:, None]                     # np.array(PIL 'L' image) / 255  (dataset.py:41)
+    return gd, gt, mask, cdp
+
+
+def _seed(k):
+    from tests.golden_inputs import SYNTH_SEED
+    np.random.seed(SYNTH_SEED + k)
+    torch.manual_seed(SYNTH_SEED + k)
+
+
+def test_csmri_items_match_reference_dataset():
+    from tfpnp_amd.data import synthesis as S
+    gd, gt, mask, _ = _ref()
+    for i in range(gt.shape[0]):
+        d = S.csmri_measure(g(gt[i:i + 1]), g(mask[None, None]))
+        for k in ("y0", "x0", "ATy0", "output"):
+            assert rel(d[k][0], t(gd[f"csmri_clean{i}_{k}"])) < 1e-6, k
+        assert torch.equal(d["gt"][0].cpu(), t(gd[f"csmri_clean{i}_gt"]))
+        assert torch.equal(d["mask"][0].cpu(), t(gd[f"csmri_clean{i}_mask"]))
+        assert float(d["sigma_n"].abs().max()) == 0.0 and d["sigma_n"][0].shape == gd[f"csmri_clean{i}_sigma_n"].shape
+    # noisy item: the reference draws  mask index (numpy), sigma (numpy), then torch.randn(*y0.shape)
+    _seed(1)
+    np.random.randint(0, 1)
+    sigma = np.random.choice([5, 10, 15])
+    noise = torch.randn(1, 64, 64, 2)
+    d = S.csmri_measure(g(gt[1:2]), g(mask[None, None]), noise_model=S.GaussianModelD([sigma]), noise=noise[None])
+    for k in ("y0", "x0", "ATy0", "output"):
+        assert rel(d[k][0], t(gd[f"csmri_noisy1_{k}"])) < 1e-6, k
+    assert rel(d["sigma_n"][0], t(gd["csmri_noisy1_sigma_n"]).float()) < 1e-6
+
+
+def test_pr_and_spi_items_match_reference_datasets():
+    from tfpnp_amd.data import synthesis as S
+    gd, gt, _, cdp = _ref()
+    d = S.pr_measure(g(gt[0:1]), g(cdp[None]))
+    assert rel(d["y0"][0], t(gd["pr_clean0_y0"])) < 1e-6
+    assert torch.equal(d["x0"][0].cpu(), t(gd["pr_clean0_x0"])) and torch.equal(d["output"][0].cpu(), t(gd["pr_clean0_output"]))
+    _seed(2)
+    np.random.randint(0, 1)
+    alpha = np.random.choice([9, 27, 81])
+    noise = torch.randn(4, 64, 64)
+    d = S.pr_measure(g(gt[1:2]), g(cdp[None]), noise_model=S.PoissonModel([alpha]), noise=noise[None])
+    assert rel(d["y0"][0], t(gd["pr_noisy1_y0"])) < 2e-6
+    assert rel(d["sigma_n"][0], t(gd["pr_noisy1_sigma_n"]).float()) < 1e-4            # std of the residual (one item)
+    # SPI: K index (numpy), then torch.poisson on the CPU generator
+    _seed(3)
+    K = [4, 6, 8][np.random.randint(0, 3)]
+    theta = S.spi_theta(t(gt[0:1]), K, K ** 2)
+    counts = torch.poisson(theta)
+    d = S.spi_measure(g(gt[0:1]), K, counts=counts)
+    assert torch.equal(d["x0"][0].cpu(), t(gd["spi0_x0"])) and torch.equal(d["output"][0].cpu(), t(gd["spi0_output"]))
+    assert np.allclose(d["K"][0].cpu().numpy(), gd["spi0_K"]) and float(gd["spi0_K"].flat[0]) == K / 10
+
+
+def test_noise_models_match_reference_noise_py():
+    from tfpnp_amd.data import synthesis as S
+    from tests.golden_inputs import noise_model_inputs
+    gd, *_ = _ref()
+    xk, xm, xs = noise_model_inputs()
+    _seed(4)
+    s = np.random.uniform(0, 55)
+    y, sig = S.GaussianModelC(0, 55)(g(xk), noise=torch.randn(*xk.shape), sigma=np.full(3, s / 255.))
+    assert rel(y, t(gd["noiseC_y"])) < 1e-6 and abs(float(sig[0]) - float(gd["noiseC_sigma"])) < 1e-7
+    _seed(5)
+    s = np.random.choice([5, 10, 15])
+    y, sig = S.GaussianModelD([s])(g(xk), idx=0, noise=torch.randn(*xk.shape))
+    assert rel(y, t(gd["noiseD_y"])) < 1e-6 and abs(float(sig[0]) - float(gd["noiseD_sigma"])) < 1e-7
+    _seed(6)
+    a = np.random.choice([9, 27, 81])
+    y, _ = S.PoissonModel([a])(g(xm), idx=0, noise=torch.randn(*xm.shape))
+    assert rel(y, t(gd["noisePo_y"])) < 2e-6
+    assert abs(float((y.cpu() - t(xm).abs()).std()) - float(gd["noisePo_sigma"])) < 1e-5   # the reference's whole-tensor std
+    _seed(7)
+    sp = np.random.choice([0.05, 0.075, 0.1], size=3)
+    y, sig = S.GaussianModelP([0.05])(g(xs), noise=torch.randn(*xs.shape), sigma=sp)
+    assert rel(y, t(gd["noiseP_y"])) < 1e-6 and rel(sig.reshape(-1), t(gd["noiseP_sigma"]).reshape(-1)) < 1e-7

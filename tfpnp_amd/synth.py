@@ -63,6 +63,22 @@ def make_unet_params(seed=0):
     return out
 
 
+def make_unet_params_default(seed=0):
+    """A second synthetic weight set at PyTorch's DEFAULT initialisation scale (nn.Conv2d.reset_parameters:
+    kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases): a contractive network like
+    the one SURVEY section 6 probed (fp32-vs-fp64 drift 6.9e-7 over 30 iterations), next to the He-scaled set of
+    make_unet_params whose gain > 1 amplifies round-off x1.5-2 per call.  Shows the real margin to the 1e-4 bar."""
+    rs = np.random.RandomState(seed + 7919)
+    out = {}
+    fan_in = 1
+    for key, shape in unet_param_specs():
+        if key.endswith("weight"):
+            fan_in = shape[1] * shape[2] * shape[3]
+        b = 1.0 / math.sqrt(fan_in)
+        out[key] = rs.uniform(-b, b, shape).astype(np.float32)
+    return out
+
+
 def flatten_params(params):
     """Concatenate in state_dict order -> 1-D float32 (the C-ABI's weight blob)."""
     return np.concatenate([params[k].reshape(-1) for k, _ in unet_param_specs()]).astype(np.float32)
