@@ -73,15 +73,22 @@ int make_fft_plan(pnpx_ctx* ctx, int n_img, int H, int W, bool centered, FftPlan
     return PNPX_ERR_SHAPE;
   }
   const int total_rows = n_img * H;
-  int lr = FFT_TILE_POINTS / W;
+  const int tile_points = ctx->opt_fft_tile > 0 ? ctx->opt_fft_tile : FFT_TILE_POINTS;
+  int lr = tile_points / W;
   if (lr < 1) lr = 1;
   if (lr > total_rows) lr = total_rows;
-  int lc = FFT_TILE_POINTS / H;
+  int lc = tile_points / H;
   if (lc < 1) lc = 1;
   if (lc > W) lc = W;
   if (lc > 64) lc = 64;
   PNPX_TRY(make_pass(ctx, n_img, H, W, W, centered, lr, &P->rows));
   PNPX_TRY(make_pass(ctx, n_img, H, W, H, centered, lc, &P->cols));
+  // XCD-affine image mapping (fft_lds.h): every pass of a chain keeps an image on one XCD, so the k-space round trips
+  // between passes are served by that XCD's L2
+  if (ctx->opt_fft_affine && n_img >= 8) {
+    P->rows.affine = (H % lr == 0) ? 1 : 0;
+    P->cols.affine = 1;
+  }
   P->grid_rows = dim3((total_rows + lr - 1) / lr);
   P->grid_cols = dim3((W + lc - 1) / lc, n_img);
   P->lds_rows = sizeof(float2) * 2 * (size_t)lr * (W + 1);

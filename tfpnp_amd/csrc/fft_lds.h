@@ -19,7 +19,7 @@
 namespace pnpx {
 
 constexpr int FFT_THREADS = 256;
-constexpr int FFT_TILE_POINTS = 2048;
+constexpr int FFT_TILE_POINTS = 1024;   // complex points per workgroup tile (r3 sweep at 48 x 256^2: 512 / 1024 / 2048 / 4096 -> 124 / 109 / 140 / 210 us per ADMM iteration for the three passes)
 constexpr int FFT_MAX_N = 2048;   // one line (+ ping-pong copy) must fit LDS
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -143,7 +143,26 @@ struct PassGeom {
   float scale;       // 1/sqrt(N) (orthonormal)
   int centered;      // apply the (-1)^n / (-1)^(k+N/2) signs
   const float2* tw;
+  int affine;        // 1: XCD-affine block -> image mapping (xcd_affine_decode); set by the launchers when it applies
 };
+
+// XCD-affine work mapping for chains of passes over the same images.  Workgroup `id` runs on XCD id % 8 (round-robin
+// dispatch); with `per_img` workgroups per image, images are dealt to XCDs in groups of eight: image 8g + x is processed
+// entirely by XCD x in EVERY pass of the chain, so what one pass wrote (0.5 MB of k-space per 256^2 image, 3 MB per
+// XCD and 48-image batch) is still in that XCD's 4 MiB L2 when the next pass reads it -- the round trip between row and
+// column passes stops at the L2 instead of the fabric.  A trailing partial group of images is mapped plainly.
+__device__ __forceinline__ void xcd_affine_decode(int id, int per_img, int n_img, int affine, int* b, int* part) {
+  const int group = 8 * per_img;
+  const int gidx = id / group;
+  if (!affine || (gidx + 1) * 8 > n_img) {
+    *b = id / per_img;
+    *part = id - *b * per_img;
+    return;
+  }
+  const int loc = id - gidx * group;
+  *b = gidx * 8 + (loc & 7);
+  *part = loc >> 3;
+}
 
 // ---- row pass: lines = image rows (contiguous).  grid.x = ceil(n_img*H / lines)
 template <bool INV, class Load, class Store>
@@ -152,7 +171,12 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_rows_kernel(PassGeom g, Load 
   const int N = g.W, ls = N + 1;
   float2* d0 = smem;
   float2* d1 = smem + g.lines * ls;
-  const int line0 = blockIdx.x * g.lines;
+  int line0 = blockIdx.x * g.lines;
+  if (g.affine) {     // (launcher guarantees H % lines == 0: a workgroup's lines belong to one image)
+    int b_, part_;
+    xcd_affine_decode(blockIdx.x, g.H / g.lines, g.n_img, 1, &b_, &part_);
+    line0 = (b_ * (g.H / g.lines) + part_) * g.lines;
+  }
   const int total = g.n_img * g.H;
   const int logW = g.logN;
   const bool flip = g.centered && !g.odd;             // even length: shifts are sign flips
@@ -194,8 +218,9 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols_kernel(PassGeom g, Load 
   const int N = g.H, ls = N + 1, C = g.lines;
   float2* d0 = smem;
   float2* d1 = smem + C * ls;
-  const int x0 = blockIdx.x * C;
-  const int b = blockIdx.y;
+  int b, xt;
+  xcd_affine_decode(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, g.n_img, g.affine, &b, &xt);
+  const int x0 = xt * C;
   const int half = N >> 1;
   const bool flip = g.centered && !g.odd;
   const int rin = g.odd ? (N + 1) / 2 : 0, rout = g.odd ? N / 2 : 0;

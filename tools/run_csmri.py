@@ -1,0 +1,26 @@
+"""CS-MRI ADMM solver calls at the headline size for profiling the prox kernels.  usage: run_csmri.py [fft_affine] [calls] [B]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tfpnp_amd import synth
+from tfpnp_amd.pnp import UNetDenoiser2D
+from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
+
+aff = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 48
+dev = torch.device("cuda:0")
+den = UNetDenoiser2D(state_dict=synth.make_unet_params(0))
+den.context(dev).set_option("fft_affine", aff)
+if os.environ.get("FFT_TILE"):
+    den.context(dev).set_option("fft_tile", int(os.environ["FFT_TILE"]))
+g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+d = synth.make_csmri_batch(B, 256, 256, ratio=4, sigma_n=15.0, seed=1234)
+a = synth.make_actions(B)[0]
+sol = ADMMSolver_CSMRI(den)
+v = sol.reset({"x0": g(d["x0"])})
+y0, m, sg, mu = g(d["y0"]), g(d["mask"]), g(a["sigma_d"]), g(a["mu"])
+for _ in range(calls):
+    v = sol((v, (y0, m)), (sg, mu))
+torch.cuda.synchronize()
+print(f"fft_affine={aff} checksum {float(v.double().sum()):.10e}")
