@@ -1,0 +1,46 @@
+"""The RCCL / side-stream path of the per-step exchange (tfpnp_amd/dist.py::StepExchange) on ONE GPU: a one-rank 'nccl'
+process group with force_collective=True runs exactly the code the 2/4/8-GPU bench runs (pack on the compute stream,
+all_gather_into_tensor on the side stream, pinned-host landing, deferred result) -- the multi-rank arithmetic itself is
+covered by the world-size-2 gloo tests."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def test_step_exchange_rccl_side_stream_single_rank():
+    from tfpnp_amd import dist as D
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda:0")
+        ex = D.StepExchange(5, dev, force_collective=True)
+        assert ex.on and ex.stream is not None
+        pend = None
+        for step in range(6):                                   # pipelined exactly like bench.py::make_episode
+            reward = (torch.arange(5, device=dev, dtype=torch.float32) * 10 + step).view(5, 1)
+            done = torch.arange(5, device=dev) <= step
+            # keep the compute stream busy so that the exchange really overlaps something
+            junk = torch.rand(2048, 2048, device=dev) @ torch.rand(2048, 2048, device=dev)
+            nxt = ex.post(reward, done, rank_finished=step >= 4)
+            if pend is not None:
+                r, d, f = pend.result()
+                assert r.view(-1).tolist() == [10.0 * i + step - 1 for i in range(5)]
+                assert d.tolist() == [i <= step - 1 for i in range(5)] and f == (step - 1 >= 4)
+            pend = nxt
+        r, d, f = pend.result()
+        assert r.view(-1).tolist() == [10.0 * i + 5 for i in range(5)] and f is True
+        assert ex.posted == 6 and junk.isfinite().all()
+        # the blocking ShardedEnv contract on the same path
+        assert D.max_over_ranks(1.25, dev) == 1.25 and D.all_true(True, dev)
+    finally:
+        dist.destroy_process_group()

@@ -106,9 +106,11 @@ class StepExchange:
 
     COLS = 3
 
-    def __init__(self, n_global, device, group=None):
+    def __init__(self, n_global, device, group=None, force_collective=False):
+        """force_collective: issue the collective even in a one-rank group (exercises the RCCL / side-stream path on a
+        single GPU: tests/test_gpu_dist.py)."""
         self.group = group
-        self.on = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.on = dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.n_global = int(n_global)
