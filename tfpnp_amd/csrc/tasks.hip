@@ -176,13 +176,22 @@ __global__ void psnr_final_kernel(const float* __restrict__ part, float* __restr
 }
 
 // =================================================================================== CT (own discretisation)
-// Ray-driven forward projector: one thread per (b, view, detector).  See oracle/pnp_oracle.py:radon_forward and
-// DESIGN.md for the geometry.  cs = [n_view] (cos, sin) pairs computed on the host in double precision.
+// Ray-driven forward projector.  See oracle/pnp_oracle.py:radon_forward and DESIGN.md for the geometry.  cs = [n_view]
+// (cos, sin) pairs computed on the host in double precision.
+// EIGHT lanes per ray (b, view, detector): lane dk of a ray takes the samples k0 + dk, k0 + dk + 8, ...; a wave is 8
+// adjacent detector bins x 8 consecutive steps, i.e. one gather instruction touches an 8 x 8-pixel rotated patch (<= ~12
+// image rows) instead of a 64-pixel line segment (up to 45 rows): the kernel is bound by cache lines per gather, not by
+// bytes (r2: 302 us at 32 x 256^2 x 30 views with one lane per ray).  The eight partial sums are combined by a fixed
+// xor-butterfly, so results are deterministic (summation order differs from the oracle's sequential one: ~1e-7).
+constexpr int RADON_LPR = 8;   // lanes per ray
 __global__ void radon_forward_kernel(const float* __restrict__ img, size_t istride, const float* __restrict__ imgT,
                                      const float* __restrict__ sub, float* __restrict__ sino,
                                      const float2* __restrict__ cs, int R, int V, int det, int B) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)B * V * det) return;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n_rays = (size_t)B * V * det;
+  const bool live = (tid / RADON_LPR) < n_rays;
+  const size_t i = live ? tid / RADON_LPR : n_rays - 1;      // dead tail lanes shadow the last ray (shuffles stay uniform)
+  const int dk = (int)(tid % RADON_LPR);
   const int s = (int)(i % det);
   const int v = (int)((i / det) % V);
   const int b = (int)(i / ((size_t)det * V));
@@ -211,8 +220,8 @@ __global__ void radon_forward_kernel(const float* __restrict__ img, size_t istri
     clip(ss + off, c);
   }
   float acc = 0.f;
-#pragma unroll 4
-  for (int k = k0; k < k1; ++k) {
+#pragma unroll 2
+  for (int k = k0 + dk; k < k1; k += RADON_LPR) {
     const float t = subr((float)k, half);
     const float px = addr(subr(sc, mulr(t, sn)), off);
     const float py = addr(addr(ss, mulr(t, c)), off);
@@ -237,7 +246,10 @@ __global__ void radon_forward_kernel(const float* __restrict__ img, size_t istri
     sm = addr(sm, (yb && xb) ? mulr(v11, mulr(fx, fy)) : 0.f);
     acc = addr(acc, sm);
   }
-  sino[i] = sub ? subr(acc, sub[i]) : acc;
+  acc = addr(acc, __shfl_xor(acc, 1, 64));
+  acc = addr(acc, __shfl_xor(acc, 2, 64));
+  acc = addr(acc, __shfl_xor(acc, 4, 64));
+  if (live && dk == 0) sino[i] = sub ? subr(acc, sub[i]) : acc;
 }
 // [B][R][R] -> transposed copy (32x32 LDS tiles).  The projector reads it for the views whose detector axis is
 // closer to vertical than to horizontal, so that the 64 lanes of a wave (adjacent bins) always walk along the
@@ -259,7 +271,7 @@ static void launch_radon_forward(const float* img, size_t istride, const float* 
                                  float* imgT, int R, int V, int det, int B, hipStream_t s) {
   hipLaunchKernelGGL(transpose_image_kernel, dim3((R + 31) / 32, (R + 31) / 32, B), dim3(256), 0, s, img, istride, imgT,
                      R);
-  hipLaunchKernelGGL(radon_forward_kernel, dim3((unsigned)(((size_t)B * V * det + 255) / 256)), dim3(256), 0, s, img,
+  hipLaunchKernelGGL(radon_forward_kernel, dim3((unsigned)(((size_t)B * V * det * RADON_LPR + 255) / 256)), dim3(256), 0, s, img,
                      istride, imgT, sub, sino, cs, R, V, det, B);
 }
 // Pixel-driven backprojection: one thread per pixel, linear interpolation along the detector.
