@@ -269,3 +269,22 @@ def test_env_step_redoes_a_tripped_step_in_exact_fp32(unet_params):
     assert any("range guard" in m for m in got[1][2]) and got[1][3] == 0
     for (v0, r0), (v1, r1) in zip(got[0][0], got[1][0]):
         assert torch.isfinite(v1).all() and torch.equal(v0, v1) and torch.equal(r0, r1)
+
+
+def test_fold_first_option_is_bit_identical(unet_params):
+    """Option fold_first = 1 (conv_hs WREG == 2: the network's first convolution evaluated inside the tile loader of the
+    second one, its output tensor never written): same arithmetic in the same order -- bit-identical outputs at the bench
+    geometry and on a ragged one; geometries the instance does not cover silently take the separate kernels."""
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    den = UNetDenoiser2D(state_dict=unet_params)
+    ctx = den.context(dev())
+    try:
+        for (B, H, W) in [(24, 256, 256), (9, 160, 224), (2, 64, 64), (3, 50, 39)]:
+            x, s = denoiser_inputs(B, H, W, 77)
+            x, s = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
+            ctx.set_option("fold_first", 0)
+            ref = den.forward_preclamp(x, s)[1].clone()
+            ctx.set_option("fold_first", 1)
+            assert torch.equal(den.forward_preclamp(x, s)[1], ref), (B, H, W)
+    finally:
+        ctx.set_option("fold_first", 0)

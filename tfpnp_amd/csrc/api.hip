@@ -198,6 +198,10 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_fuse_first = value;
     return PNPX_OK;
   }
+  if (is("fold_first") && (value == 0 || value == 1)) {
+    ctx->opt_fold_first = value;
+    return PNPX_OK;
+  }
   if (is("fft_tile") && value >= 0 && value <= 8192) {
     ctx->opt_fft_tile = value;
     return PNPX_OK;
@@ -257,6 +261,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fuse_up")) *value = ctx->opt_fuse_up;
   else if (is("wreg")) *value = ctx->opt_wreg;
   else if (is("chains")) *value = ctx->opt_chains;
+  else if (is("fold_first")) *value = ctx->opt_fold_first;
   else if (is("fft_affine")) *value = ctx->opt_fft_affine;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
   else if (is("train_cache_gb")) *value = ctx->opt_train_cache_gb;

@@ -134,6 +134,8 @@ struct pnpx_ctx {
   int opt_fuse_first = 1;          // VALU first convolution straight from the fp32 image (no padded-input tensor)
   int opt_fuse_up = 0;             // opt-in: bilinear x2 of the full-resolution decoder entry inside the conv kernel
                                    // (producer waves; +1.7 % iterations/s)
+  int opt_fold_first = 0;          // opt-in: first convolution folded into the loader of the second one (conv_hs WREG == 2;
+                                   // bit-identical, 400 MB less HBM traffic per forward, time-neutral: 5.835 vs 5.841 ms)
   int opt_fft_tile = 0;            // complex points per FFT workgroup tile (0 = FFT_TILE_POINTS)
   int opt_fft_affine = 1;          // XCD-affine block -> image mapping of the FFT passes (fft_lds.h)
   int opt_chains = 0;              // denoiser forward as n independent launch chains over slices of the batch (0 = auto)

@@ -59,6 +59,15 @@ struct ConvHsArgs {
   // fused bilinear x2 (UPS instance): in1 is the low-resolution tensor [B][G1][ups_h+2][ups_w+2], H = 2*ups_h, W = 2*ups_w
   int ups_h, ups_w;
   float ups_sy, ups_sx;        // (h-1)/(2h-1), (w-1)/(2w-1): align_corners=True source step
+  // WREG == 2 ("first layer folded in"): the 32-channel input of this layer is not read from `in0` but computed per tile
+  // as LeakyReLU(first_b + first_w * [x, sigma]) straight from the fp32 network input (conv_first.h's arithmetic)
+  const float* first_x;        // [B,1,H,W]
+  const float* first_sigma;    // [B * first_sigma_stride]
+  const float* first_w;        // [32][2][9]
+  const float* first_b;        // [32]
+  const float* first_zero;     // a zero word in device memory (window elements outside the image)
+  int first_sigma_stride;
+  float first_slope;
 };
 
 int conv_hs_mt(int cout);
@@ -80,7 +89,18 @@ struct ConvHsFuse {       // optional fused work
   // cin = cout = 32 single-source layers: weights in registers, one pipeline step per tile (conv_hs_kernel.h WREG):
   // 0 = generic kernel, 1 = four waves x four pixel blocks, 2 = eight waves x two pixel blocks.  Same K order: same bits.
   int wreg = 2;
+  // fold the network's first convolution (2 -> 32 channels, K = 18, vector ALU) into THIS 32 -> 32 layer's tile loader
+  // (weights-in-registers instance only): its 32-channel output tensor is then neither written nor read
+  const float* first_x = nullptr;
+  const float* first_sigma = nullptr;
+  const float* first_w = nullptr;
+  const float* first_b = nullptr;
+  const float* first_zero = nullptr;
+  int first_sigma_stride = 0;
+  float first_slope = 0.2f;
 };
+// true when launch_conv_hs will honour ConvHsFuse::first_x for this layer / geometry (else the caller runs conv_first)
+bool conv_hs_can_fold_first(const ConvLayerHs& L, int G0, int B, int H, int W, const ConvHsFuse& fuse);
 bool conv_hs_can_fuse_upsample(const ConvLayerHs& L, int G0, int G1, int H, int W);
 // true when launch_conv_hs will honour ConvHsFuse::pool_out for this geometry
 bool conv_hs_can_pool(int H, int W);

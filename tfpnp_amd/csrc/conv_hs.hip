@@ -133,6 +133,9 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.B = B;
   a.ups_h = a.ups_w = 0;
   a.ups_sy = a.ups_sx = 0.f;
+  a.first_x = a.first_sigma = a.first_w = a.first_b = a.first_zero = nullptr;
+  a.first_sigma_stride = 0;
+  a.first_slope = 0.f;
   if (fuse.ups_h) {   // fused bilinear x2 of the second source: one instance, picked here
     if (!conv_hs_can_fuse_upsample(L, G0, G1, H, W) || fuse.ups_h * 2 != H || fuse.ups_w * 2 != W || !in1 || fuse.pool_out ||
         fuse.outc_w || fuse.dmask || fuse.res) {
@@ -167,6 +170,21 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   if (a.dmask) return launch_conv_hs_dmask(a, mt_run, B, s);
   if (a.res) return launch_conv_hs_res(a, mt_run, B, s);
   // weights-in-registers instances: 32 -> 32 channels from one source, 32-pixel-wide blocks, enough tiles to fill the chip
+  if (fuse.first_x) {   // first convolution folded into this layer's loader: one instance (checked by the caller through
+                        // conv_hs_can_fold_first)
+    if (!conv_hs_can_fold_first(L, G0, B, H, W, fuse) || G1 != 0) {
+      set_error("conv_hs: the first convolution cannot be folded into this layer / geometry");
+      return PNPX_ERR_SHAPE;
+    }
+    a.first_x = fuse.first_x;
+    a.first_sigma = fuse.first_sigma;
+    a.first_sigma_stride = fuse.first_sigma_stride;
+    a.first_w = fuse.first_w;
+    a.first_b = fuse.first_b;
+    a.first_zero = fuse.first_zero;
+    a.first_slope = fuse.first_slope;
+    return launch_hs_cfg<32, 2, 32, 8, EPI_ACT, 0, 2>(a, B, s);
+  }
   if (fuse.wreg && L.mt == 32 && L.cout == 32 && G0 == 4 && G1 == 0 && W >= 32) {
     const bool w8 = fuse.wreg == 2;
     const long long tiles = (long long)((W + 31) / 32) * ((H + 15) / 16) * B;   // both shapes: 16-row tiles
@@ -178,6 +196,12 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   if (a.outc_w) return launch_hs_mt<32, EPI_OUTC>(a, B, s);
   if (mt_run == 64) return launch_hs_mt<64, EPI_ACT>(a, B, s);
   return launch_hs_mt<32, EPI_ACT>(a, B, s);
+}
+
+bool conv_hs_can_fold_first(const ConvLayerHs& L, int G0, int B, int H, int W, const ConvHsFuse& fuse) {
+  const long long tiles = (long long)((W + 31) / 32) * ((H + 15) / 16) * B;
+  return fuse.wreg != 0 && L.mt == 32 && L.cout == 32 && L.cin == 32 && G0 == 4 && W >= 32 && tiles >= 256 && !fuse.pool_out &&
+         !fuse.outc_w && !fuse.dmask && !fuse.res && !fuse.ups_h;
 }
 
 // The fused bilinear x2 instance: 32 output channels, 32-pixel-wide blocks, the first two K-chunks from the skip source.

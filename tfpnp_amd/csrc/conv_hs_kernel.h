@@ -67,7 +67,10 @@ struct HsGeom {
   static constexpr int STAGE = IN_BYTES + W_BYTES;
   static constexpr int BIAS_OFF = 2 * STAGE;
   static constexpr int BIAS_BYTES = WREG ? 256 : HS_BIAS_BYTES;   // WREG: one 32-cout tile
-  static constexpr int LDS_USED = 2 * STAGE + BIAS_BYTES;
+  static constexpr int XWIN_W = TW + 4, XWIN_H = TH + 4;          // WREG == 2: fp32 network-input window of a tile
+  static constexpr int XWIN_OFF = 2 * STAGE + BIAS_BYTES;
+  static constexpr int XWIN_BYTES = WREG == 2 ? ((XWIN_W * XWIN_H * 4 + 255) & ~255) : 0;
+  static constexpr int LDS_USED = 2 * STAGE + BIAS_BYTES + XWIN_BYTES;
   // One workgroup per CU BY CONSTRUCTION: the request is padded past half of the 160 KiB so that two workgroups can
   // never be co-resident (see DESIGN.md "co-residency"); the persistent grid is <= 256 workgroups.
   static constexpr int LDS_BYTES = LDS_USED > 82 * 1024 ? LDS_USED : 82 * 1024;
@@ -128,6 +131,7 @@ template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0>
 __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES * UPS) / 4) void conv_hs_kernel(ConvHsArgs a) {
   using G = HsGeom<MT, NBW, MBW, NW, WREG>;
   static_assert(!(WREG && UPS) && (!WREG || MT == 32), "WREG: 32-cout single-source layers only");
+  constexpr bool FIRST = (WREG == 2);   // the layer's input halo is computed from the fp32 network input (no halo DMA)
   using U = HsUpsGeom<MBW, NW * NBW>;
   constexpr int NT = (NW + HS_UPS_WAVES * UPS) * 64;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -217,6 +221,7 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   };
   bool next_halo_by_dma = true;   // UPS: false while the next step's chunk comes from the low-resolution source
   auto issue_slot = [&](int slot, const char* src, const char* wsrc, char* lstage) {
+    if constexpr (FIRST) return;
     // the (wave-uniform) guards are compile-time true except on the last slot of each kind
     if (slot < G::NI) {
       if (UPS && !next_halo_by_dma) return;
@@ -522,6 +527,83 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     }
   };
 
+  // FIRST: the fp32 input window of the NEXT tile goes global -> LDS by 4-byte LDS-DMA right after this tile's halo has
+  // been generated, i.e. BEFORE this tile's record stores (vmcnt retires in order: a load behind the stores would wait for
+  // them); window elements outside the image are fetched from a zero word.  Element i lands at byte 4 i.
+  [[maybe_unused]] auto xwin_fetch = [&](const Tile& T) {
+    const float* xb = a.first_x + (size_t)T.b * a.H * a.W;
+    char* xw = lds + G::XWIN_OFF;
+#pragma unroll
+    for (int k = 0; k < (G::XWIN_BYTES / 256 + NW - 1) / NW; ++k) {
+      const int instr = wave + NW * k;
+      if (instr < G::XWIN_BYTES / 256) {
+        const int i = instr * 64 + lane;
+        const int wy = i / G::XWIN_W, wx = i - wy * G::XWIN_W;
+        const int yy = T.y0 - 2 + wy, xc = T.x0 - 2 + wx;
+        const bool ok = (i < G::XWIN_W * G::XWIN_H) && (yy >= 0) && (yy < a.H) && (xc >= 0) && (xc < a.W);
+        const float* src = ok ? xb + (size_t)yy * a.W + xc : a.first_zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xw + instr * 256), 4, 0, 0);
+      }
+    }
+  };
+  // FIRST: this tile's (TH+2) x (TW+2) x 32-channel input halo = the network's first convolution evaluated on the fly
+  // (exact fp32 FMA chains in conv_first_hs_kernel's order, same hi/lo split: bit-identical to the tensor it replaces;
+  // halo pixels outside the image are the tensor's zero border).  One (pixel, 8-channel group) item per lane and round;
+  // the 100 left-over pixels of every group go to a different pair of waves so that all waves do five rounds.
+  // The first layer's weights + bias live in LDS for the life of the workgroup: group g's 8 x 18 weights and 8 biases
+  // (608 B) sit in the 768-byte slack behind chunk region g of the two halo stages (a chunk region is IN_BYTES_C = a whole
+  // number of 1-KiB DMA pieces; the planes end 768 B earlier and nothing else writes there in FIRST mode).
+  // (Measured alternatives: wave-uniform scalar weight loads per item 0.285 ms per folded launch, scalar weights hoisted
+  // per channel over two pixels 0.45 ms (143 spilled registers); this form 0.211 ms = the two separate launches + 0.034.)
+  static_assert(!FIRST || G::IN_BYTES_C - 4 * G::PLANE * 16 >= 608, "no slack for the first layer's weights");
+  [[maybe_unused]] auto first_wtab = [&](int g) -> float* {
+    return reinterpret_cast<float*>(lds + (g >> 1) * G::STAGE + (g & 1) * G::IN_BYTES_C + 4 * G::PLANE * 16);
+  };
+  if constexpr (FIRST) {
+    for (int i = tid; i < 4 * 152; i += NT) {
+      const int g = i / 152, k = i - g * 152;
+      first_wtab(g)[k] = k < 144 ? a.first_w[g * 144 + k] : a.first_b[g * 8 + (k - 144)];
+    }
+    __syncthreads();
+  }
+  [[maybe_unused]] auto gen_halo = [&](const Tile& T, char* lstage) {
+    const float sg = a.first_sigma[(size_t)T.b * a.first_sigma_stride];
+    const float* xw = reinterpret_cast<const float*>(lds + G::XWIN_OFF);   // window origin = image (y0 - 2, x0 - 2), 0 outside
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+      const float* wt = first_wtab(g);
+      const int rot = (tid + NT - g * 128) % NT;     // lane's slot in this group's item list
+#pragma unroll 1
+      for (int r = rot; r < G::PLANE; r += NT) {
+        const int hy = r / G::LW, hx = r - hy * G::LW;
+        const int y = T.y0 - 1 + hy, x = T.x0 - 1 + hx;
+        const bool inside = (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
+        float xi[9], si[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int yy = y + t / 3 - 1, xc = x + t % 3 - 1;
+          const bool in = inside && (yy >= 0) && (yy < a.H) && (xc >= 0) && (xc < a.W);
+          xi[t] = xw[(hy + t / 3) * G::XWIN_W + hx + t % 3];       // (yy - (y0 - 2), xc - (x0 - 2)); zero outside the image
+          si[t] = in ? sg : 0.f;
+        }
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          float acc = wt[144 + c];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc = fmaf(wt[c * 18 + t], xi[t], acc);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc = fmaf(wt[c * 18 + 9 + t], si[t], acc);
+          v[c] = inside ? fmaxf(acc, acc * a.first_slope) * HS_ASCALE : 0.f;
+        }
+        const HsRec rec = hs_pack(v);
+        char* dst = lstage + (g >> 1) * G::IN_BYTES_C + (((g & 1) * 2) * G::PLANE + r) * 16;
+        *reinterpret_cast<h8v*>(dst) = rec.hi;
+        *reinterpret_cast<h8v*>(dst + G::PLANE * 16) = rec.lo;
+      }
+    }
+  };
+
 #ifdef HS_TRACE
   int tk = 0;
   const bool tr_on = a.trace && blockIdx.x == 8 && wave == 0;
@@ -644,6 +726,7 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   if (!valid(tile)) return;
   Tile cur = decode(tile);
   int ch = 0, stage = 0;
+  if constexpr (FIRST) xwin_fetch(cur);
   if (!producer) {
     const char* src = chunk_src(cur, 0);
     const char* w = chunk_w(cur, 0);
@@ -678,6 +761,14 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     mark(2);
     __builtin_amdgcn_s_barrier();
     mark(3);
+    if constexpr (FIRST) {
+      // the counted wait + barrier above published this tile's fp32 input window (its 4-byte LDS-DMA was issued one tile ago,
+      // before that tile's stores).  Compute the 32-channel halo from it (nobody reads this stage: its last readers passed
+      // the previous barrier), then start the next tile's window.
+      gen_halo(cur, lds + stage * G::STAGE);
+      __syncthreads();
+      if (has_next) xwin_fetch(nxt);
+    }
     if (producer) {
       const int i0 = lr_i, i1 = lr_i == 2 ? 0 : lr_i + 1, i2 = lr_i == 0 ? 2 : lr_i - 1;   // s % 3, (s+1) % 3, (s+2) % 3
       // (A) window of step s+3

@@ -356,6 +356,9 @@ struct Recorder {
     sink->n++;
     return PNPX_OK;
   }
+  void credit(double flops) {   // extra algorithmic FLOPs of the launch marked last (work folded into it)
+    if (sink && !sink->flops.empty()) sink->flops.back() += flops;
+  }
 };
 
 inline dim3 g1d(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -420,7 +423,32 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
                    const ConvHsFuse& fuse, const ConvHsFuse& first_fuse = ConvHsFuse()) -> int {
     const Act& ta = i1 ? P.da[lvl] : P.a[lvl];   // decoder blocks (two sources) have their own temporaries
     const Act& tb = i1 ? P.db[lvl] : P.b[lvl];
-    if (li == 0 && first_fused) {
+    bool folded = false;
+    if (li == 0 && first_fused && ctx->opt_fold_first && !keep_all) {
+      // the first convolution (2 -> 32 channels, vector ALU) folded into the loader of the block's second convolution
+      // (weights-in-registers instance): its output tensor `ta` is neither written nor read
+      const ConvLayerHsDev& D1 = ctx->conv_hs[1];
+      ConvLayerHs L1;
+      L1.cin = D1.cin;
+      L1.cout = D1.cout;
+      L1.mt = D1.mt;
+      ConvHsFuse f1;
+      f1.wreg = ctx->opt_wreg;
+      if (conv_hs_can_fold_first(L1, ta.C / 8, nb, H, W, f1)) {
+        f1.first_x = x + (size_t)b0 * H * W;
+        f1.first_sigma = sigma + (size_t)b0 * sigma_stride;
+        f1.first_sigma_stride = sigma_stride;
+        f1.first_w = ctx->conv0_w;
+        f1.first_b = ctx->conv[0].b;
+        f1.first_zero = ctx->zero_bias;
+        f1.first_slope = 0.2f;
+        PNPX_TRY(conv(1, ta, nullptr, tb, b0, nb, f1));
+        rec.credit(2.0 * 9.0 * 2 * 32 * (double)H * W * nb);   // the folded first convolution's FLOPs
+        folded = true;
+      }
+    }
+    if (folded) {
+    } else if (li == 0 && first_fused) {
       hipLaunchKernelGGL(conv_first_hs_kernel, dim3((H * W + 255) / 256, 4, nb), dim3(256), 0, s, x + (size_t)b0 * H * W,
                          sigma + (size_t)b0 * sigma_stride, sigma_stride, ctx->conv0_w, ctx->conv[0].b, rat(ta, b0), H, W,
                          0.2f);
@@ -428,7 +456,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
       PNPX_TRY(rec.mark("conv3x3", 2.0 * 9.0 * 2 * 32 * (double)H * W * nb));
     } else
     PNPX_TRY(conv(li, i0, i1, ta, b0, nb, first_fuse));
-    PNPX_TRY(conv(li + 1, ta, nullptr, tb, b0, nb, ConvHsFuse()));
+    if (!folded) PNPX_TRY(conv(li + 1, ta, nullptr, tb, b0, nb, ConvHsFuse()));
     return conv(li + 2, tb, nullptr, o, b0, nb, fuse);
   };
 
