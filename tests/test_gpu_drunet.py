@@ -118,3 +118,21 @@ def test_drunet_contract_errors(drunet):
     class Opt:
         denoiser = "drunet"
     assert isinstance(create_denoiser(Opt(), state_dict=synth.make_drunet_params(0)), DRUNetDenoiser2D)
+
+
+def test_drunet_range_overflow_is_loud():
+    """The DRUNet has no exact-fp32 fallback: if an activation leaves the half-split range the guard latches the context
+    and every later denoiser call FAILS (PNPX_ERR_RANGE) instead of returning possibly invalid values."""
+    from tfpnp_amd._lib import PnpxError
+    from tfpnp_amd.pnp import DRUNetDenoiser2D
+    hot = {k: np.array(v, copy=True) for k, v in synth.make_drunet_params(0).items()}
+    hot["m_head.weight"] = (hot["m_head.weight"] * 1e4).astype(np.float32)
+    den = DRUNetDenoiser2D(state_dict=hot)
+    x = torch.rand(2, 1, 64, 64, device=dev())
+    s = torch.full((2,), 0.1, device=dev())
+    den(x, s)                                   # trips the guard (not visible yet: no synchronisation in the default mode)
+    torch.cuda.synchronize()
+    with pytest.raises(PnpxError, match="range guard"):
+        den.context(dev()).status()
+    with pytest.raises(PnpxError, match="half-split"):
+        den(x, s)

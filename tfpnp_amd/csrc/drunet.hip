@@ -271,6 +271,14 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
     set_error("DRUNet denoiser called before pnpx_drunet_load");
     return PNPX_ERR_NO_WEIGHTS;
   }
+  if (ctx->conv_mode != CONV_HS) {
+    // the DRUNet exists on the half-split kernel family only: conv_mode 0 (set by the caller, or latched by the range
+    // guard after an activation left the f16 hi/lo range) cannot be honoured -- fail loudly instead of returning
+    // values that may be invalid
+    set_error("DRUNet runs on the half-split convolutions only (conv_mode 1); conv_mode 0 was %s",
+              ctx->range_tripped ? "latched by the range guard: an activation left the f16 hi/lo range (|v| >= 4095)" : "requested");
+    return ctx->range_tripped ? PNPX_ERR_RANGE : PNPX_ERR_ARG;
+  }
   if (B <= 0 || H < 8 || W < 8 || (H & 7) || (W & 7)) {
     set_error("DRUNet: need B > 0 and H, W positive multiples of 8 (three 2x2 strided convolutions; got B=%d H=%d W=%d)", B, H, W);
     return PNPX_ERR_SHAPE;
