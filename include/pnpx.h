@@ -58,8 +58,17 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *      2 (strict): every denoiser / solver entry synchronises its stream before returning and, if the flag was set,
  *         repeats itself in conv_mode 0 -- the caller always receives valid output, at the price of a sync per call.
  *      0: off.
- *  "train_cache_gb" (default 96): device-memory budget of the training path's activation cache (see
- *      pnpx_csmri_admm_train); 0 releases it and makes every backward re-compute.
+ *  "train_cache_gb" (default -1): device-memory budget of the training path's activation cache (see
+ *      pnpx_csmri_admm_train); -1 = a quarter of the device memory free when the ring is first laid out, at most 96 GiB
+ *      (the ring is raw device memory outside any framework allocator); 0 releases it and makes every backward
+ *      re-compute.  "train_cache_release" (any value): give the ring's memory back now, budget unchanged.
+ *  "wreg" (default 2): weights-in-registers instances of the 32 -> 32 channel convolutions (0 = generic kernel, 1 = four
+ *      waves x four pixel blocks, 2 = eight waves x two pixel blocks); bit-identical results.
+ *  "chains" (default 0 = automatic): run a denoiser forward as n independent launch chains over slices of the batch on
+ *      side streams (pays for small batches whose launches cannot fill the chip; bit-identical per image).
+ *  "fft_affine" (default 1), "fft_tile" (default 0 = 1024 points): XCD-affine image mapping and tile size of the FFT passes.
+ *  "fold_first" (default 0): 1 = the network's first convolution is evaluated inside the tile loader of the second one
+ *      (its output tensor is neither written nor read; bit-identical, time-neutral).
  *  "fuse_up" (default 0): 1 = the full-resolution decoder entry (96 -> 32 channels) up-samples its low-resolution source
  *      inside the convolution kernel (four producer waves per workgroup interpolate each K-chunk's halo into LDS), so the
  *      largest up-sampled tensor never exists in HBM.  Same arithmetic (per-call difference 1.4e-7), +1.7 % iterations/s;
