@@ -110,6 +110,7 @@ struct DruNet {
   bool loaded = false;
   int nb = 0;
   std::vector<ConvLayerHsDev> layers;
+  std::vector<int> taps;           // per layer: 3x3 tap mask its weights are packed with (0x010 for the 1x1 layers)
   const float* head_w = nullptr;   // [64][2][3][3] native (VALU head convolution)
   const float* zero = nullptr;     // [1024] zeros: the bias operand of the bias-free network
   const float* e0 = nullptr;       // [32] = (1, 0, ...): channel selector of the fused tail epilogue, followed by zeros

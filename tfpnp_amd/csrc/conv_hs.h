@@ -41,6 +41,7 @@ struct ConvHsArgs {
   float* out_img;        // [B,1,H,W]
   float* out_pre;        // [B,1,H,W] or null
   int G0, G1;
+  int G0t;           // channel groups per image of the tensor behind in0 (>= G0: a layer may read only its first G0 groups)
   int H, W, Hp, Wp;
   int tilesX, tilesY, nct, B;
   HsFastDiv div_nct, div_tx, div_ty;
@@ -72,6 +73,8 @@ struct ConvHsArgs {
 
 int conv_hs_mt(int cout);
 float pack_conv_weights_hs(const float* w, int cout, int cin, int mt, uint16_t* dst);
+// same from w[cout][cin][3][3] but storing only the taps of `tapmask` (in ascending tap order): [..][ntaps][hi,lo][kg][mt][8]
+float pack_conv_weights_hs_taps(const float* w, int cout, int cin, int mt, int tapmask, uint16_t* dst);
 struct ConvHsFuse {       // optional fused work
   char* pool_out = nullptr;
   const float* outc_w = nullptr;
@@ -89,6 +92,10 @@ struct ConvHsFuse {       // optional fused work
   // cin = cout = 32 single-source layers: weights in registers, one pipeline step per tile (conv_hs_kernel.h WREG):
   // 0 = generic kernel, 1 = four waves x four pixel blocks, 2 = eight waves x two pixel blocks.  Same K order: same bits.
   int wreg = 2;
+  // sparse-tap layers (EPI_ACT only): bit mask of the 3x3 taps the layer was PACKED with (pack_conv_weights_hs_taps);
+  // 0x1FF = ordinary 3x3.  in0_groups: channel groups per image of the in0 tensor when the layer reads only its first G0.
+  int taps = 0x1FF;
+  int in0_groups = 0;
   // fold the network's first convolution (2 -> 32 channels, K = 18, vector ALU) into THIS 32 -> 32 layer's tile loader
   // (weights-in-registers instance only): its 32-channel output tensor is then neither written nor read
   const float* first_x = nullptr;

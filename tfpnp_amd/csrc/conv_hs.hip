@@ -98,6 +98,7 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.G0 = G0;
   a.in1 = in1 ? in1 : in0;
   a.G1 = G1;
+  a.G0t = fuse.in0_groups > 0 ? fuse.in0_groups : G0;
   a.wpk = L.w;
   a.bias = L.b;
   a.out = out;
@@ -167,6 +168,13 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
       a.nct = L.cout / 32;
     }
   }
+  if (fuse.taps != 0x1FF) {
+    if (a.dmask || a.res || a.outc_w || a.pool_out || fuse.ups_h || fuse.first_x || G1 != 0) {
+      set_error("conv_hs: sparse-tap layers support the plain activation epilogue and one source only");
+      return PNPX_ERR_SHAPE;
+    }
+    return launch_conv_hs_taps(a, mt_run, fuse.taps, B, s);
+  }
   if (a.dmask) return launch_conv_hs_dmask(a, mt_run, B, s);
   if (a.res) return launch_conv_hs_res(a, mt_run, B, s);
   // weights-in-registers instances: 32 -> 32 channels from one source, 32-pixel-wide blocks, enough tiles to fill the chip
@@ -230,6 +238,13 @@ static inline int hs_row_channel(int row) {
 // scaled by a power of two.
 // Returns the scale s (weights are stored as split(s*w)).
 float pack_conv_weights_hs(const float* w, int cout, int cin, int mt, uint16_t* dst) {
+  return pack_conv_weights_hs_taps(w, cout, cin, mt, 0x1FF, dst);
+}
+
+float pack_conv_weights_hs_taps(const float* w, int cout, int cin, int mt, int tapmask, uint16_t* dst) {
+  int taps[9], nt = 0;
+  for (int t = 0; t < 9; ++t)
+    if ((tapmask >> t) & 1) taps[nt++] = t;
   const int cin_pad = (cin + 15) / 16 * 16;
   float mx = 0.f;
   for (size_t i = 0; i < (size_t)cout * cin * 9; ++i) mx = std::fmax(mx, std::fabs(w[i]));
@@ -242,15 +257,16 @@ float pack_conv_weights_hs(const float* w, int cout, int cin, int mt, uint16_t* 
   const int nct = cout / mt, nch = cin_pad / 16;
   for (int ct = 0; ct < nct; ++ct)
     for (int ch = 0; ch < nch; ++ch)
-      for (int tap = 0; tap < 9; ++tap)
+      for (int ti = 0; ti < nt; ++ti)
         for (int kgi = 0; kgi < 2; ++kgi)
           for (int m = 0; m < mt; ++m)
             for (int el = 0; el < 8; ++el) {
+              const int tap = taps[ti];
               const int co = ct * mt + (m & ~31) + hs_row_channel(m & 31), ci = ch * 16 + kgi * 8 + el;
               const float v = (ci < cin) ? w[((size_t)co * cin + ci) * 9 + tap] * s : 0.f;
               const _Float16 hi = (_Float16)v;
               const _Float16 lo = (_Float16)(v - (float)hi);
-              const size_t base = ((((size_t)ct * nch + ch) * 9 + tap) * 2) * 2 * mt * 8;   // start of [hi,lo] pair
+              const size_t base = ((((size_t)ct * nch + ch) * nt + ti) * 2) * 2 * mt * 8;   // start of [hi,lo] pair
               dst[base + ((size_t)(0 * 2 + kgi) * mt + m) * 8 + el] = f16_bits(hi);
               dst[base + ((size_t)(1 * 2 + kgi) * mt + m) * 8 + el] = f16_bits(lo);
             }

@@ -44,8 +44,25 @@ constexpr int HS_BIAS_BYTES = 4096;   // LDS copy of the layer's (pre-scaled) bi
 // hi/lo = 36 fragments of 16 B per lane) is loaded into registers once per workgroup, a pipeline step is a whole TILE
 // (CPS = 2 chunks: both halo planes sets in one stage, one barrier per tile instead of two, no weight DMA, no A-fragment
 // ds_reads), and the LDS stage holds halos only.
-template <int MT, int NBW, int MBW, int NW, int WREG = 0>
+// TAPS = bit mask of the 3x3 taps a layer has (bit dy*3+dx; 0x1FF = all nine).  Sparse-tap layers store, copy and
+// multiply only their taps: 0x010 = 1x1 convolution, 0x01B = taps (0,0) (0,1) (1,0) (1,1) = a stride-2 3x3 convolution
+// evaluated as a 2x2-window convolution over the space-to-depth input (policy ResNet stage entries).
+constexpr int hs_ntaps(int mask) {
+  int n = 0;
+  for (int t = 0; t < 9; ++t) n += (mask >> t) & 1;
+  return n;
+}
+constexpr int hs_nth_tap(int mask, int i) {   // the i-th set bit
+  for (int t = 0; t < 9; ++t)
+    if ((mask >> t) & 1) {
+      if (i == 0) return t;
+      --i;
+    }
+  return 0;
+}
+template <int MT, int NBW, int MBW, int NW, int WREG = 0, int TAPS = 0x1FF>
 struct HsGeom {
+  static constexpr int NTAPS = hs_ntaps(TAPS);
   static constexpr int CPS = WREG ? 2 : 1;              // K-chunks per pipeline step
   static constexpr int MBH = 32 / MBW;
   static constexpr int NBLK = NW * NBW;
@@ -60,7 +77,7 @@ struct HsGeom {
   static constexpr int IN_INSTR = CPS * IN_INSTR_C;
   static constexpr int NI = (IN_INSTR + NW - 1) / NW;   // DMA slots per wave
   static constexpr int IN_BYTES = IN_INSTR * 1024;
-  static constexpr int W_BYTES_FULL = 9 * 2 * 2 * MT * 16;   // [tap][hi,lo][kg][MT] x 16 B (multiple of 1 KiB)
+  static constexpr int W_BYTES_FULL = NTAPS * 2 * 2 * MT * 16;   // [tap][hi,lo][kg][MT] x 16 B (multiple of 1 KiB)
   static constexpr int W_BYTES = WREG ? 0 : W_BYTES_FULL;    // ... staged through LDS
   static constexpr int W_INSTR = W_BYTES / 1024;
   static constexpr int NWJ = (W_INSTR + NW - 1) / NW;
@@ -127,9 +144,10 @@ struct HsUpsGeom {   // low-resolution window feeding one (TH+2) x (TW+2) halo
   static constexpr int BYTES = INSTR * 1024;
 };
 
-template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0>
+template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF>
 __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES * UPS) / 4) void conv_hs_kernel(ConvHsArgs a) {
-  using G = HsGeom<MT, NBW, MBW, NW, WREG>;
+  using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS>;
+  static_assert(TAPS == 0x1FF || (!WREG && !UPS), "sparse-tap layers: generic instances only");
   static_assert(!(WREG && UPS) && (!WREG || MT == 32), "WREG: 32-cout single-source layers only");
   constexpr bool FIRST = (WREG == 2);   // the layer's input halo is computed from the fp32 network input (no halo DMA)
   using U = HsUpsGeom<MBW, NW * NBW>;
@@ -202,7 +220,7 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   };
   auto chunk_src = [&](const Tile& T, int chunk) -> const char* {   // chunk = pipeline step (CPS K-chunks)
     const int g0 = chunk * 2 * G::CPS;
-    const char* src = (g0 < a.G0) ? a.in0 + ((size_t)T.b * a.G0 + g0) * HpWp * 32
+    const char* src = (g0 < a.G0) ? a.in0 + ((size_t)T.b * a.G0t + g0) * HpWp * 32
                                   : a.in1 + ((size_t)T.b * a.G1 + (g0 - a.G0)) * HpWp * 32;
 #ifdef PNPX_TUNING
     if (a.abl & 4) return src + ((size_t)T.y0 * a.Wp + T.x0) * 16;
@@ -274,8 +292,9 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   };
   // `tap` runs over the CPS * 9 (chunk, tap) pairs of a step
   auto load_frags = [&](Frags& f, const char* la, const char* lb, int tapx) {
-    const int cc = tapx / 9, tap = tapx % 9;
-    const int dy = tap / 3, dx = tap % 3;
+    const int cc = tapx / G::NTAPS, tap = tapx % G::NTAPS;     // tap = index among the layer's taps (weight packing order)
+    const int rt = hs_nth_tap(TAPS, tap);                      // ... and which of the 3x3 positions it is
+    const int dy = rt / 3, dx = rt % 3;
     if constexpr (WREG) {
       f.ah[0] = areg[cc][tap][0];
       f.al[0] = areg[cc][tap][1];
@@ -299,8 +318,8 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     char* nstage = lds + (stage ^ 1) * G::STAGE;
     const char* lb = lds + stage * G::STAGE + b_lane;
     const char* la = lds + stage * G::STAGE + a_lane;
-    constexpr int NTAP = 9 * G::CPS;                              // (chunk, tap) pairs of one step
-    constexpr int DMA_TAPS = WREG ? NTAP : HS_DMA_TAPS;           // taps the next step's DMA slots are spread over
+    constexpr int NTAP = G::NTAPS * G::CPS;                       // (chunk, tap) pairs of one step
+    constexpr int DMA_TAPS = WREG ? NTAP : (HS_DMA_TAPS < NTAP ? HS_DMA_TAPS : NTAP);   // taps the next step's DMA slots are spread over
     Frags fr[2];
     load_frags(fr[0], la, lb, 0);
 #pragma unroll
@@ -850,12 +869,12 @@ inline int ensure_dyn_lds(const void* func, int bytes) {
   return PNPX_OK;
 }
 
-template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0>
+template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF>
 static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
-  using G = HsGeom<MT, NBW, MBW, NW, WREG>;
+  using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS>;
   constexpr int LDS_REQ = G::LDS_BYTES + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES;
   static_assert(G::LDS_USED + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES <= 160 * 1024, "no LDS room for the low-resolution windows");
-  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG>), LDS_REQ));
+  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS>), LDS_REQ));
   ConvHsArgs a = a0;
   a.tilesX = (a.W + G::TW - 1) / G::TW;
   a.tilesY = (a.H + G::TH - 1) / G::TH;
@@ -908,7 +927,7 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
     a.trace = tbuf;
   }
 #endif
-  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG>), dim3((unsigned)grid),
+  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS>), dim3((unsigned)grid),
                      dim3((NW + HS_UPS_WAVES * UPS) * 64), lds_req, s, a);
   PNPX_LAUNCH_CHECK();
 #ifdef PNPX_TUNING
@@ -956,30 +975,31 @@ struct HsChoice {
   int nbw, nw;
 };
 
-template <int MT, int MBW, int EPI>
+template <int MT, int MBW, int EPI, int TAPS = 0x1FF>
 static int launch_hs_mbw(const ConvHsArgs& a, int B, HsChoice c, hipStream_t s) {
   if (c.nw == 8) {
-    if (c.nbw >= 2) return launch_hs_cfg<MT, 2, MBW, 8, EPI>(a, B, s);
-    return launch_hs_cfg<MT, 1, MBW, 8, EPI>(a, B, s);
+    if (c.nbw >= 2) return launch_hs_cfg<MT, 2, MBW, 8, EPI, 0, 0, TAPS>(a, B, s);
+    return launch_hs_cfg<MT, 1, MBW, 8, EPI, 0, 0, TAPS>(a, B, s);
   }
-  if (c.nbw == 4) return launch_hs_cfg<MT, 4, MBW, 4, EPI>(a, B, s);
-  if (c.nbw == 2) return launch_hs_cfg<MT, 2, MBW, 4, EPI>(a, B, s);
-  return launch_hs_cfg<MT, 1, MBW, 4, EPI>(a, B, s);
+  if (c.nbw == 4) return launch_hs_cfg<MT, 4, MBW, 4, EPI, 0, 0, TAPS>(a, B, s);
+  if (c.nbw == 2) return launch_hs_cfg<MT, 2, MBW, 4, EPI, 0, 0, TAPS>(a, B, s);
+  return launch_hs_cfg<MT, 1, MBW, 4, EPI, 0, 0, TAPS>(a, B, s);
 }
 
 HsChoice hs_choose(int mt, const ConvHsArgs& a, int B);   // conv_hs.hip
 
-template <int MT, int EPI>
+template <int MT, int EPI, int TAPS = 0x1FF>
 static int launch_hs_mt(const ConvHsArgs& a, int B, hipStream_t s) {
   const int mbw = a.W >= 32 ? 32 : (a.W >= 16 ? 16 : 8);
   const HsChoice c = hs_choose(MT, a, B);
-  if (mbw == 32) return launch_hs_mbw<MT, 32, EPI>(a, B, c, s);
-  if (mbw == 16) return launch_hs_mbw<MT, 16, EPI>(a, B, c, s);
-  return launch_hs_mbw<MT, 8, EPI>(a, B, c, s);
+  if (mbw == 32) return launch_hs_mbw<MT, 32, EPI, TAPS>(a, B, c, s);
+  if (mbw == 16) return launch_hs_mbw<MT, 16, EPI, TAPS>(a, B, c, s);
+  return launch_hs_mbw<MT, 8, EPI, TAPS>(a, B, c, s);
 }
 
 // entry points of the other translation units
 int launch_conv_hs_dmask(const ConvHsArgs& a, int mt, int B, hipStream_t s);   // conv_hs_bwd.hip
 int launch_conv_hs_res(const ConvHsArgs& a, int mt, int B, hipStream_t s);     // conv_hs_res.hip
+int launch_conv_hs_taps(const ConvHsArgs& a, int mt, int taps, int B, hipStream_t s);   // conv_hs_taps.hip (EPI_ACT)
 
 }  // namespace pnpx

@@ -12,7 +12,7 @@
 //   * ResBlock = conv3x3 + ReLU (EPI_ACT, slope 0), then conv3x3 + residual add in the epilogue (EPI_RES, linear);
 //   * strided 2x2 conv = space-to-depth re-layout (record copies) + a 1x1 convolution over 4*Cin channels;
 //   * transposed 2x2 conv = a 1x1 convolution to 4*Cout channels + depth-to-space re-layout;
-//     (1x1 convolutions run as 3x3 launches whose weights are zero outside the centre tap -- 6 of the 64 launches);
+//     (1x1 convolutions are sparse-tap launches, conv_hs_taps.hip: only the centre tap is stored, copied and multiplied);
 //   * head (K = 18) on the vector ALU straight from the fp32 image (conv_first_hs_kernel, as the UNet's first layer);
 //   * tail (64 -> 1) as a 32-cout launch with the fused "1x1 + residual + clamp" epilogue (EPI_OUTC) selecting channel 0.
 #include <cstring>
@@ -146,6 +146,7 @@ int drunet_load(pnpx_ctx* ctx, const float* params, size_t n, int nb) {
   auto align = [&]() { host.resize((host.size() + 255) & ~(size_t)255, 0.f); };
   std::vector<size_t> off(L.size(), 0);
   std::vector<ConvLayerHsDev> dev(L.size());
+  std::vector<int> taps(L.size(), 0x1FF);
   const float* src = params;
   std::vector<float> w3;
   size_t head_off = 0;
@@ -183,11 +184,15 @@ int drunet_load(pnpx_ctx* ctx, const float* params, size_t n, int nb) {
     }
     const int mt = conv_hs_mt(cout);
     const int cin_pad = (cin + 15) / 16 * 16;
+    const int tapmask = (d.kind == 3 || d.kind == 4) ? 0x010 : 0x1FF;   // 1x1 layers store / multiply the centre tap only
+    int ntap = 0;
+    for (int t = 0; t < 9; ++t) ntap += (tapmask >> t) & 1;
     align();
     off[i] = host.size();
-    const size_t n16 = (size_t)cout * cin_pad * 9 * 2;
+    const size_t n16 = (size_t)cout * cin_pad * ntap * 2;
     host.resize(host.size() + (n16 + 1) / 2, 0.f);
-    const float scale = pack_conv_weights_hs(wp, cout, cin, mt, reinterpret_cast<uint16_t*>(host.data() + off[i]));
+    const float scale = pack_conv_weights_hs_taps(wp, cout, cin, mt, tapmask, reinterpret_cast<uint16_t*>(host.data() + off[i]));
+    taps[i] = tapmask;
     dev[i].cin = cin;
     dev[i].cout = cout;
     dev[i].cin_pad = cin_pad;
@@ -220,6 +225,7 @@ int drunet_load(pnpx_ctx* ctx, const float* params, size_t n, int nb) {
   float* d = static_cast<float*>(p);
   for (size_t i = 0; i < L.size(); ++i) dev[i].w = reinterpret_cast<char*>(d + off[i]);
   N.layers = dev;
+  N.taps = taps;
   N.head_w = d + head_off;
   N.zero = d + zoff;
   N.e0 = d + eoff;
@@ -327,6 +333,7 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
     f.res = res;
     f.range_flag = range_flag;
     f.wreg = 0;
+    f.taps = N.taps[li];
     if (tail) {
       f.outc_w = N.e0;
       f.outc_b = N.e0 + 32;      // a zero
