@@ -198,6 +198,12 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_fuse_first = value;
     return PNPX_OK;
   }
+  if (is("policy_s2_hs") && (value == 0 || value == 1)) {   // (the arena is re-zeroed: the two layouts share a buffer)
+    PNPX_HIP(hipDeviceSynchronize());
+    ctx->opt_policy_s2_hs = value;
+    ctx->policy.capB = ctx->policy.capH = ctx->policy.capW = 0;
+    return PNPX_OK;
+  }
   if (is("fold_first") && (value == 0 || value == 1)) {
     ctx->opt_fold_first = value;
     return PNPX_OK;
@@ -262,6 +268,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("wreg")) *value = ctx->opt_wreg;
   else if (is("chains")) *value = ctx->opt_chains;
   else if (is("fold_first")) *value = ctx->opt_fold_first;
+  else if (is("policy_s2_hs")) *value = ctx->opt_policy_s2_hs;
   else if (is("fft_affine")) *value = ctx->opt_fft_affine;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
   else if (is("train_cache_gb")) *value = ctx->opt_train_cache_gb;

@@ -22,52 +22,13 @@
 #include "conv_first.h"
 #include "conv_hs.h"
 #include "hs_rec.h"
+#include "hs_relayout.h"
 
 namespace pnpx {
 
 namespace {
 
 constexpr int DRU_NC[4] = {64, 128, 256, 512};
-
-// [B][G][H+2][W+2] -> [B][4G][H/2+2][W/2+2]; output group = (dy*2+dx)*G + g holds input pixel (2y+dy, 2x+dx)
-__global__ __launch_bounds__(256) void dru_s2d_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int G, int H,
-                                                      int W, size_t n) {   // n = B*4G*(H/2)*(W/2)*2 16-byte pieces
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int piece = (int)(i & 1);
-  size_t t = i >> 1;
-  const int Wo = W / 2, Ho = H / 2;
-  const int x = (int)(t % Wo);
-  t /= Wo;
-  const int y = (int)(t % Ho);
-  t /= Ho;
-  const int go = (int)(t % (4 * G));
-  const size_t b = t / (4 * G);
-  const int ph = go / G, g = go - ph * G;
-  const size_t s = ((b * G + g) * (H + 2) + (2 * y + (ph >> 1) + 1)) * (W + 2) + 2 * x + (ph & 1) + 1;
-  const size_t d = ((b * 4 * G + go) * (Ho + 2) + (y + 1)) * (Wo + 2) + x + 1;
-  dst[d * 2 + piece] = src[s * 2 + piece];
-}
-
-// [B][4G][h+2][w+2] -> [B][G][2h+2][2w+2]; input group (dy*2+dx)*G + g at (y, x) lands at (2y+dy, 2x+dx) of group g
-__global__ __launch_bounds__(256) void dru_d2s_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int G, int h,
-                                                      int w, size_t n) {   // n = B*G*(2h)*(2w)*2 pieces
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int piece = (int)(i & 1);
-  size_t t = i >> 1;
-  const int W = 2 * w, H = 2 * h;
-  const int X = (int)(t % W);
-  t /= W;
-  const int Y = (int)(t % H);
-  t /= H;
-  const int g = (int)(t % G);
-  const size_t b = t / G;
-  const int ph = (Y & 1) * 2 + (X & 1);
-  const size_t s = ((b * 4 * G + ph * G + g) * (h + 2) + (Y / 2 + 1)) * (w + 2) + X / 2 + 1;
-  const size_t d = ((b * G + g) * (H + 2) + (Y + 1)) * (W + 2) + X + 1;
-  dst[d * 2 + piece] = src[s * 2 + piece];
-}
 
 // out = a + b on interior records (fp32 add of the recombined halves, re-split)
 __global__ __launch_bounds__(256) void dru_add_kernel(const HsRec* __restrict__ a, const HsRec* __restrict__ b,
@@ -371,7 +332,7 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
     PNPX_TRY(resblocks(l, cur, &cur));
     const int h = H >> l, w = W >> l, G = DRU_NC[l] / 8;
     const size_t n = (size_t)B * 4 * G * (h / 2) * (w / 2) * 2;
-    hipLaunchKernelGGL(dru_s2d_kernel, g1(n), dim3(256), 0, s, reinterpret_cast<const uint4*>(cur),
+    hipLaunchKernelGGL(hs_s2d_kernel, g1(n), dim3(256), 0, s, reinterpret_cast<const uint4*>(cur),
                        reinterpret_cast<uint4*>(A + Pl.DT[l + 1]), G, h, w, n);
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(conv(A + Pl.DT[l + 1], A + Pl.S[l + 1], h / 2, w / 2, 1.f, nullptr, false));
@@ -386,7 +347,7 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(conv(A + Pl.M[l + 1], A + Pl.DT[l + 1], h, w, 1.f, nullptr, false));
     const size_t nd = (size_t)B * Gout * (2 * h) * (2 * w) * 2;
-    hipLaunchKernelGGL(dru_d2s_kernel, g1(nd), dim3(256), 0, s, reinterpret_cast<const uint4*>(A + Pl.DT[l + 1]),
+    hipLaunchKernelGGL(hs_d2s_kernel, g1(nd), dim3(256), 0, s, reinterpret_cast<const uint4*>(A + Pl.DT[l + 1]),
                        reinterpret_cast<uint4*>(A + Pl.U[l]), Gout, h, w, nd);
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(resblocks(l, A + Pl.U[l], &cur));

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "conv_hs.h"
 #include "hs_rec.h"
+#include "hs_relayout.h"
 #include "policy_conv.h"
 
 namespace pnpx {
@@ -342,6 +343,9 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
   float hs_scale[12];
   int hs_c[12];
   int hi_ = 0;
+  size_t s2_w[4][2] = {}, s2_b[4][2] = {};
+  float s2_scale[4][2] = {};
+  int s2_K[4][2] = {}, s2_c[4][2] = {};
   auto finish_hs = [&](Eff& E) {
     H.align();
     hs_w[hi_] = H.f.size();
@@ -381,6 +385,27 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
       put_conv_s2(E, 0, w1, b1, p, in_planes, in_planes);
       put_shortcut(E, p, ws, bs, p, in_planes);
       finish(E, p);
+    }
+    if (s >= 1) {   // the same two convolutions packed for the sparse-tap half-split instances (stages 1..3)
+      Eff E1(p, 4 * in_planes), Es(p, in_planes);
+      put_conv_s2(E1, 0, w1, b1, p, in_planes, in_planes);
+      put_shortcut(Es, 0, ws, bs, p, in_planes);
+      Eff* both[2] = {&E1, &Es};
+      const int masks[2] = {0x01B, 0x010};
+      for (int k = 0; k < 2; ++k) {
+        Eff& E = *both[k];
+        int nt = 0;
+        for (int t = 0; t < 9; ++t) nt += (masks[k] >> t) & 1;
+        H.align();
+        s2_w[s][k] = H.f.size();
+        const size_t n16 = (size_t)E.cout * E.K * nt * 2;
+        H.f.resize(H.f.size() + (n16 + 1) / 2, 0.f);
+        s2_scale[s][k] = pack_conv_weights_hs_taps(E.w.data(), E.cout, E.K, 64, masks[k],
+                                                   reinterpret_cast<uint16_t*>(H.f.data() + s2_w[s][k]));
+        s2_b[s][k] = H.add(E.bias.data(), E.bias.size());
+        s2_K[s][k] = E.K;
+        s2_c[s][k] = E.cout;
+      }
     }
     {
       Eff E(p, p);
@@ -438,6 +463,15 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
     N.conv_hs[i].inv_scale = 1.0f / (hs_scale[i] * HS_ASCALE);
     N.bias_hs[i] = base + hs_b[i];
   }
+  for (int st = 1; st < 4; ++st)
+    for (int k = 0; k < 2; ++k) {
+      N.s2_hs[st][k].cin = N.s2_hs[st][k].cin_pad = s2_K[st][k];
+      N.s2_hs[st][k].cout = s2_c[st][k];
+      N.s2_hs[st][k].mt = 64;
+      N.s2_hs[st][k].w = const_cast<char*>(reinterpret_cast<const char*>(base + s2_w[st][k]));
+      N.s2_hs[st][k].inv_scale = 1.0f / (s2_scale[st][k] * HS_ASCALE);
+      N.s2_bias[st][k] = base + s2_b[st][k];
+    }
   N.fc_sm_w = base + o_smw;
   N.fc_sm_b = base + o_smb;
   N.fc_det_w = base + o_dw;
@@ -514,11 +548,40 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
   const float* xin = ptr(P.stem);
   for (int st = 0; st < 4; ++st) {
     const int h = H >> (st + 2), w = W >> (st + 2);
-    PNPX_TRY(launch_policy_conv(N.conv[1 + 4 * st], xin, ptr(P.t1[st]), ptr(P.sc[st]), nullptr, false, B, h, w, s, true));
+    if (st == 0 || !ctx->opt_policy_s2_hs) {
+      PNPX_TRY(launch_policy_conv(N.conv[1 + 4 * st], xin, ptr(P.t1[st]), ptr(P.sc[st]), nullptr, false, B, h, w, s, true));
+    } else {
+      // stride-2 entry on the sparse-tap half-split instances: conv1 = 2x2-window convolution over the HS8 space-to-depth
+      // input (taps 0x01B, ReLU), shortcut = 1x1 over its first Cin channels (tap 0x010, linear)
+      for (int k = 0; k < 2; ++k) {
+        const ConvLayerHsDev& D = N.s2_hs[st][k];
+        ConvLayerHs Lh;
+        Lh.cin = D.cin;
+        Lh.cout = D.cout;
+        Lh.cin_pad = D.cin_pad;
+        Lh.mt = D.mt;
+        Lh.w = D.w;
+        Lh.b = N.s2_bias[st][k];
+        Lh.inv_scale = D.inv_scale;
+        ConvHsFuse f;
+        f.slope = k == 0 ? 0.f : 1.f;
+        f.taps = k == 0 ? 0x01B : 0x010;
+        f.in0_groups = P.o1s[st - 1].C / 8;
+        f.wreg = 0;
+        f.range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
+        PNPX_TRY(launch_conv_hs(Lh, hsc(P.o1s[st - 1]), D.cin_pad / 8, nullptr, 0, hsc(k == 0 ? P.t1[st] : P.sc[st]), B, h, w, f, s));
+      }
+    }
     PNPX_TRY(conv_hs(3 * st + 0, P.t1[st], P.o0[st], &P.sc[st], h, w));
     PNPX_TRY(conv_hs(3 * st + 1, P.o0[st], P.t2[st], nullptr, h, w));
     PNPX_TRY(conv_hs(3 * st + 2, P.t2[st], P.o1[st], &P.o0[st], h, w));
-    if (st < 3) {
+    if (st < 3 && ctx->opt_policy_s2_hs) {   // HS8 -> HS8 space-to-depth (phase-major groups) for the next stage's entry
+      const int G = P.o1[st].C / 8;
+      const size_t n2 = (size_t)B * 4 * G * (h / 2) * (w / 2) * 2;
+      hipLaunchKernelGGL(hs_s2d_kernel, g1(n2), dim3(256), 0, s, reinterpret_cast<const uint4*>(hsc(P.o1[st])),
+                         reinterpret_cast<uint4*>(hsc(P.o1s[st])), G, h, w, n2);
+      PNPX_LAUNCH_CHECK();
+    } else if (st < 3) {
       const size_t n8 = (size_t)B * (P.o1[st].C / 8) * h * w;
       hipLaunchKernelGGL(hs8_to_s2d_kernel, g1(n8), dim3(256), 0, s, reinterpret_cast<const HsRec*>(hsc(P.o1[st])),
                          ptr(P.o1s[st]), P.o1[st].C, h, w, n8);
