@@ -94,7 +94,7 @@ struct PolicyNet {
   // f16x3 MFMA kernel (conv_hs.hip); conv[] keeps their fp32 packing only for the stride-2 launches and the stem
   ConvLayerHsDev conv_hs[12];
   const float* bias_hs[12] = {};
-  // stage entries of stages 1..3 (stride 2) on the sparse-tap half-split instances over the HS8 space-to-depth input:
+  // stage entries (stride 2) on the sparse-tap half-split instances over the HS8 space-to-depth input:
   // [st][0] = conv1 as a 2x2-window convolution (tap mask 0x01B), [st][1] = the 1x1 shortcut (0x010, first Cin channels)
   ConvLayerHsDev s2_hs[4][2];
   const float* s2_bias[4][2] = {};
@@ -139,7 +139,7 @@ struct pnpx_ctx {
   int opt_fuse_first = 1;          // VALU first convolution straight from the fp32 image (no padded-input tensor)
   int opt_fuse_up = 0;             // opt-in: bilinear x2 of the full-resolution decoder entry inside the conv kernel
                                    // (producer waves; +1.7 % iterations/s)
-  int opt_policy_s2_hs = 1;        // policy actor: stride-2 stage entries 1..3 on the sparse-tap half-split instances
+  int opt_policy_s2_hs = 1;        // policy actor: the stride-2 stage entries on the sparse-tap half-split instances
   int opt_fold_first = 0;          // opt-in: first convolution folded into the loader of the second one (conv_hs WREG == 2;
                                    // bit-identical, 400 MB less HBM traffic per forward, time-neutral: 5.835 vs 5.841 ms)
   int opt_fft_tile = 0;            // complex points per FFT workgroup tile (0 = FFT_TILE_POINTS)

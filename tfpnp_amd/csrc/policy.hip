@@ -68,6 +68,26 @@ __global__ __launch_bounds__(256) void hs8_to_s2d_kernel(const HsRec* __restrict
   for (int k = 0; k < 8; ++k) o[(size_t)k * Hp2 * Wp2] = v[k] * (1.f / HS_ASCALE);
 }
 
+// fp32 planar [B][C][h+2][pol_wp(w)] -> half-split HS8 [B][C/8][h+2][w+2] (the stem's space-to-depth output for the stage-0
+// entry on the half-split instances)
+__global__ __launch_bounds__(256) void planar_to_hs8_kernel(const float* __restrict__ src, HsRec* __restrict__ dst, int C,
+                                                            int h, int w, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % w);
+  size_t t = i / w;
+  const int y = (int)(t % h);
+  t /= h;
+  const int g = (int)(t % (C >> 3));
+  const size_t b = t / (C >> 3);
+  const int Hp = padded_h(h), Wp = pol_wp(w);
+  const float* p = src + ((b * C + (size_t)g * 8) * Hp + (y + 1)) * Wp + x + POL_PADL;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = p[(size_t)k * Hp * Wp] * HS_ASCALE;
+  dst[((b * (C >> 3) + g) * (h + 2) + (y + 1)) * (size_t)(w + 2) + (x + 1)] = hs_pack(v);
+}
+
 __global__ __launch_bounds__(256) void pool_heads_kernel(const HsRec* __restrict__ feat, int h, int w,
                                                          const float* __restrict__ sm_w, const float* __restrict__ sm_b,
                                                          const float* __restrict__ d_w, const float* __restrict__ d_b,
@@ -253,6 +273,7 @@ struct PolAct {
 };
 struct PolicyPlan {
   PolAct ob, stem;               // fp32, space-to-depth
+  PolAct stem_hs;                // HS8 copy of `stem` (stage-0 entry on the half-split instances)
   PolAct t1[4], sc[4], o0[4], t2[4], o1[4];   // half-split HS8 (same 4 bytes per value)
   PolAct o1s[3];                 // fp32 space-to-depth copy of o1 for the next stage's stride-2 convolution
   size_t total = 0;              // floats for capB observations
@@ -278,6 +299,7 @@ PolicyPlan make_policy_plan(int capB, int cin_pad, int H, int W) {
   };
   add(P.ob, 4 * cin_pad, H / 2, W / 2);
   add(P.stem, 4 * 64, H / 4, W / 4);
+  add_hs(P.stem_hs, 4 * 64, H / 4, W / 4);
   for (int n = 0; n < 4; ++n) {
     const int p = stage_planes(n), h = H >> (n + 2), w = W >> (n + 2);
     add_hs(P.t1[n], p, h, w);
@@ -386,7 +408,7 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
       put_shortcut(E, p, ws, bs, p, in_planes);
       finish(E, p);
     }
-    if (s >= 1) {   // the same two convolutions packed for the sparse-tap half-split instances (stages 1..3)
+    {   // the same two convolutions packed for the sparse-tap half-split instances
       Eff E1(p, 4 * in_planes), Es(p, in_planes);
       put_conv_s2(E1, 0, w1, b1, p, in_planes, in_planes);
       put_shortcut(Es, 0, ws, bs, p, in_planes);
@@ -463,7 +485,7 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
     N.conv_hs[i].inv_scale = 1.0f / (hs_scale[i] * HS_ASCALE);
     N.bias_hs[i] = base + hs_b[i];
   }
-  for (int st = 1; st < 4; ++st)
+  for (int st = 0; st < 4; ++st)
     for (int k = 0; k < 2; ++k) {
       N.s2_hs[st][k].cin = N.s2_hs[st][k].cin_pad = s2_K[st][k];
       N.s2_hs[st][k].cout = s2_c[st][k];
@@ -548,9 +570,16 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
   const float* xin = ptr(P.stem);
   for (int st = 0; st < 4; ++st) {
     const int h = H >> (st + 2), w = W >> (st + 2);
-    if (st == 0 || !ctx->opt_policy_s2_hs) {
+    if (!ctx->opt_policy_s2_hs) {
       PNPX_TRY(launch_policy_conv(N.conv[1 + 4 * st], xin, ptr(P.t1[st]), ptr(P.sc[st]), nullptr, false, B, h, w, s, true));
     } else {
+      const PolAct& s2in = st == 0 ? P.stem_hs : P.o1s[st - 1];
+      if (st == 0) {
+        const size_t n0 = (size_t)B * (P.stem.C / 8) * h * w;
+        hipLaunchKernelGGL(planar_to_hs8_kernel, g1(n0), dim3(256), 0, s, ptr(P.stem), reinterpret_cast<HsRec*>(hsc(P.stem_hs)),
+                           P.stem.C, h, w, n0);
+        PNPX_LAUNCH_CHECK();
+      }
       // stride-2 entry on the sparse-tap half-split instances: conv1 = 2x2-window convolution over the HS8 space-to-depth
       // input (taps 0x01B, ReLU), shortcut = 1x1 over its first Cin channels (tap 0x010, linear)
       for (int k = 0; k < 2; ++k) {
@@ -566,10 +595,10 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
         ConvHsFuse f;
         f.slope = k == 0 ? 0.f : 1.f;
         f.taps = k == 0 ? 0x01B : 0x010;
-        f.in0_groups = P.o1s[st - 1].C / 8;
+        f.in0_groups = s2in.C / 8;
         f.wreg = 0;
         f.range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
-        PNPX_TRY(launch_conv_hs(Lh, hsc(P.o1s[st - 1]), D.cin_pad / 8, nullptr, 0, hsc(k == 0 ? P.t1[st] : P.sc[st]), B, h, w, f, s));
+        PNPX_TRY(launch_conv_hs(Lh, hsc(s2in), D.cin_pad / 8, nullptr, 0, hsc(k == 0 ? P.t1[st] : P.sc[st]), B, h, w, f, s));
       }
     }
     PNPX_TRY(conv_hs(3 * st + 0, P.t1[st], P.o0[st], &P.sc[st], h, w));
