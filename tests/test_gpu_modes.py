@@ -288,3 +288,43 @@ def test_fold_first_option_is_bit_identical(unet_params):
             assert torch.equal(den.forward_preclamp(x, s)[1], ref), (B, H, W)
     finally:
         ctx.set_option("fold_first", 0)
+
+
+def test_round3_execution_options_are_bit_identical(unet_params):
+    """wreg (weights-in-registers instances), chains (independent launch chains over slices of the batch), fft_affine /
+    fft_tile (FFT pass mapping and tile size) only change HOW the work is scheduled: outputs must not move by a bit."""
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
+    den = UNetDenoiser2D(state_dict=unet_params)
+    ctx = den.context(dev())
+    defaults = {k: ctx.get_option(k) for k in ("wreg", "chains", "fft_affine", "fft_tile")}
+    try:
+        for (B, H, W) in [(24, 256, 256), (7, 128, 160), (6, 256, 256)]:
+            x, s = denoiser_inputs(B, H, W, 91)
+            x, s = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
+            ref = None
+            for wreg in (2, 0, 1):
+                for chains in (1, 2, 3):
+                    ctx.set_option("wreg", wreg)
+                    ctx.set_option("chains", chains)
+                    pre = den.forward_preclamp(x, s)[1]
+                    ref = pre.clone() if ref is None else ref
+                    assert torch.equal(pre, ref), (B, H, W, wreg, chains)
+        ctx.set_option("wreg", defaults["wreg"])
+        ctx.set_option("chains", defaults["chains"])
+        d = synth.make_csmri_batch(9, 256, 256, ratio=4, seed=17)      # 9 images: one full XCD group + a plain-mapped image
+        g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+        a = synth.make_actions(9)[0]
+        sol = ADMMSolver_CSMRI(den)
+        v0 = sol.reset({"x0": g(d["x0"])})
+        ref = None
+        for aff in (1, 0):
+            for tile in (0, 512, 2048, 4096):
+                ctx.set_option("fft_affine", aff)
+                ctx.set_option("fft_tile", tile)
+                out = sol((v0, (g(d["y0"]), g(d["mask"]))), (g(a["sigma_d"]), g(a["mu"])))
+                ref = out.clone() if ref is None else ref
+                assert torch.equal(out, ref), (aff, tile)
+    finally:
+        for k, v in defaults.items():
+            ctx.set_option(k, v)

@@ -270,6 +270,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fold_first")) *value = ctx->opt_fold_first;
   else if (is("policy_s2_hs")) *value = ctx->opt_policy_s2_hs;
   else if (is("fft_affine")) *value = ctx->opt_fft_affine;
+  else if (is("fft_tile")) *value = ctx->opt_fft_tile;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
   else if (is("train_cache_gb")) *value = ctx->opt_train_cache_gb;
   else {
