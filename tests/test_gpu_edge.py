@@ -317,13 +317,16 @@ def test_two_devices_in_one_process(unet_params):
     assert torch.equal(out[0], out[1])
 
 
-def test_solver_call_is_hipgraph_capturable(den):
+@pytest.mark.parametrize("chains", [1, 2])
+def test_solver_call_is_hipgraph_capturable(den, chains):
     """One solver call (all inner iterations: denoiser launches, fused FFT passes, range-guard bookkeeping) records
     into a hipGraph (torch.cuda.graph) once its workspaces exist, and a replay reproduces the eager result bit for bit --
     i.e. the native path issues nothing but stream-ordered work (no hidden allocation, host read-back or default-stream
     operation) in steady state.  (Replay is not faster: the path is GPU-bound down to B=1, tools/graph_capture.py.)"""
     from tfpnp_amd.tasks import csmri
     sol = csmri.ADMMSolver_CSMRI(den)
+    # chains = 2: the denoiser forward forks onto a side stream and joins back (fork / join events are capturable)
+    den.context(dev()).set_option("chains", chains)
     B, H, W, T = 3, 64, 64, 4
     d = synth.make_csmri_batch(B, H, W, seed=311)
     a = csmri_actions(B, T, 312, ("sigma_d", "mu"))
@@ -348,6 +351,7 @@ def test_solver_call_is_hipgraph_capturable(den):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, sol((v0, (y0, m)), (sg, mu)))
+    den.context(dev()).set_option("chains", 0)
     den.context(dev()).status()
 
 
