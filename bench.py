@@ -338,7 +338,8 @@ def roofline(den, dev, B, H, W, reps=3):
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12
     return {
         "bound": "mfma",
-        "kernel": "conv_hs_kernel (27 launches per denoiser forward; half-split f16 MFMA, 3 MFMAs per fp32 product)",
+        "kernel": "conv_hs_kernel: the 27 3x3 convolutions of one denoiser forward (half-split f16 MFMA, 3 MFMAs per fp32 "
+                  "product; 33 launches at B=48 with two level-0 sub-batches, the K=18 first layer on the vector ALU included)",
         "achieved": achieved,
         "peak": PEAK_HS_TFLOPS,
         "unit": "TFLOP/s",
