@@ -231,6 +231,16 @@ int pnpx_csmri_admm_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask
 int pnpx_csmri_hqs(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                    const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
                    int H, int W, int T, void* stream);
+/* Training path of HQSSolver_CSMRI.forward, same contract as pnpx_csmri_admm_train / _backward above with vars
+ * [B,2,H,W,2]: `saved` = 3*T*B*H*W floats (denoiser inputs, then the k-space images before the blend), activations parked
+ * under *ticket + i; the backward returns grad_vars_in [B,2,H,W,2], grad_sigma_d and grad_mu [T][B], work = 3*B*H*W floats. */
+int pnpx_csmri_hqs_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                         const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
+                         int H, int W, int T, float* saved, unsigned long long* ticket, void* stream);
+int pnpx_csmri_hqs_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, const float* sigma_d,
+                            const float* mu, int param_stride, const float* saved, const float* grad_vars_out,
+                            float* grad_vars_in, float* grad_sigma_d, float* grad_mu, float* work, int B, int H,
+                            int W, int T, unsigned long long ticket, void* stream);
 /* PGSolver_CSMRI.forward (tasks/csmri/solver.py:96-120).  vars [B,1,H,W,2] = x. */
 int pnpx_csmri_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                   const uint8_t* mask, const float* sigma_d, const float* tau, int param_stride, int B,

@@ -279,6 +279,42 @@ def test_csmri_admm_fused_vjp_vs_composed_autograd(den):
     assert all(torch.equal(x, y) for x, y in zip(gf, gf2))   # deterministic reductions
 
 
+def test_csmri_hqs_fused_vjp_vs_composed_autograd(den):
+    """HQSSolver_CSMRI under autograd runs ONE native call each way as well (pnpx_csmri_hqs_train / _backward): same
+    checks as for ADMM against the composed path (HQSSolver_CSMRI._forward_autograd)."""
+    from tfpnp_amd.tasks import csmri
+    sol = csmri.HQSSolver_CSMRI(den)
+    B, H, W, T = 3, 48, 64, 3
+    d = synth.make_csmri_batch(B, H, W, seed=171)
+    a = csmri_actions(B, 5, 172, ("sigma_d", "mu"))
+    v0 = sol.reset({"x0": g(d["x0"])})
+    v0 = v0 + 0.05 * torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(3))
+    wts = torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(4))
+    y0, m = g(d["y0"]), g(d["mask"])
+
+    def grads(fn):
+        leaves = [v0.clone().requires_grad_(True), g(a["sigma_d"], True), g(a["mu"], True)]
+        out = fn(*leaves)
+        (out * wts).sum().backward()
+        return out.detach(), [l.grad for l in leaves]
+
+    out_f, gf = grads(lambda v, s_, mu: sol((v, (y0, m)), (s_, mu), iter_num=T))
+    out_c, gc = grads(lambda v, s_, mu: sol._forward_autograd(v, y0, m, s_, mu, T))
+    with torch.no_grad():
+        assert rel(out_f, sol((v0, (y0, m)), (g(a["sigma_d"]), g(a["mu"])), iter_num=T)) < 1e-6
+    assert rel(out_f, out_c) < 1e-5
+    for n, x, y in zip(("variables", "sigma_d", "mu"), gf, gc):
+        print(f"  HQS fused vs composed d/d{n}: {rel(x, y):.2e}")
+        assert rel(x, y) < 2e-2 and x.shape == y.shape, n
+    assert float(gf[0][:, 0].abs().max()) == 0.0             # x of the incoming state is never read by an iteration
+    assert float(gf[1][:, T:].abs().max()) == 0.0 and float(gf[2][:, T:].abs().max()) == 0.0
+    assert float(gf[1][:, :T].abs().min()) > 0 and float(gf[2][:, :T].abs().min()) > 0
+    _, gf2 = grads(lambda v, s_, mu: sol((v, (y0, m)), (s_, mu), iter_num=T))
+    assert all(torch.equal(x, y) for x, y in zip(gf, gf2))   # deterministic reductions
+    out0 = sol((v0.clone().requires_grad_(True), (y0, m)), (g(a["sigma_d"], True), g(a["mu"], True)), iter_num=0)
+    assert torch.equal(out0, v0)
+
+
 def test_csmri_admm_train_degenerate_calls(den):
     """iter_num = 0 (identity: gradient passes straight through, hyper-parameters get zeros) and an empty batch."""
     from tfpnp_amd.tasks import csmri

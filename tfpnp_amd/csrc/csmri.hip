@@ -156,6 +156,12 @@ struct StoreAdmmAdjoint {
     gu.at(b, y, x) = make_float2(a.x + gs.x, a.y + gs.y);
   }
 };
+// Backward of one HQS iteration after the data step's adjoint gs: cotangent of the denoiser output xr = Re(gx' + gs)
+struct StoreHqsAdjoint {
+  CSlot gx;
+  RealImg gxr;
+  __device__ void operator()(int b, int y, int x, float2 gs) const { gxr.at(b, y, x) = gx.at(b, y, x).x + gs.x; }
+};
 struct StoreAdmmCx {  // same with a complex x held in a slot (RED-ADMM); no denoiser input emitted
   Slot z, uo;
   CSlot ui, xc;
@@ -250,6 +256,15 @@ __global__ void admm_adjoint_finish_kernel(const float* __restrict__ gd, float2*
   gi[0] = make_float2(0.f, 0.f);
   gi[HW] = make_float2(v, 0.f);
   gi[2 * (size_t)HW] = make_float2(gu.x - v, gu.y);
+}
+// HQS: backward of d = Re(z): gz = r2c(gd); x of the previous state is not read by an iteration: gx = 0
+__global__ void hqs_adjoint_finish_kernel(const float* __restrict__ gd, float2* g, size_t istride, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  float2* gi = g + b * istride + r;
+  gi[0] = make_float2(0.f, 0.f);
+  gi[HW] = make_float2(gd[i], 0.f);
 }
 // out[b] = sum of the HW values of item b, fixed summation order (deterministic)
 __global__ void __launch_bounds__(256) item_sum_kernel(const float* __restrict__ c, float* __restrict__ out, int HW) {
@@ -438,13 +453,14 @@ extern "C" int pnpx_csmri_admm_backward(pnpx_ctx* ctx, const float* y0, const ui
   });
 }
 
-extern "C" int pnpx_csmri_hqs(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
-                              const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
-                              int H, int W, int T, void* stream) {
-  LOCK_CTX(ctx);
-  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+// HQS forward; `saved` != NULL (training path): as admm_forward -- per iteration the denoiser input d_i [T][B][HW] and the
+// k-space image before the blend [T][B][HW] complex are kept, activations parked in the training ring (ticket + i).
+static int hqs_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const uint8_t* mask,
+                       const float* sigma_d, const float* mu, int param_stride, int B, int H, int W, int T, float* saved,
+                       hipStream_t s, unsigned long long* ticket_out = nullptr) {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ticket_out) *ticket_out = 0;
+  const bool park = saved && ticket_out;
   const int HW = H * W;
   const size_t is = 2 * (size_t)HW;
   Scratch S;
@@ -465,13 +481,97 @@ extern "C" int pnpx_csmri_hqs(pnpx_ctx* ctx, const float* vars_in, float* vars_o
   StoreC kst{S.k, H, W};
   LoadC kld{S.k, H, W};
   for (int i = 0; i < T; ++i) {
-    PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    if (saved)
+      PNPX_HIP(hipMemcpyAsync(saved + (size_t)i * B * HW, S.d, sizeof(float) * B * HW, hipMemcpyDeviceToDevice, s));
+    if (park) {
+      unsigned long long tk = 0;
+      PNPX_TRY(unet_denoise_train(ctx, S.d, sigma_d + i, param_stride, S.xr, B, H, W, s, &tk));
+      if (i == 0) *ticket_out = tk;
+    } else {
+      PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    }
     PNPX_TRY((launch_rows<false>(P, LoadXr{xr}, kst, s)));
     KSpace ks{reinterpret_cast<const float2*>(y0), mask, mu + i, param_stride, W, HW};
-    PNPX_TRY((launch_cols<false, true>(P, kld, MidBlend{ks}, kst, s)));
+    if (saved) {
+      float2* ksave = reinterpret_cast<float2*>(saved + (size_t)T * B * HW) + (size_t)i * B * HW;
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidBlendSave{ks, ksave}, kst, s)));
+    } else {
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidBlend{ks}, kst, s)));
+    }
     PNPX_TRY((launch_rows<true>(P, kld, StoreHqs{zo, xo, xr, d, i == T - 1}, s)));
   }
   return PNPX_OK;
+}
+
+extern "C" int pnpx_csmri_hqs(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                              const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
+                              int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return hqs_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, mu, param_stride, B, H, W, T, nullptr, s);
+  });
+}
+
+extern "C" int pnpx_csmri_hqs_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                                    const uint8_t* mask, const float* sigma_d, const float* mu, int param_stride, int B,
+                                    int H, int W, int T, float* saved, unsigned long long* ticket, void* stream) {
+  LOCK_CTX(ctx);
+  if ((!saved && T > 0) || !ticket) {
+    pnpx::set_error("csmri_hqs_train: saved / ticket is null");
+    return PNPX_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return hqs_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, mu, param_stride, B, H, W, T, saved, s, ticket);
+  });
+}
+
+// VJP of the T-iteration HQS map wrt (variables, sigma_d, mu), iterations walked in reverse:
+//   forward i:   x = r2c(D(d_i, sigma_i)),  d_i = Re(z);   z' = F^-1 blend_mu_i(F(x))
+//   backward i:  gs = F^-1 blend^T(F gz');  g_mu_i = sum contrib;  gxr = Re(gx' + gs);  (gd, g_sigma_i) = D^T(gxr);
+//                gz = r2c(gd), gx = 0
+extern "C" int pnpx_csmri_hqs_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, const float* sigma_d,
+                                       const float* mu, int param_stride, const float* saved,
+                                       const float* grad_vars_out, float* grad_vars_in, float* grad_sigma_d,
+                                       float* grad_mu, float* work, int B, int H, int W, int T,
+                                       unsigned long long ticket, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    PNPX_TRY(check_common(grad_vars_out, grad_vars_in, y0, mask, sigma_d, B, H, W, T, param_stride));
+    if (T > 0 && (!saved || !grad_sigma_d || !grad_mu || !work || !mu)) {
+      set_error("csmri_hqs_backward: null pointer");
+      return PNPX_ERR_ARG;
+    }
+    const int HW = H * W;
+    const size_t is = 2 * (size_t)HW, n = (size_t)B * HW;
+    PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+    if (T == 0) return PNPX_OK;
+    FftPlan2D P;
+    PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
+    float2* g = reinterpret_cast<float2*>(grad_vars_in);
+    float *gxr = work, *gd = work + n, *contrib = work + 2 * n;
+    const float* saved_d = saved;
+    const float2* saved_k = reinterpret_cast<const float2*>(saved + (size_t)T * n);
+    for (int i = T - 1; i >= 0; --i) {
+      Scratch S;
+      PNPX_TRY(get_scratch(ctx, B, H, W, &S));
+      StoreC kst{S.k, H, W};
+      LoadC kld{S.k, H, W};
+      CSlot gx{g, is, W, HW}, gz{g + HW, is, W, HW};
+      PNPX_TRY((launch_rows<false>(P, LoadSlot{gz}, kst, s)));
+      KSpace ks{reinterpret_cast<const float2*>(y0), mask, mu + i, param_stride, W, HW};
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidBlendAdjoint{ks, saved_k + (size_t)i * n, contrib}, kst, s)));
+      PNPX_TRY((launch_rows<true>(P, kld, StoreHqsAdjoint{gx, RealImg{gxr, W, HW}}, s)));
+      hipLaunchKernelGGL(item_sum_kernel, dim3(B), dim3(256), 0, s, contrib, grad_mu + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(unet_denoise_backward_ticket(ctx, saved_d + (size_t)i * n, sigma_d + i, param_stride, gxr, gd,
+                                            grad_sigma_d + (size_t)i * B, B, H, W, s, ticket ? ticket + i : 0));
+      hipLaunchKernelGGL(hqs_adjoint_finish_kernel, g1(n), dim3(256), 0, s, gd, g, is, HW, B);
+      PNPX_LAUNCH_CHECK();
+    }
+    return PNPX_OK;
   });
 }
 

@@ -396,10 +396,10 @@ def csmri_admm(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
     return _csmri_common("pnpx_csmri_admm", 3, ctx, variables, y0, mask, (sigma_d, mu), iter_num)
 
 
-def csmri_admm_train(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
+def csmri_admm_train(ctx, variables, y0, mask, sigma_d, mu, iter_num=None, _entry="pnpx_csmri_admm_train", _nvar=3):
     """pnpx_csmri_admm_train: the ADMM forward that also returns what its VJP needs -> (next state, saved [3*T*B*H*W],
     ticket of the context's activation cache (int, 0 = not cached))."""
-    v = _vars(variables, 3, True)
+    v = _vars(variables, _nvar, True)
     B, _, H, W, _ = v.shape
     y0, m = _f32(y0, "y0"), _mask_u8(mask)
     if y0.numel() != B * H * W * 2 or m.numel() != B * H * W:
@@ -415,14 +415,25 @@ def csmri_admm_train(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
         return out, saved, 0
     ticket = C.c_ulonglong(0)
     with torch.cuda.device(v.device):
-        check(_lib.lib().pnpx_csmri_admm_train(ctx.handle, _p(v), _p(out), _p(y0), _p(m), _p(ps[0]), _p(ps[1]),
-                                               ps[0].shape[1], B, H, W, T, _p(saved), C.byref(ticket), _stream(v)))
+        check(getattr(_lib.lib(), _entry)(ctx.handle, _p(v), _p(out), _p(y0), _p(m), _p(ps[0]), _p(ps[1]),
+                                          ps[0].shape[1], B, H, W, T, _p(saved), C.byref(ticket), _stream(v)))
     return out, saved, int(ticket.value)
 
 
-def csmri_admm_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num=None, ticket=0):
+def csmri_hqs_train(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
+    """pnpx_csmri_hqs_train: HQSSolver_CSMRI.forward for autograd (state [B,2,H,W,2]); same returns as csmri_admm_train."""
+    return csmri_admm_train(ctx, variables, y0, mask, sigma_d, mu, iter_num, "pnpx_csmri_hqs_train", 2)
+
+
+def csmri_hqs_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num=None, ticket=0):
+    """pnpx_csmri_hqs_backward -> (grad variables [B,2,H,W,2], grad sigma_d [B,T], grad mu [B,T])."""
+    return csmri_admm_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num, ticket, "pnpx_csmri_hqs_backward", 2)
+
+
+def csmri_admm_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num=None, ticket=0,
+                        _entry="pnpx_csmri_admm_backward", _nvar=3):
     """pnpx_csmri_admm_backward -> (grad variables [B,3,H,W,2], grad sigma_d [B,T], grad mu [B,T])."""
-    g = _vars(grad_out, 3, True)
+    g = _vars(grad_out, _nvar, True)
     B, _, H, W, _ = g.shape
     y0, m = _f32(y0, "y0"), _mask_u8(mask)
     ps, T = _params(B, sigma_d, mu)
@@ -435,9 +446,9 @@ def csmri_admm_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num=No
     if B and T:
         work = torch.empty(3 * B * H * W, dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            check(_lib.lib().pnpx_csmri_admm_backward(ctx.handle, _p(y0), _p(m), _p(ps[0]), _p(ps[1]), ps[0].shape[1],
-                                                      _p(saved), _p(g), _p(gin), _p(gs), _p(gm), _p(work), B, H, W, T,
-                                                      int(ticket), _stream(g)))
+            check(getattr(_lib.lib(), _entry)(ctx.handle, _p(y0), _p(m), _p(ps[0]), _p(ps[1]), ps[0].shape[1],
+                                              _p(saved), _p(g), _p(gin), _p(gs), _p(gm), _p(work), B, H, W, T,
+                                              int(ticket), _stream(g)))
     elif B:
         gin.copy_(g)
     return gin, gs.t().contiguous(), gm.t().contiguous()

@@ -62,14 +62,21 @@ class HQSSolver_CSMRI(CSMRIMixin, HQSSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, mask) = inputs
         sigma_d, mu = parameters
-        if A.needs_grad(variables, sigma_d, mu):
-            x, z = torch.split(variables, variables.shape[1] // 2, dim=1)
-            B, m = x.shape[0], (mask != 0).unsqueeze(-1)
-            for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):      # tasks/csmri/solver.py:76-85
-                x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
-                z = A.fft2(_blend(A.fft2(x), y0, m, _v5(mu[:, i], B)), inverse=True)
-            return torch.cat([x, z], dim=1)
+        if A.needs_grad(variables, sigma_d, mu):      # training path: native forward + fused native VJP (csmri.hip)
+            return T.call("csmri_hqs_train", variables, y0, mask, sigma_d, mu, -1 if iter_num is None else iter_num,
+                          self._ctx(variables).cid)[0]
         return T.call("csmri_hqs", variables, y0, mask, sigma_d, mu, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
+
+
+    def _forward_autograd(self, variables, y0, mask, sigma_d, mu, iter_num):
+        """The reference's loop (tasks/csmri/solver.py:76-85) from differentiable building blocks: what the fused native VJP
+        (pnpx_csmri_hqs_backward) is tested against."""
+        x, z = torch.split(variables, variables.shape[1] // 2, dim=1)
+        B, m = x.shape[0], (mask != 0).unsqueeze(-1)
+        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
+            x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
+            z = A.fft2(_blend(A.fft2(x), y0, m, _v5(mu[:, i], B)), inverse=True)
+        return torch.cat([x, z], dim=1)
 
 
 class PGSolver_CSMRI(CSMRIMixin, PGSolver):
