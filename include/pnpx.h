@@ -245,6 +245,15 @@ int pnpx_csmri_hqs_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask,
 int pnpx_csmri_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                   const uint8_t* mask, const float* sigma_d, const float* tau, int param_stride, int B,
                   int H, int W, int T, void* stream);
+/* Training path of PGSolver_CSMRI.forward (same contract; vars [B,1,H,W,2]): `saved` = 2*T*B*H*W floats (the denoiser inputs,
+ * then the real parts of the masked-residual images ifft2c(mask * (fft2c(x_i) - y0))); grads wrt (x, sigma_d, tau). */
+int pnpx_csmri_pg_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                        const uint8_t* mask, const float* sigma_d, const float* tau, int param_stride, int B,
+                        int H, int W, int T, float* saved, unsigned long long* ticket, void* stream);
+int pnpx_csmri_pg_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, const float* sigma_d,
+                           const float* tau, int param_stride, const float* saved, const float* grad_vars_out,
+                           float* grad_vars_in, float* grad_sigma_d, float* grad_tau, float* work, int B, int H,
+                           int W, int T, unsigned long long ticket, void* stream);
 /* APGSolver_CSMRI.forward (tasks/csmri/solver.py:127-165).  vars [B,2,H,W,2] = cat(x,s). */
 int pnpx_csmri_apg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                    const uint8_t* mask, const float* sigma_d, const float* tau, const float* beta,

@@ -315,6 +315,39 @@ def test_csmri_hqs_fused_vjp_vs_composed_autograd(den):
     assert torch.equal(out0, v0)
 
 
+def test_csmri_pg_fused_vjp_vs_composed_autograd(den):
+    """PGSolver_CSMRI under autograd: pnpx_csmri_pg_train / _backward (one native call each way) against the composed path,
+    incl. the complex first iterate (x0 = ATy0 has an imaginary part; later iterates are real)."""
+    from tfpnp_amd.tasks import csmri
+    sol = csmri.PGSolver_CSMRI(den)
+    B, H, W, T = 3, 64, 48, 3
+    d = synth.make_csmri_batch(B, H, W, seed=173)
+    a = csmri_actions(B, 4, 174, ("sigma_d", "tau"))
+    v0 = sol.reset({"x0": g(d["x0"])})
+    v0 = v0 + 0.05 * torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(3))
+    wts = torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(4))
+    y0, m = g(d["y0"]), g(d["mask"])
+
+    def grads(fn):
+        leaves = [v0.clone().requires_grad_(True), g(a["sigma_d"], True), g(a["tau"], True)]
+        out = fn(*leaves)
+        (out * wts).sum().backward()
+        return out.detach(), [l.grad for l in leaves]
+
+    out_f, gf = grads(lambda v, s_, t_: sol((v, (y0, m)), (s_, t_), iter_num=T))
+    out_c, gc = grads(lambda v, s_, t_: sol._forward_autograd(v, y0, m, s_, t_, T))
+    with torch.no_grad():
+        assert rel(out_f, sol((v0, (y0, m)), (g(a["sigma_d"]), g(a["tau"])), iter_num=T)) < 1e-6
+    assert rel(out_f, out_c) < 1e-5
+    for n, x, y in zip(("x", "sigma_d", "tau"), gf, gc):
+        print(f"  PG fused vs composed d/d{n}: {rel(x, y):.2e}")
+        assert rel(x, y) < 2e-2 and x.shape == y.shape, n
+    assert float(gf[0][..., 1].abs().max()) > 0              # the complex first iterate receives an imaginary cotangent
+    assert float(gf[1][:, T:].abs().max()) == 0.0 and float(gf[2][:, T:].abs().max()) == 0.0
+    _, gf2 = grads(lambda v, s_, t_: sol((v, (y0, m)), (s_, t_), iter_num=T))
+    assert all(torch.equal(x, y) for x, y in zip(gf, gf2))
+
+
 def test_csmri_admm_train_degenerate_calls(den):
     """iter_num = 0 (identity: gradient passes straight through, hyper-parameters get zeros) and an empty batch."""
     from tfpnp_amd.tasks import csmri

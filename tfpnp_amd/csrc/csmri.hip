@@ -188,9 +188,36 @@ struct StoreGrad {  // d = Re(base - tau * g)                             tasks/
   const float* tau;
   int stride;
   RealImg d;
+  float* gsave = nullptr;   // training path: keeps Re(g) [B][HW] (d d / d tau = -Re(g))
   __device__ void operator()(int b, int y, int x, float2 g) const {
     const float bx = use_real ? base_r.at(b, y, x) : base.at(b, y, x).x;
     d.at(b, y, x) = subr(bx, mulr(tau[(size_t)b * stride], g.x));
+    if (gsave) gsave[(size_t)b * d.HW + (size_t)y * d.W + x] = g.x;
+  }
+};
+struct MidMask {  // k[~mask] = 0 (adjoint / Jacobian of the masked residual wrt its k-space input)
+  KSpace k;
+  __device__ float2 operator()(int b, int ky, int kx, float2 v) const {
+    return k.mask[(size_t)b * k.HW + (size_t)ky * k.W + kx] ? v : make_float2(0.f, 0.f);
+  }
+};
+// PG backward, inverse row pass: with r = F^-1 M F r2c(gd):  cotangent of x_i = r2c(gd) - tau * r; also the per-pixel term of
+// d/d tau = -<gd, Re(w_i)> (w_i = the forward's masked-residual image, saved).  Iterations > 0 only need the real part.
+struct StorePgAdjoint {
+  const float* gd;      // [B][HW]
+  const float* wre;     // [B][HW] saved Re(w_i)
+  const float* tau;
+  int stride;
+  RealImg gxr;          // next cotangent of the denoiser output (real) ...
+  Slot gx;              // ... or the complex input cotangent (first iteration)
+  int first;
+  float* contrib;       // [B][HW]
+  __device__ void operator()(int b, int y, int x, float2 r) const {
+    const size_t o = (size_t)b * gxr.HW + (size_t)y * gxr.W + x;
+    const float t = tau[(size_t)b * stride], v = gd[o];
+    contrib[o] = -v * wre[o];
+    if (first) gx.at(b, y, x) = make_float2(v - t * r.x, -t * r.y);
+    else gxr.at(b, y, x) = v - t * r.x;
   }
 };
 
@@ -575,13 +602,14 @@ extern "C" int pnpx_csmri_hqs_backward(pnpx_ctx* ctx, const float* y0, const uin
   });
 }
 
-extern "C" int pnpx_csmri_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
-                             const uint8_t* mask, const float* sigma_d, const float* tau, int param_stride, int B,
-                             int H, int W, int T, void* stream) {
-  LOCK_CTX(ctx);
-  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+// PG forward; `saved` != NULL (training path): per iteration the denoiser input d_i [T][B][HW] followed by Re(w_i)
+// [T][B][HW] (w_i = ifft2c(mask * (fft2c(x_i) - y0))), activations parked in the training ring (ticket + i).
+static int pg_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const uint8_t* mask,
+                      const float* sigma_d, const float* tau, int param_stride, int B, int H, int W, int T, float* saved,
+                      hipStream_t s, unsigned long long* ticket_out = nullptr) {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ticket_out) *ticket_out = 0;
+  const bool park = saved && ticket_out;
   const int HW = H * W;
   const size_t is = (size_t)HW;
   Scratch S;
@@ -604,12 +632,95 @@ extern "C" int pnpx_csmri_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_ou
     else PNPX_TRY((launch_rows<false>(P, LoadXr{xr}, kst, s)));
     KSpace ks{reinterpret_cast<const float2*>(y0), mask, tau + i, param_stride, W, HW};
     PNPX_TRY((launch_cols<false, true>(P, kld, MidResidual{ks}, kst, s)));
-    PNPX_TRY((launch_rows<true>(P, kld, StoreGrad{x0, xr, i != 0, tau + i, param_stride, d}, s)));
-    PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    float* wsave = saved ? saved + ((size_t)T + i) * B * HW : nullptr;
+    PNPX_TRY((launch_rows<true>(P, kld, StoreGrad{x0, xr, i != 0, tau + i, param_stride, d, wsave}, s)));
+    if (saved)
+      PNPX_HIP(hipMemcpyAsync(saved + (size_t)i * B * HW, S.d, sizeof(float) * B * HW, hipMemcpyDeviceToDevice, s));
+    if (park) {
+      unsigned long long tk = 0;
+      PNPX_TRY(unet_denoise_train(ctx, S.d, sigma_d + i, param_stride, S.xr, B, H, W, s, &tk));
+      if (i == 0) *ticket_out = tk;
+    } else {
+      PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    }
   }
   hipLaunchKernelGGL(real_to_slot_kernel, g1((size_t)HW * B), dim3(256), 0, s, S.xr, vout, is, HW, B);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
+}
+
+extern "C" int pnpx_csmri_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                             const uint8_t* mask, const float* sigma_d, const float* tau, int param_stride, int B,
+                             int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return pg_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, tau, param_stride, B, H, W, T, nullptr, s);
+  });
+}
+
+extern "C" int pnpx_csmri_pg_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                                   const uint8_t* mask, const float* sigma_d, const float* tau, int param_stride, int B,
+                                   int H, int W, int T, float* saved, unsigned long long* ticket, void* stream) {
+  LOCK_CTX(ctx);
+  if ((!saved && T > 0) || !ticket) {
+    pnpx::set_error("csmri_pg_train: saved / ticket is null");
+    return PNPX_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return pg_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, tau, param_stride, B, H, W, T, saved, s, ticket);
+  });
+}
+
+// VJP of the T-iteration PG map wrt (x, sigma_d, tau), iterations walked in reverse:
+//   forward i:   w = F^-1 M (F x - y0);  d_i = Re(x - tau_i w);  x' = r2c(D(d_i, sigma_i))
+//   backward i:  (gd, g_sigma_i) = D^T(Re gx');  g_tau_i = -<gd, Re w>;  gx = r2c(gd) - tau_i F^-1 M F r2c(gd)
+//                (F^-1 M F is self-adjoint: F unitary, M a real mask); iterations > 0 only pass Re(gx) on.
+extern "C" int pnpx_csmri_pg_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, const float* sigma_d,
+                                      const float* tau, int param_stride, const float* saved,
+                                      const float* grad_vars_out, float* grad_vars_in, float* grad_sigma_d,
+                                      float* grad_tau, float* work, int B, int H, int W, int T,
+                                      unsigned long long ticket, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    PNPX_TRY(check_common(grad_vars_out, grad_vars_in, y0, mask, sigma_d, B, H, W, T, param_stride));
+    if (T > 0 && (!saved || !grad_sigma_d || !grad_tau || !work || !tau)) {
+      set_error("csmri_pg_backward: null pointer");
+      return PNPX_ERR_ARG;
+    }
+    const int HW = H * W;
+    const size_t is = (size_t)HW, n = (size_t)B * HW;
+    if (T == 0) {
+      PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+      return PNPX_OK;
+    }
+    FftPlan2D P;
+    PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
+    float *gxr = work, *gd = work + n, *contrib = work + 2 * n;
+    // cotangent of the last denoiser output = Re(grad of x_T)
+    hipLaunchKernelGGL(real_of_diff_kernel, g1(n), dim3(256), 0, s, reinterpret_cast<const float2*>(grad_vars_out),
+                       (const float2*)nullptr, is, gxr, HW, B);
+    PNPX_LAUNCH_CHECK();
+    for (int i = T - 1; i >= 0; --i) {
+      PNPX_TRY(unet_denoise_backward_ticket(ctx, saved + (size_t)i * n, sigma_d + i, param_stride, gxr, gd,
+                                            grad_sigma_d + (size_t)i * B, B, H, W, s, ticket ? ticket + i : 0));
+      Scratch S;
+      PNPX_TRY(get_scratch(ctx, B, H, W, &S));
+      StoreC kst{S.k, H, W};
+      LoadC kld{S.k, H, W};
+      PNPX_TRY((launch_rows<false>(P, LoadXr{RealImg{gd, W, HW}}, kst, s)));
+      KSpace ks{reinterpret_cast<const float2*>(y0), mask, tau + i, param_stride, W, HW};
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidMask{ks}, kst, s)));
+      PNPX_TRY((launch_rows<true>(P, kld,
+                                  StorePgAdjoint{gd, saved + ((size_t)T + i) * n, tau + i, param_stride, RealImg{gxr, W, HW},
+                                                 Slot{reinterpret_cast<float2*>(grad_vars_in), is, W, HW}, i == 0, contrib},
+                                  s)));
+      hipLaunchKernelGGL(item_sum_kernel, dim3(B), dim3(256), 0, s, contrib, grad_tau + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+    }
+    return PNPX_OK;
   });
 }
 

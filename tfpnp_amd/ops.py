@@ -396,7 +396,8 @@ def csmri_admm(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
     return _csmri_common("pnpx_csmri_admm", 3, ctx, variables, y0, mask, (sigma_d, mu), iter_num)
 
 
-def csmri_admm_train(ctx, variables, y0, mask, sigma_d, mu, iter_num=None, _entry="pnpx_csmri_admm_train", _nvar=3):
+def csmri_admm_train(ctx, variables, y0, mask, sigma_d, mu, iter_num=None, _entry="pnpx_csmri_admm_train", _nvar=3,
+                     _saved_per=3):
     """pnpx_csmri_admm_train: the ADMM forward that also returns what its VJP needs -> (next state, saved [3*T*B*H*W],
     ticket of the context's activation cache (int, 0 = not cached))."""
     v = _vars(variables, _nvar, True)
@@ -410,7 +411,7 @@ def csmri_admm_train(ctx, variables, y0, mask, sigma_d, mu, iter_num=None, _entr
             raise PnpxError(f"iter_num {iter_num} exceeds the {T} hyper-parameter columns provided")
         T = iter_num
     out = torch.empty_like(v)
-    saved = torch.empty(3 * T * B * H * W, dtype=torch.float32, device=v.device)
+    saved = torch.empty(_saved_per * T * B * H * W, dtype=torch.float32, device=v.device)
     if B == 0:
         return out, saved, 0
     ticket = C.c_ulonglong(0)
@@ -430,15 +431,25 @@ def csmri_hqs_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num=Non
     return csmri_admm_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num, ticket, "pnpx_csmri_hqs_backward", 2)
 
 
+def csmri_pg_train(ctx, variables, y0, mask, sigma_d, tau, iter_num=None):
+    """pnpx_csmri_pg_train: PGSolver_CSMRI.forward for autograd (state [B,1,H,W,2]); saved = 2*T*B*H*W floats."""
+    return csmri_admm_train(ctx, variables, y0, mask, sigma_d, tau, iter_num, "pnpx_csmri_pg_train", 1, 2)
+
+
+def csmri_pg_backward(ctx, y0, mask, sigma_d, tau, saved, grad_out, iter_num=None, ticket=0):
+    """pnpx_csmri_pg_backward -> (grad x [B,1,H,W,2], grad sigma_d [B,T], grad tau [B,T])."""
+    return csmri_admm_backward(ctx, y0, mask, sigma_d, tau, saved, grad_out, iter_num, ticket, "pnpx_csmri_pg_backward", 1, 2)
+
+
 def csmri_admm_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num=None, ticket=0,
-                        _entry="pnpx_csmri_admm_backward", _nvar=3):
+                        _entry="pnpx_csmri_admm_backward", _nvar=3, _saved_per=3):
     """pnpx_csmri_admm_backward -> (grad variables [B,3,H,W,2], grad sigma_d [B,T], grad mu [B,T])."""
     g = _vars(grad_out, _nvar, True)
     B, _, H, W, _ = g.shape
     y0, m = _f32(y0, "y0"), _mask_u8(mask)
     ps, T = _params(B, sigma_d, mu)
     T = T if iter_num is None else iter_num
-    if saved.numel() != 3 * T * B * H * W:
+    if saved.numel() != _saved_per * T * B * H * W:
         raise PnpxError("saved does not belong to a forward of this shape / iteration count")
     gin = torch.empty_like(g)
     gs = torch.zeros(T, B, dtype=torch.float32, device=g.device)

@@ -85,14 +85,21 @@ class PGSolver_CSMRI(CSMRIMixin, PGSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, mask) = inputs
         sigma_d, tau = parameters
-        if A.needs_grad(variables, sigma_d, tau):
-            x, B, m = variables, variables.shape[0], (mask != 0).unsqueeze(-1)
-            for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):      # tasks/csmri/solver.py:107-116
-                temp = torch.where(m, A.fft2(x) - y0, torch.zeros_like(y0))
-                z = x - _v5(tau[:, i], B) * A.fft2(temp, inverse=True)
-                x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
-            return x
+        if A.needs_grad(variables, sigma_d, tau):      # training path: native forward + fused native VJP (csmri.hip)
+            return T.call("csmri_pg_train", variables, y0, mask, sigma_d, tau, -1 if iter_num is None else iter_num,
+                          self._ctx(variables).cid)[0]
         return T.call("csmri_pg", variables, y0, mask, sigma_d, tau, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
+
+
+    def _forward_autograd(self, variables, y0, mask, sigma_d, tau, iter_num):
+        """The reference's loop (tasks/csmri/solver.py:107-116) from differentiable building blocks: what the fused native
+        VJP (pnpx_csmri_pg_backward) is tested against."""
+        x, B, m = variables, variables.shape[0], (mask != 0).unsqueeze(-1)
+        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
+            temp = torch.where(m, A.fft2(x) - y0, torch.zeros_like(y0))
+            z = x - _v5(tau[:, i], B) * A.fft2(temp, inverse=True)
+            x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
+        return x
 
 
 class APGSolver_CSMRI(CSMRIMixin, APGSolver):

@@ -380,6 +380,57 @@ def _hqs_train_bwd(ctx, g_out, _g_saved, _g_ticket):
 csmri_hqs_train.register_autograd(_hqs_train_bwd, setup_context=_admm_train_setup)
 
 
+@_lib_def("pnpx::csmri_pg_train", mutates_args=(), device_types="cuda")
+def csmri_pg_train(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, tau: Tensor, iter_num: int,
+                   ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """Differentiable PGSolver_CSMRI.forward (tasks/csmri/solver.py:96-120); autograd = the fused native VJP
+    pnpx_csmri_pg_backward."""
+    out, saved, ticket = ops.csmri_pg_train(_ctx(ctx, variables), variables, y0, mask, sigma_d, tau, _it(iter_num))
+    return out, saved, torch.tensor([ticket], dtype=torch.int64)
+
+
+@csmri_pg_train.register_fake
+def _(variables, y0, mask, sigma_d, tau, iter_num, ctx):
+    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
+    B, _, H, W, _ = variables.shape
+    return (torch.empty_like(variables, memory_format=torch.contiguous_format),
+            torch.empty((2 * T * B * H * W,), dtype=variables.dtype, device=variables.device),
+            torch.empty((1,), dtype=torch.int64))
+
+
+@_lib_def("pnpx::csmri_pg_backward", mutates_args=(), device_types="cuda")
+def csmri_pg_backward(y0: Tensor, mask: Tensor, sigma_d: Tensor, tau: Tensor, saved: Tensor, ticket: Tensor,
+                      grad_out: Tensor, iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """VJP of csmri_pg_train wrt (x, sigma_d[:, :T], tau[:, :T])."""
+    return ops.csmri_pg_backward(_ctx(ctx, grad_out), y0, mask, sigma_d, tau, saved, grad_out, _it(iter_num),
+                                 ticket=int(ticket[0]))
+
+
+@csmri_pg_backward.register_fake
+def _(y0, mask, sigma_d, tau, saved, ticket, grad_out, iter_num, ctx):
+    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
+    B = grad_out.shape[0]
+    e = lambda: torch.empty((B, T), dtype=grad_out.dtype, device=grad_out.device)
+    return torch.empty_like(grad_out, memory_format=torch.contiguous_format), e(), e()
+
+
+def _pg_train_bwd(ctx, g_out, _g_saved, _g_ticket):
+    y0, mask, sigma_d, tau, saved, ticket = ctx.saved_tensors
+    gv, gs, gt = torch.ops.pnpx.csmri_pg_backward(y0, mask, sigma_d, tau, saved, ticket, g_out.contiguous(),
+                                                  ctx.iter_num, ctx.cid)
+
+    def like(g, p):
+        full = torch.zeros_like(p)
+        if p.numel():
+            full.view(p.shape[0], -1)[:, :g.shape[1]] = g
+        return full
+
+    return gv, None, None, like(gs, sigma_d), like(gt, tau), None, None
+
+
+csmri_pg_train.register_autograd(_pg_train_bwd, setup_context=_admm_train_setup)
+
+
 @_lib_def("pnpx::csmri_hqs", mutates_args=(), device_types="cuda")
 def csmri_hqs(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int, ctx: int) -> Tensor:
     """HQSSolver_CSMRI.forward (tasks/csmri/solver.py:64-89)."""
