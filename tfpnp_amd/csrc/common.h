@@ -98,6 +98,8 @@ struct PolicyNet {
   // [st][0] = conv1 as a 2x2-window convolution (tap mask 0x01B), [st][1] = the 1x1 shortcut (0x010, first Cin channels)
   ConvLayerHsDev s2_hs[4][2];
   const float* s2_bias[4][2] = {};
+  ConvLayerHsDev stem_hs;          // the stem (3x3 stride 2) as a 2x2-window sparse-tap launch over the HS8 space-to-depth observation
+  const float* stem_hs_bias = nullptr;
   const float* fc_sm_w = nullptr;   // [2][512], [2]
   const float* fc_sm_b = nullptr;
   const float* fc_det_w = nullptr;  // [n_det][512] ([64][512] with the SPI head)

@@ -47,6 +47,31 @@ __global__ __launch_bounds__(256) void pack_ob_s2d_kernel(const float* __restric
   out[((b * 4 * Cp + (size_t)ph * Cp + c) * Hp2 + (y >> 1) + 1) * Wp2 + (x >> 1) + POL_PADL] = ob[i];
 }
 
+// observation [B][C][H][W] fp32 -> half-split HS8 space-to-depth tensor [B][4*Cp/8][H/2+2][W/2+2] (phase-major channel
+// groups; channels >= C are zero): the input of the stem on the sparse-tap half-split instance
+__global__ __launch_bounds__(256) void pack_ob_s2d_hs_kernel(const float* __restrict__ ob, HsRec* __restrict__ out, int C,
+                                                             int Cp, int H, int W, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int W2 = W >> 1, H2 = H >> 1, Gp = Cp >> 3;
+  const int x2 = (int)(i % W2);
+  size_t t = i / W2;
+  const int y2 = (int)(t % H2);
+  t /= H2;
+  const int g = (int)(t % Gp);
+  t /= Gp;
+  const int ph = (int)(t % 4);
+  const size_t b = t / 4;
+  const int y = 2 * y2 + (ph >> 1), x = 2 * x2 + (ph & 1);
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = g * 8 + k;
+    v[k] = c < C ? ob[((b * C + c) * H + y) * (size_t)W + x] * HS_ASCALE : 0.f;
+  }
+  out[((b * 4 * Gp + (size_t)ph * Gp + g) * (H2 + 2) + (y2 + 1)) * (size_t)(W2 + 2) + (x2 + 1)] = hs_pack(v);
+}
+
 // global average pool over [B][512][h][w] (padded planar) + the two heads.  One workgroup per observation.
 // half-split HS8 [B][C/8][h+2][w+2] -> space-to-depth fp32 planar [B][4*C][h/2+2][w/2+8] (input of a stride-2 conv)
 __global__ __launch_bounds__(256) void hs8_to_s2d_kernel(const HsRec* __restrict__ src, float* __restrict__ dst, int C,
@@ -273,7 +298,8 @@ struct PolAct {
 };
 struct PolicyPlan {
   PolAct ob, stem;               // fp32, space-to-depth
-  PolAct stem_hs;                // HS8 copy of `stem` (stage-0 entry on the half-split instances)
+  PolAct stem_hs;                // HS8 space-to-depth of the stem output (stage-0 entry on the half-split instances)
+  PolAct ob_hs, stem_o;          // HS8: space-to-depth observation, stem output (64 channels, H/2 x W/2)
   PolAct t1[4], sc[4], o0[4], t2[4], o1[4];   // half-split HS8 (same 4 bytes per value)
   PolAct o1s[3];                 // fp32 space-to-depth copy of o1 for the next stage's stride-2 convolution
   size_t total = 0;              // floats for capB observations
@@ -300,6 +326,8 @@ PolicyPlan make_policy_plan(int capB, int cin_pad, int H, int W) {
   add(P.ob, 4 * cin_pad, H / 2, W / 2);
   add(P.stem, 4 * 64, H / 4, W / 4);
   add_hs(P.stem_hs, 4 * 64, H / 4, W / 4);
+  add_hs(P.ob_hs, 4 * cin_pad, H / 2, W / 2);
+  add_hs(P.stem_o, 64, H / 2, W / 2);
   for (int n = 0; n < 4; ++n) {
     const int p = stage_planes(n), h = H >> (n + 2), w = W >> (n + 2);
     add_hs(P.t1[n], p, h, w);
@@ -365,6 +393,9 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
   float hs_scale[12];
   int hs_c[12];
   int hi_ = 0;
+  size_t stem_w = 0, stem_b = 0;
+  float stem_scale = 1.f;
+  int stem_K = 0;
   size_t s2_w[4][2] = {}, s2_b[4][2] = {};
   float s2_scale[4][2] = {};
   int s2_K[4][2] = {}, s2_c[4][2] = {};
@@ -391,6 +422,14 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
     Eff E(64, 4 * N.cin_pad);
     put_conv_s2(E, 0, w, bn, 64, num_inputs, N.cin_pad);
     finish(E, 64);
+    // ... and as a 2x2-window sparse-tap half-split launch over the HS8 space-to-depth observation
+    H.align();
+    stem_w = H.f.size();
+    const size_t n16 = (size_t)E.cout * E.K * 4 * 2;
+    H.f.resize(H.f.size() + (n16 + 1) / 2, 0.f);
+    stem_scale = pack_conv_weights_hs_taps(E.w.data(), E.cout, E.K, 64, 0x01B, reinterpret_cast<uint16_t*>(H.f.data() + stem_w));
+    stem_b = H.add(E.bias.data(), E.bias.size());
+    stem_K = E.K;
   }
   int in_planes = 64;
   for (int s = 0; s < 4; ++s) {
@@ -494,6 +533,12 @@ int policy_load(pnpx_ctx* ctx, const float* params, size_t n, int num_inputs, in
       N.s2_hs[st][k].inv_scale = 1.0f / (s2_scale[st][k] * HS_ASCALE);
       N.s2_bias[st][k] = base + s2_b[st][k];
     }
+  N.stem_hs.cin = N.stem_hs.cin_pad = stem_K;
+  N.stem_hs.cout = 64;
+  N.stem_hs.mt = 64;
+  N.stem_hs.w = const_cast<char*>(reinterpret_cast<const char*>(base + stem_w));
+  N.stem_hs.inv_scale = 1.0f / (stem_scale * HS_ASCALE);
+  N.stem_hs_bias = base + stem_b;
   N.fc_sm_w = base + o_smw;
   N.fc_sm_b = base + o_smb;
   N.fc_det_w = base + o_dw;
@@ -541,11 +586,40 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
   float* A = static_cast<float*>(N.arena.p);
   auto ptr = [&](const PolAct& d) { return A + d.off; };
 
-  const size_t n = (size_t)B * N.num_inputs * H * W;
-  hipLaunchKernelGGL(pack_ob_s2d_kernel, g1(n), dim3(256), 0, s, ob, ptr(P.ob), N.num_inputs, N.cin_pad, H, W, n);
-  PNPX_LAUNCH_CHECK();
-  // stem (on the H/2 grid) -> space-to-depth for stage 1
-  PNPX_TRY(launch_policy_conv(N.conv[0], ptr(P.ob), ptr(P.stem), nullptr, nullptr, true, B, H / 2, W / 2, s));
+  auto hsc0 = [&](const PolAct& d) { return reinterpret_cast<char*>(A + d.off); };
+  const bool stem_on_hs = ctx->opt_policy_s2_hs && (N.stem_hs.cin_pad % 16 == 0);
+  if (stem_on_hs) {
+    // stem on the sparse-tap half-split instance: HS8 space-to-depth observation -> 2x2-window convolution (+ folded BN,
+    // ReLU) -> HS8 [64][H/2][W/2] -> space-to-depth for the stage-0 entry
+    const size_t n = (size_t)B * 4 * (N.cin_pad / 8) * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(pack_ob_s2d_hs_kernel, g1(n), dim3(256), 0, s, ob, reinterpret_cast<HsRec*>(hsc0(P.ob_hs)),
+                       N.num_inputs, N.cin_pad, H, W, n);
+    PNPX_LAUNCH_CHECK();
+    ConvLayerHs Lh;
+    Lh.cin = N.stem_hs.cin;
+    Lh.cout = 64;
+    Lh.cin_pad = N.stem_hs.cin_pad;
+    Lh.mt = 64;
+    Lh.w = N.stem_hs.w;
+    Lh.b = N.stem_hs_bias;
+    Lh.inv_scale = N.stem_hs.inv_scale;
+    ConvHsFuse f;
+    f.slope = 0.f;
+    f.taps = 0x01B;
+    f.wreg = 0;
+    f.range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
+    PNPX_TRY(launch_conv_hs(Lh, hsc0(P.ob_hs), N.stem_hs.cin_pad / 8, nullptr, 0, hsc0(P.stem_o), B, H / 2, W / 2, f, s));
+    const size_t n2 = (size_t)B * 4 * 8 * (H / 4) * (W / 4) * 2;
+    hipLaunchKernelGGL(hs_s2d_kernel, g1(n2), dim3(256), 0, s, reinterpret_cast<const uint4*>(hsc0(P.stem_o)),
+                       reinterpret_cast<uint4*>(hsc0(P.stem_hs)), 8, H / 2, W / 2, n2);
+    PNPX_LAUNCH_CHECK();
+  } else {
+    const size_t n = (size_t)B * N.num_inputs * H * W;
+    hipLaunchKernelGGL(pack_ob_s2d_kernel, g1(n), dim3(256), 0, s, ob, ptr(P.ob), N.num_inputs, N.cin_pad, H, W, n);
+    PNPX_LAUNCH_CHECK();
+    // stem (on the H/2 grid) -> space-to-depth for stage 1
+    PNPX_TRY(launch_policy_conv(N.conv[0], ptr(P.ob), ptr(P.stem), nullptr, nullptr, true, B, H / 2, W / 2, s));
+  }
   // residual stages.  The stride-2 entry (conv1 + 1x1 shortcut, one fp32 tap-sparse launch) writes its two outputs as
   // half-split HS8 tensors; the three stride-1 convolutions of the stage run on the f16x3 MFMA kernel (conv_hs.hip:
   // folded-BN bias, residual add and ReLU in its epilogue); the stage output is re-laid out space-to-depth in fp32 for
@@ -574,7 +648,7 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
       PNPX_TRY(launch_policy_conv(N.conv[1 + 4 * st], xin, ptr(P.t1[st]), ptr(P.sc[st]), nullptr, false, B, h, w, s, true));
     } else {
       const PolAct& s2in = st == 0 ? P.stem_hs : P.o1s[st - 1];
-      if (st == 0) {
+      if (st == 0 && !stem_on_hs) {
         const size_t n0 = (size_t)B * (P.stem.C / 8) * h * w;
         hipLaunchKernelGGL(planar_to_hs8_kernel, g1(n0), dim3(256), 0, s, ptr(P.stem), reinterpret_cast<HsRec*>(hsc(P.stem_hs)),
                            P.stem.C, h, w, n0);
