@@ -258,6 +258,18 @@ int pnpx_csmri_pg_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, 
 int pnpx_csmri_apg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                    const uint8_t* mask, const float* sigma_d, const float* tau, const float* beta,
                    int param_stride, int B, int H, int W, int T, void* stream);
+/* Training path of APGSolver_CSMRI.forward (same contract; vars [B,2,H,W,2]): `saved` = 4*T*B*H*W floats (denoiser inputs,
+ * real parts of the masked-residual images, x' - x_prev as complex); grads wrt (cat(x, s), sigma_d, tau, beta); work =
+ * 4*B*H*W floats. */
+int pnpx_csmri_apg_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                         const uint8_t* mask, const float* sigma_d, const float* tau, const float* beta,
+                         int param_stride, int B, int H, int W, int T, float* saved, unsigned long long* ticket,
+                         void* stream);
+int pnpx_csmri_apg_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, const float* sigma_d,
+                            const float* tau, const float* beta, int param_stride, const float* saved,
+                            const float* grad_vars_out, float* grad_vars_in, float* grad_sigma_d, float* grad_tau,
+                            float* grad_beta, float* work, int B, int H, int W, int T, unsigned long long ticket,
+                            void* stream);
 /* REDADMMSolver_CSMRI.forward (tasks/csmri/solver.py:172-204).  vars [B,3,H,W,2]. */
 int pnpx_csmri_redadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                        const uint8_t* mask, const float* sigma_d, const float* mu, const float* lamda,

@@ -257,6 +257,36 @@ __global__ void apg_update_kernel(const float* __restrict__ xr, const float2* xp
   sout[b * istride + r] = make_float2(addr(xv, mulr(be, subr(xv, xp.x))), addr(0.f, mulr(be, subr(0.f, xp.y))));
   xout[b * istride + r] = make_float2(xv, 0.f);
 }
+// training forward: the same update that also keeps x' - x_prev (complex) for d/d beta
+__global__ void apg_update_save_kernel(const float* __restrict__ xr, const float2* xprev, float2* xout,
+                                       float2* __restrict__ sout, size_t istride, const float* __restrict__ beta,
+                                       int stride, int HW, int B, float2* __restrict__ diff) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  const float be = beta[b * stride];
+  const float2 xp = xprev[b * istride + r];
+  const float xv = xr[i];
+  const float dx = subr(xv, xp.x), dy = subr(0.f, xp.y);
+  diff[i] = make_float2(dx, dy);
+  sout[b * istride + r] = make_float2(addr(xv, mulr(be, dx)), addr(0.f, mulr(be, dy)));
+  xout[b * istride + r] = make_float2(xv, 0.f);
+}
+// APG backward, first half of an iteration: with s' = x' + beta (x' - x_prev):
+//   d/d beta term <gs', x' - x_prev>;  cotangent of the denoiser output Re(gx' + (1 + beta) gs');  cotangent of x_prev = -beta gs'
+__global__ void apg_adjoint_pre_kernel(float2* g, size_t istride, const float* __restrict__ beta, int stride,
+                                       const float2* __restrict__ diff, float* __restrict__ gxr,
+                                       float* __restrict__ contrib, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  float2* gi = g + b * istride + r;
+  const float be = beta[b * stride];
+  const float2 gx = gi[0], gs = gi[HW], df = diff[i];
+  contrib[i] = gs.x * df.x + gs.y * df.y;
+  gxr[i] = gx.x + (1.f + be) * gs.x;
+  gi[0] = make_float2(-be * gs.x, -be * gs.y);
+}
 // RED x-update: x = (lamda*x_half + mu*(z-u)) / (mu + lamda)               tasks/csmri/solver.py:188-190
 __global__ void red_update_kernel(const float* __restrict__ xh, const float2* __restrict__ z,
                                   const float2* __restrict__ u, float2* xout, size_t istride,
@@ -724,27 +754,26 @@ extern "C" int pnpx_csmri_pg_backward(pnpx_ctx* ctx, const float* y0, const uint
   });
 }
 
-extern "C" int pnpx_csmri_apg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
-                              const uint8_t* mask, const float* sigma_d, const float* tau, const float* beta,
-                              int param_stride, int B, int H, int W, int T, void* stream) {
-  LOCK_CTX(ctx);
-  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+// APG forward; `saved` != NULL (training path): per iteration the denoiser input d_i [T][B][HW], Re(w_i) [T][B][HW]
+// (w_i = ifft2c(mask * (fft2c(s_i) - y0))) and x' - x_prev [T][B][HW] complex; activations parked (ticket + i).
+static int apg_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const uint8_t* mask,
+                       const float* sigma_d, const float* tau, const float* beta, int param_stride, int B, int H, int W,
+                       int T, float* saved, hipStream_t s, unsigned long long* ticket_out = nullptr) {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
   if (!beta || !tau) {
     set_error("csmri_apg: null tau/beta");
     return PNPX_ERR_ARG;
   }
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ticket_out) *ticket_out = 0;
+  const bool park = saved && ticket_out;
   const int HW = H * W;
-  const size_t is = 2 * (size_t)HW;
+  const size_t is = 2 * (size_t)HW, n = (size_t)B * HW;
   Scratch S;
   PNPX_TRY(get_scratch(ctx, B, H, W, &S));
   FftPlan2D P;
   PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
-  const float2* vin = reinterpret_cast<const float2*>(vars_in);
   float2* vout = reinterpret_cast<float2*>(vars_out);
   PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
-  (void)vin;
   RealImg xr{S.xr, W, HW}, d{S.d, W, HW};
   StoreC kst{S.k, H, W};
   LoadC kld{S.k, H, W};
@@ -753,13 +782,104 @@ extern "C" int pnpx_csmri_apg(pnpx_ctx* ctx, const float* vars_in, float* vars_o
     PNPX_TRY((launch_rows<false>(P, LoadSlot{sc}, kst, s)));
     KSpace ks{reinterpret_cast<const float2*>(y0), mask, tau + i, param_stride, W, HW};
     PNPX_TRY((launch_cols<false, true>(P, kld, MidResidual{ks}, kst, s)));
-    PNPX_TRY((launch_rows<true>(P, kld, StoreGrad{sc, xr, 0, tau + i, param_stride, d}, s)));
-    PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
-    hipLaunchKernelGGL(apg_update_kernel, g1((size_t)HW * B), dim3(256), 0, s, S.xr, vout, vout, vout + HW, is,
-                       beta + i, param_stride, HW, B);
+    float* wsave = saved ? saved + ((size_t)T + i) * n : nullptr;
+    PNPX_TRY((launch_rows<true>(P, kld, StoreGrad{sc, xr, 0, tau + i, param_stride, d, wsave}, s)));
+    if (saved) PNPX_HIP(hipMemcpyAsync(saved + (size_t)i * n, S.d, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+    if (park) {
+      unsigned long long tk = 0;
+      PNPX_TRY(unet_denoise_train(ctx, S.d, sigma_d + i, param_stride, S.xr, B, H, W, s, &tk));
+      if (i == 0) *ticket_out = tk;
+    } else {
+      PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    }
+    if (saved) {
+      float2* diff = reinterpret_cast<float2*>(saved + 2 * (size_t)T * n) + (size_t)i * n;
+      hipLaunchKernelGGL(apg_update_save_kernel, g1(n), dim3(256), 0, s, S.xr, vout, vout, vout + HW, is, beta + i,
+                         param_stride, HW, B, diff);
+    } else {
+      hipLaunchKernelGGL(apg_update_kernel, g1(n), dim3(256), 0, s, S.xr, vout, vout, vout + HW, is, beta + i,
+                         param_stride, HW, B);
+    }
     PNPX_LAUNCH_CHECK();
   }
   return PNPX_OK;
+}
+
+extern "C" int pnpx_csmri_apg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                              const uint8_t* mask, const float* sigma_d, const float* tau, const float* beta,
+                              int param_stride, int B, int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return apg_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, tau, beta, param_stride, B, H, W, T, nullptr, s);
+  });
+}
+
+extern "C" int pnpx_csmri_apg_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                                    const uint8_t* mask, const float* sigma_d, const float* tau, const float* beta,
+                                    int param_stride, int B, int H, int W, int T, float* saved,
+                                    unsigned long long* ticket, void* stream) {
+  LOCK_CTX(ctx);
+  if ((!saved && T > 0) || !ticket) {
+    pnpx::set_error("csmri_apg_train: saved / ticket is null");
+    return PNPX_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return apg_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, tau, beta, param_stride, B, H, W, T, saved, s, ticket);
+  });
+}
+
+// VJP of the T-iteration APG map wrt (cat(x, s), sigma_d, tau, beta), iterations walked in reverse:
+//   forward i:   w = F^-1 M (F s - y0);  d_i = Re(s - tau_i w);  x' = r2c(D(d_i, sigma_i));  s' = x' + beta_i (x' - x)
+//   backward i:  g_beta_i = <gs', x' - x>;  gxr = Re(gx' + (1 + beta_i) gs');  gx = -beta_i gs';  (gd, g_sigma_i) = D^T(gxr);
+//                g_tau_i = -<gd, Re w>;  gs = r2c(gd) - tau_i F^-1 M F r2c(gd)
+extern "C" int pnpx_csmri_apg_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, const float* sigma_d,
+                                       const float* tau, const float* beta, int param_stride, const float* saved,
+                                       const float* grad_vars_out, float* grad_vars_in, float* grad_sigma_d,
+                                       float* grad_tau, float* grad_beta, float* work, int B, int H, int W, int T,
+                                       unsigned long long ticket, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    PNPX_TRY(check_common(grad_vars_out, grad_vars_in, y0, mask, sigma_d, B, H, W, T, param_stride));
+    if (T > 0 && (!saved || !grad_sigma_d || !grad_tau || !grad_beta || !work || !tau || !beta)) {
+      set_error("csmri_apg_backward: null pointer");
+      return PNPX_ERR_ARG;
+    }
+    const int HW = H * W;
+    const size_t is = 2 * (size_t)HW, n = (size_t)B * HW;
+    PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+    if (T == 0) return PNPX_OK;
+    FftPlan2D P;
+    PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
+    float2* g = reinterpret_cast<float2*>(grad_vars_in);
+    float *gxr = work, *gd = work + n, *contrib = work + 2 * n, *contrib_b = work + 3 * n;
+    const float2* diff = reinterpret_cast<const float2*>(saved + 2 * (size_t)T * n);
+    for (int i = T - 1; i >= 0; --i) {
+      hipLaunchKernelGGL(apg_adjoint_pre_kernel, g1(n), dim3(256), 0, s, g, is, beta + i, param_stride, diff + (size_t)i * n,
+                         gxr, contrib_b, HW, B);
+      PNPX_LAUNCH_CHECK();
+      hipLaunchKernelGGL(item_sum_kernel, dim3(B), dim3(256), 0, s, contrib_b, grad_beta + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(unet_denoise_backward_ticket(ctx, saved + (size_t)i * n, sigma_d + i, param_stride, gxr, gd,
+                                            grad_sigma_d + (size_t)i * B, B, H, W, s, ticket ? ticket + i : 0));
+      Scratch S;
+      PNPX_TRY(get_scratch(ctx, B, H, W, &S));
+      StoreC kst{S.k, H, W};
+      LoadC kld{S.k, H, W};
+      PNPX_TRY((launch_rows<false>(P, LoadXr{RealImg{gd, W, HW}}, kst, s)));
+      KSpace ks{reinterpret_cast<const float2*>(y0), mask, tau + i, param_stride, W, HW};
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidMask{ks}, kst, s)));
+      // (the "first iteration" form of the PG store functor writes the complex cotangent -- here into the s slot, always)
+      PNPX_TRY((launch_rows<true>(P, kld,
+                                  StorePgAdjoint{gd, saved + ((size_t)T + i) * n, tau + i, param_stride, RealImg{gxr, W, HW},
+                                                 Slot{g + HW, is, W, HW}, 1, contrib},
+                                  s)));
+      hipLaunchKernelGGL(item_sum_kernel, dim3(B), dim3(256), 0, s, contrib, grad_tau + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+    }
+    return PNPX_OK;
   });
 }
 

@@ -465,6 +465,51 @@ def csmri_admm_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num=No
     return gin, gs.t().contiguous(), gm.t().contiguous()
 
 
+def csmri_apg_train(ctx, variables, y0, mask, sigma_d, tau, beta, iter_num=None):
+    """pnpx_csmri_apg_train: APGSolver_CSMRI.forward for autograd -> (next state [B,2,H,W,2], saved [4*T*B*H*W], ticket)."""
+    v = _vars(variables, 2, True)
+    B, _, H, W, _ = v.shape
+    y0, m = _f32(y0, "y0"), _mask_u8(mask)
+    if y0.numel() != B * H * W * 2 or m.numel() != B * H * W:
+        raise PnpxError("y0/mask do not match the state's [B,H,W]")
+    ps, T = _params(B, sigma_d, tau, beta)
+    if iter_num is not None:
+        if iter_num > T:
+            raise PnpxError(f"iter_num {iter_num} exceeds the {T} hyper-parameter columns provided")
+        T = iter_num
+    out = torch.empty_like(v)
+    saved = torch.empty(4 * T * B * H * W, dtype=torch.float32, device=v.device)
+    if B == 0:
+        return out, saved, 0
+    ticket = C.c_ulonglong(0)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().pnpx_csmri_apg_train(ctx.handle, _p(v), _p(out), _p(y0), _p(m), _p(ps[0]), _p(ps[1]), _p(ps[2]),
+                                              ps[0].shape[1], B, H, W, T, _p(saved), C.byref(ticket), _stream(v)))
+    return out, saved, int(ticket.value)
+
+
+def csmri_apg_backward(ctx, y0, mask, sigma_d, tau, beta, saved, grad_out, iter_num=None, ticket=0):
+    """pnpx_csmri_apg_backward -> (grad variables [B,2,H,W,2], grad sigma_d, grad tau, grad beta, each [B,T])."""
+    g = _vars(grad_out, 2, True)
+    B, _, H, W, _ = g.shape
+    y0, m = _f32(y0, "y0"), _mask_u8(mask)
+    ps, T = _params(B, sigma_d, tau, beta)
+    T = T if iter_num is None else iter_num
+    if saved.numel() != 4 * T * B * H * W:
+        raise PnpxError("saved does not belong to a forward of this shape / iteration count")
+    gin = torch.empty_like(g)
+    gs, gt, gb = (torch.zeros(T, B, dtype=torch.float32, device=g.device) for _ in range(3))
+    if B and T:
+        work = torch.empty(4 * B * H * W, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(_lib.lib().pnpx_csmri_apg_backward(ctx.handle, _p(y0), _p(m), _p(ps[0]), _p(ps[1]), _p(ps[2]),
+                                                     ps[0].shape[1], _p(saved), _p(g), _p(gin), _p(gs), _p(gt), _p(gb),
+                                                     _p(work), B, H, W, T, int(ticket), _stream(g)))
+    elif B:
+        gin.copy_(g)
+    return gin, gs.t().contiguous(), gt.t().contiguous(), gb.t().contiguous()
+
+
 def csmri_hqs(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):
     return _csmri_common("pnpx_csmri_hqs", 2, ctx, variables, y0, mask, (sigma_d, mu), iter_num)
 

@@ -108,17 +108,24 @@ class APGSolver_CSMRI(CSMRIMixin, APGSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, mask) = inputs
         sigma_d, tau, beta = parameters
-        if A.needs_grad(variables, sigma_d, tau, beta):
-            x, s = torch.split(variables, variables.shape[1] // 2, dim=1)
-            B, m = x.shape[0], (mask != 0).unsqueeze(-1)
-            for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):      # tasks/csmri/solver.py:141-159
-                temp = torch.where(m, A.fft2(s) - y0, torch.zeros_like(y0))
-                z = s - _v5(tau[:, i], B) * A.fft2(temp, inverse=True)
-                x_prev = x
-                x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
-                s = x + _v5(beta[:, i], B) * (x - x_prev)
-            return torch.cat([x, s], dim=1)
+        if A.needs_grad(variables, sigma_d, tau, beta):      # training path: native forward + fused native VJP (csmri.hip)
+            return T.call("csmri_apg_train", variables, y0, mask, sigma_d, tau, beta, -1 if iter_num is None else iter_num,
+                          self._ctx(variables).cid)[0]
         return T.call("csmri_apg", variables, y0, mask, sigma_d, tau, beta, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
+
+
+    def _forward_autograd(self, variables, y0, mask, sigma_d, tau, beta, iter_num):
+        """The reference's loop (tasks/csmri/solver.py:141-159) from differentiable building blocks: what the fused native VJP
+        (pnpx_csmri_apg_backward) is tested against."""
+        x, s = torch.split(variables, variables.shape[1] // 2, dim=1)
+        B, m = x.shape[0], (mask != 0).unsqueeze(-1)
+        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
+            temp = torch.where(m, A.fft2(s) - y0, torch.zeros_like(y0))
+            z = s - _v5(tau[:, i], B) * A.fft2(temp, inverse=True)
+            x_prev = x
+            x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
+            s = x + _v5(beta[:, i], B) * (x - x_prev)
+        return torch.cat([x, s], dim=1)
 
 
 class REDADMMSolver_CSMRI(CSMRIMixin, REDADMMSolver):
