@@ -274,6 +274,18 @@ int pnpx_csmri_apg_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask,
 int pnpx_csmri_redadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                        const uint8_t* mask, const float* sigma_d, const float* mu, const float* lamda,
                        int param_stride, int B, int H, int W, int T, void* stream);
+/* Training path of REDADMMSolver_CSMRI.forward (same contract; vars [B,3,H,W,2]): `saved` = 7*T*B*H*W floats (denoiser
+ * inputs Re x, the k-space images before the blend, r2c(xh) - x' and (z - u) - x' as complex); grads wrt (cat(x, z, u),
+ * sigma_d, mu, lamda); work = 4*B*H*W floats. */
+int pnpx_csmri_redadmm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                             const uint8_t* mask, const float* sigma_d, const float* mu, const float* lamda,
+                             int param_stride, int B, int H, int W, int T, float* saved, unsigned long long* ticket,
+                             void* stream);
+int pnpx_csmri_redadmm_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, const float* sigma_d,
+                                const float* mu, const float* lamda, int param_stride, const float* saved,
+                                const float* grad_vars_out, float* grad_vars_in, float* grad_sigma_d, float* grad_mu,
+                                float* grad_lamda, float* work, int B, int H, int W, int T, unsigned long long ticket,
+                                void* stream);
 /* IADMMSolver_PR.forward (tasks/pr/solver.py:37-76).
  * vars [B,3,H,W,2]; y0 [B,S,H,W]; mask [B,S,H,W,2]. */
 int pnpx_pr_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,

@@ -381,6 +381,39 @@ def test_csmri_apg_fused_vjp_vs_composed_autograd(den):
     assert all(torch.equal(x, y) for x, y in zip(gf, gf2))
 
 
+def test_csmri_redadmm_fused_vjp_vs_composed_autograd(den):
+    """REDADMMSolver_CSMRI under autograd: pnpx_csmri_redadmm_train / _backward against the composed path (mu enters both the
+    x-update and the k-space blend; lamda only the x-update; the state is complex with a non-zero imaginary part)."""
+    from tfpnp_amd.tasks import csmri
+    sol = csmri.REDADMMSolver_CSMRI(den)
+    B, H, W, T = 3, 48, 48, 3
+    d = synth.make_csmri_batch(B, H, W, seed=181)
+    a = csmri_actions(B, 4, 182, ("sigma_d", "mu", "lamda"))
+    v0 = sol.reset({"x0": g(d["x0"])})
+    v0 = v0 + 0.05 * torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(5))
+    wts = torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(6))
+    y0, m = g(d["y0"]), g(d["mask"])
+
+    def grads(fn):
+        leaves = [v0.clone().requires_grad_(True), g(a["sigma_d"], True), g(a["mu"], True), g(a["lamda"], True)]
+        out = fn(*leaves)
+        (out * wts).sum().backward()
+        return out.detach(), [l.grad for l in leaves]
+
+    out_f, gf = grads(lambda v, s_, m_, l_: sol((v, (y0, m)), (s_, m_, l_), iter_num=T))
+    out_c, gc = grads(lambda v, s_, m_, l_: sol._forward_autograd(v, y0, m, s_, m_, l_, T))
+    with torch.no_grad():
+        assert rel(out_f, sol((v0, (y0, m)), (g(a["sigma_d"]), g(a["mu"]), g(a["lamda"])), iter_num=T)) < 1e-6
+    assert rel(out_f, out_c) < 1e-5
+    for n, x, y in zip(("variables", "sigma_d", "mu", "lamda"), gf, gc):
+        print(f"  RED-ADMM fused vs composed d/d{n}: {rel(x, y):.2e}")
+        assert rel(x, y) < 2e-2 and x.shape == y.shape, n
+    for k in (1, 2, 3):
+        assert float(gf[k][:, T:].abs().max()) == 0.0 and float(gf[k][:, :T].abs().min()) > 0
+    _, gf2 = grads(lambda v, s_, m_, l_: sol((v, (y0, m)), (s_, m_, l_), iter_num=T))
+    assert all(torch.equal(x, y) for x, y in zip(gf, gf2))
+
+
 def test_csmri_admm_train_degenerate_calls(den):
     """iter_num = 0 (identity: gradient passes straight through, hyper-parameters get zeros) and an empty batch."""
     from tfpnp_amd.tasks import csmri

@@ -162,6 +162,30 @@ struct StoreHqsAdjoint {
   RealImg gxr;
   __device__ void operator()(int b, int y, int x, float2 gs) const { gxr.at(b, y, x) = gx.at(b, y, x).x + gs.x; }
 };
+// Backward of one RED-ADMM iteration after the data step's adjoint gs (cotangent of x' + u).  With D = mu + lamda:
+//   gxt = gx' + gu' + gs;  d/d lamda += <gxt, q1> / D;  d/d mu += <gxt, q2> / D (added to the blend's term in `contrib_mu`);
+//   cotangent of the denoiser output = lamda / D * Re(gxt);  gz = mu / D * gxt;  gu = gu' + gs - mu / D * gxt
+struct StoreRedAdjoint {
+  Slot gx, gz, gu;          // cotangent slots of the state (gx, gu hold gx', gu' on entry)
+  const float2 *q1, *q2;    // [B][HW] saved by the forward
+  const float *mu, *lam;
+  int stride;
+  RealImg gxh;
+  float *contrib_mu, *contrib_lam;
+  __device__ void operator()(int b, int y, int x, float2 gs) const {
+    const size_t o = (size_t)b * gxh.HW + (size_t)y * gxh.W + x;
+    const float m = mu[(size_t)b * stride], l = lam[(size_t)b * stride], D = m + l;
+    const float2 gxp = gx.at(b, y, x), gup = gu.at(b, y, x);
+    const float2 gxt = make_float2(gxp.x + gup.x + gs.x, gxp.y + gup.y + gs.y);
+    const float2 a = q1[o], c = q2[o];
+    contrib_lam[o] = (gxt.x * a.x + gxt.y * a.y) / D;
+    contrib_mu[o] += (gxt.x * c.x + gxt.y * c.y) / D;
+    gxh.at(b, y, x) = l / D * gxt.x;
+    const float bm = m / D;
+    gz.at(b, y, x) = make_float2(bm * gxt.x, bm * gxt.y);
+    gu.at(b, y, x) = make_float2(gup.x + gs.x - bm * gxt.x, gup.y + gs.y - bm * gxt.y);
+  }
+};
 struct StoreAdmmCx {  // same with a complex x held in a slot (RED-ADMM); no denoiser input emitted
   Slot z, uo;
   CSlot ui, xc;
@@ -302,6 +326,31 @@ __global__ void red_update_kernel(const float* __restrict__ xh, const float2* __
                                       divr(addr(mulr(l, 0.f), mulr(m, subr(zv.y, uv.y))), den));
 }
 
+// training forward of RED-ADMM: the same x-update that also keeps q1 = r2c(xh) - x' and q2 = (z - u) - x' (d x' / d lamda and
+// d x' / d mu up to the factor 1 / (mu + lamda))
+__global__ void red_update_save_kernel(const float* __restrict__ xh, const float2* __restrict__ z,
+                                       const float2* __restrict__ u, float2* xout, size_t istride,
+                                       const float* __restrict__ mu, const float* __restrict__ lam, int stride, int HW,
+                                       int B, float2* __restrict__ q1, float2* __restrict__ q2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  const float m = mu[b * stride], l = lam[b * stride];
+  const float2 zv = z[b * istride + r], uv = u[b * istride + r];
+  const float den = addr(m, l);
+  const float2 zu = make_float2(subr(zv.x, uv.x), subr(zv.y, uv.y));
+  const float2 xn = make_float2(divr(addr(mulr(l, xh[i]), mulr(m, zu.x)), den), divr(addr(mulr(l, 0.f), mulr(m, zu.y)), den));
+  xout[b * istride + r] = xn;
+  q1[i] = make_float2(xh[i] - xn.x, -xn.y);
+  q2[i] = make_float2(zu.x - xn.x, zu.y - xn.y);
+}
+// RED-ADMM backward: the x slot takes the denoiser's input cotangent (d = Re(x))
+__global__ void red_adjoint_finish_kernel(const float* __restrict__ gd, float2* g, size_t istride, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  g[b * istride + r] = make_float2(gd[i], 0.f);
+}
 // backward of d = Re(z - u): gz = r2c(gd), gu -= r2c(gd); x of the previous state is not read by an iteration: gx = 0
 __global__ void admm_adjoint_finish_kernel(const float* __restrict__ gd, float2* g, size_t istride, int HW, int B) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -883,19 +932,20 @@ extern "C" int pnpx_csmri_apg_backward(pnpx_ctx* ctx, const float* y0, const uin
   });
 }
 
-extern "C" int pnpx_csmri_redadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
-                                  const uint8_t* mask, const float* sigma_d, const float* mu, const float* lamda,
-                                  int param_stride, int B, int H, int W, int T, void* stream) {
-  LOCK_CTX(ctx);
-  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+// RED-ADMM forward; `saved` != NULL (training path): per iteration d_i = Re(x) [T][n], the k-space image before the blend
+// [T][n][2], q1 = r2c(xh) - x' [T][n][2], q2 = (z - u) - x' [T][n][2] (n = B*H*W); activations parked (ticket + i).
+static int red_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const uint8_t* mask,
+                       const float* sigma_d, const float* mu, const float* lamda, int param_stride, int B, int H, int W,
+                       int T, float* saved, hipStream_t s, unsigned long long* ticket_out = nullptr) {
   PNPX_TRY(check_common(vars_in, vars_out, y0, mask, sigma_d, B, H, W, T, param_stride));
   if (!mu || !lamda) {
     set_error("csmri_redadmm: null mu/lamda");
     return PNPX_ERR_ARG;
   }
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ticket_out) *ticket_out = 0;
+  const bool park = saved && ticket_out;
   const int HW = H * W;
-  const size_t is = 3 * (size_t)HW;
+  const size_t is = 3 * (size_t)HW, n = (size_t)B * HW;
   Scratch S;
   PNPX_TRY(get_scratch(ctx, B, H, W, &S));
   FftPlan2D P;
@@ -907,18 +957,115 @@ extern "C" int pnpx_csmri_redadmm(pnpx_ctx* ctx, const float* vars_in, float* va
   Slot zo{vout + HW, is, W, HW}, uo{vout + 2 * HW, is, W, HW};
   CSlot xc{vout, is, W, HW}, uc{vout + 2 * HW, is, W, HW};
   for (int i = 0; i < T; ++i) {
-    hipLaunchKernelGGL(real_of_diff_kernel, g1((size_t)HW * B), dim3(256), 0, s, vout, (const float2*)nullptr, is, S.d,
-                       HW, B);
+    hipLaunchKernelGGL(real_of_diff_kernel, g1(n), dim3(256), 0, s, vout, (const float2*)nullptr, is, S.d, HW, B);
     PNPX_LAUNCH_CHECK();
-    PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
-    hipLaunchKernelGGL(red_update_kernel, g1((size_t)HW * B), dim3(256), 0, s, S.xr, vout + HW, vout + 2 * HW, vout, is,
-                       mu + i, lamda + i, param_stride, HW, B);
+    if (saved) PNPX_HIP(hipMemcpyAsync(saved + (size_t)i * n, S.d, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+    if (park) {
+      unsigned long long tk = 0;
+      PNPX_TRY(unet_denoise_train(ctx, S.d, sigma_d + i, param_stride, S.xr, B, H, W, s, &tk));
+      if (i == 0) *ticket_out = tk;
+    } else {
+      PNPX_TRY(unet_denoise(ctx, S.d, sigma_d + i, param_stride, S.xr, nullptr, B, H, W, s, nullptr));
+    }
+    if (saved) {
+      float2* q1 = reinterpret_cast<float2*>(saved + 3 * (size_t)T * n) + (size_t)i * n;
+      float2* q2 = reinterpret_cast<float2*>(saved + 5 * (size_t)T * n) + (size_t)i * n;
+      hipLaunchKernelGGL(red_update_save_kernel, g1(n), dim3(256), 0, s, S.xr, vout + HW, vout + 2 * HW, vout, is, mu + i,
+                         lamda + i, param_stride, HW, B, q1, q2);
+    } else {
+      hipLaunchKernelGGL(red_update_kernel, g1(n), dim3(256), 0, s, S.xr, vout + HW, vout + 2 * HW, vout, is, mu + i,
+                         lamda + i, param_stride, HW, B);
+    }
     PNPX_LAUNCH_CHECK();
     PNPX_TRY((launch_rows<false>(P, LoadSlotPlusSlot{xc, uc}, kst, s)));
     KSpace ks{reinterpret_cast<const float2*>(y0), mask, mu + i, param_stride, W, HW};
-    PNPX_TRY((launch_cols<false, true>(P, kld, MidBlend{ks}, kst, s)));
+    if (saved) {
+      float2* ksave = reinterpret_cast<float2*>(saved + (size_t)T * n) + (size_t)i * n;
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidBlendSave{ks, ksave}, kst, s)));
+    } else {
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidBlend{ks}, kst, s)));
+    }
     PNPX_TRY((launch_rows<true>(P, kld, StoreAdmmCx{zo, uo, uc, xc}, s)));
   }
   return PNPX_OK;
+}
+
+extern "C" int pnpx_csmri_redadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                                  const uint8_t* mask, const float* sigma_d, const float* mu, const float* lamda,
+                                  int param_stride, int B, int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return red_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, mu, lamda, param_stride, B, H, W, T, nullptr, s);
+  });
+}
+
+extern "C" int pnpx_csmri_redadmm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
+                                        const uint8_t* mask, const float* sigma_d, const float* mu, const float* lamda,
+                                        int param_stride, int B, int H, int W, int T, float* saved,
+                                        unsigned long long* ticket, void* stream) {
+  LOCK_CTX(ctx);
+  if ((!saved && T > 0) || !ticket) {
+    pnpx::set_error("csmri_redadmm_train: saved / ticket is null");
+    return PNPX_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return red_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, mu, lamda, param_stride, B, H, W, T, saved, s, ticket);
+  });
+}
+
+// VJP of the T-iteration RED-ADMM map wrt (cat(x, z, u), sigma_d, mu, lamda), iterations walked in reverse:
+//   forward i:   xh = D(Re x, sigma_i);  x' = (lamda r2c(xh) + mu (z - u)) / (mu + lamda);  z' = F^-1 blend_mu(F(x' + u));
+//                u' = u + x' - z'
+//   backward i:  gs = F^-1 blend^T F (gz' - gu');  StoreRedAdjoint (above);  (gd, g_sigma_i) = D^T(lamda / D Re gxt);  gx = r2c(gd)
+extern "C" int pnpx_csmri_redadmm_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* mask, const float* sigma_d,
+                                           const float* mu, const float* lamda, int param_stride, const float* saved,
+                                           const float* grad_vars_out, float* grad_vars_in, float* grad_sigma_d,
+                                           float* grad_mu, float* grad_lamda, float* work, int B, int H, int W, int T,
+                                           unsigned long long ticket, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    PNPX_TRY(check_common(grad_vars_out, grad_vars_in, y0, mask, sigma_d, B, H, W, T, param_stride));
+    if (T > 0 && (!saved || !grad_sigma_d || !grad_mu || !grad_lamda || !work || !mu || !lamda)) {
+      set_error("csmri_redadmm_backward: null pointer");
+      return PNPX_ERR_ARG;
+    }
+    const int HW = H * W;
+    const size_t is = 3 * (size_t)HW, n = (size_t)B * HW;
+    PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+    if (T == 0) return PNPX_OK;
+    FftPlan2D P;
+    PNPX_TRY(make_fft_plan(ctx, B, H, W, true, &P));
+    float2* g = reinterpret_cast<float2*>(grad_vars_in);
+    float *gxh = work, *gd = work + n, *contrib = work + 2 * n, *contrib_l = work + 3 * n;
+    const float2* saved_k = reinterpret_cast<const float2*>(saved + (size_t)T * n);
+    const float2* saved_q1 = reinterpret_cast<const float2*>(saved + 3 * (size_t)T * n);
+    const float2* saved_q2 = reinterpret_cast<const float2*>(saved + 5 * (size_t)T * n);
+    for (int i = T - 1; i >= 0; --i) {
+      Scratch S;
+      PNPX_TRY(get_scratch(ctx, B, H, W, &S));
+      StoreC kst{S.k, H, W};
+      LoadC kld{S.k, H, W};
+      CSlot gzc{g + HW, is, W, HW}, guc{g + 2 * HW, is, W, HW};
+      PNPX_TRY((launch_rows<false>(P, LoadSlotMinusSlot{gzc, guc}, kst, s)));
+      KSpace ks{reinterpret_cast<const float2*>(y0), mask, mu + i, param_stride, W, HW};
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidBlendAdjoint{ks, saved_k + (size_t)i * n, contrib}, kst, s)));
+      PNPX_TRY((launch_rows<true>(P, kld,
+                                  StoreRedAdjoint{Slot{g, is, W, HW}, Slot{g + HW, is, W, HW}, Slot{g + 2 * HW, is, W, HW},
+                                                  saved_q1 + (size_t)i * n, saved_q2 + (size_t)i * n, mu + i, lamda + i,
+                                                  param_stride, RealImg{gxh, W, HW}, contrib, contrib_l},
+                                  s)));
+      hipLaunchKernelGGL(item_sum_kernel, dim3(B), dim3(256), 0, s, contrib, grad_mu + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+      hipLaunchKernelGGL(item_sum_kernel, dim3(B), dim3(256), 0, s, contrib_l, grad_lamda + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(unet_denoise_backward_ticket(ctx, saved + (size_t)i * n, sigma_d + i, param_stride, gxh, gd,
+                                            grad_sigma_d + (size_t)i * B, B, H, W, s, ticket ? ticket + i : 0));
+      hipLaunchKernelGGL(red_adjoint_finish_kernel, g1(n), dim3(256), 0, s, gd, g, is, HW, B);
+      PNPX_LAUNCH_CHECK();
+    }
+    return PNPX_OK;
   });
 }

@@ -465,49 +465,72 @@ def csmri_admm_backward(ctx, y0, mask, sigma_d, mu, saved, grad_out, iter_num=No
     return gin, gs.t().contiguous(), gm.t().contiguous()
 
 
-def csmri_apg_train(ctx, variables, y0, mask, sigma_d, tau, beta, iter_num=None):
-    """pnpx_csmri_apg_train: APGSolver_CSMRI.forward for autograd -> (next state [B,2,H,W,2], saved [4*T*B*H*W], ticket)."""
-    v = _vars(variables, 2, True)
+def _csmri_train3(entry, nvar, per, ctx, variables, y0, mask, params, iter_num):
+    """Training forward of a CS-MRI solver with three hyper-parameter rows -> (next state, saved [per*T*B*H*W], ticket)."""
+    v = _vars(variables, nvar, True)
     B, _, H, W, _ = v.shape
     y0, m = _f32(y0, "y0"), _mask_u8(mask)
     if y0.numel() != B * H * W * 2 or m.numel() != B * H * W:
         raise PnpxError("y0/mask do not match the state's [B,H,W]")
-    ps, T = _params(B, sigma_d, tau, beta)
+    ps, T = _params(B, *params)
     if iter_num is not None:
         if iter_num > T:
             raise PnpxError(f"iter_num {iter_num} exceeds the {T} hyper-parameter columns provided")
         T = iter_num
     out = torch.empty_like(v)
-    saved = torch.empty(4 * T * B * H * W, dtype=torch.float32, device=v.device)
+    saved = torch.empty(per * T * B * H * W, dtype=torch.float32, device=v.device)
     if B == 0:
         return out, saved, 0
     ticket = C.c_ulonglong(0)
     with torch.cuda.device(v.device):
-        check(_lib.lib().pnpx_csmri_apg_train(ctx.handle, _p(v), _p(out), _p(y0), _p(m), _p(ps[0]), _p(ps[1]), _p(ps[2]),
-                                              ps[0].shape[1], B, H, W, T, _p(saved), C.byref(ticket), _stream(v)))
+        check(getattr(_lib.lib(), entry)(ctx.handle, _p(v), _p(out), _p(y0), _p(m), _p(ps[0]), _p(ps[1]), _p(ps[2]),
+                                         ps[0].shape[1], B, H, W, T, _p(saved), C.byref(ticket), _stream(v)))
     return out, saved, int(ticket.value)
+
+
+def _csmri_backward3(entry, nvar, per, ctx, y0, mask, params, saved, grad_out, iter_num, ticket):
+    """Fused VJP of the same -> (grad variables, three hyper-parameter gradients, each [B,T])."""
+    g = _vars(grad_out, nvar, True)
+    B, _, H, W, _ = g.shape
+    y0, m = _f32(y0, "y0"), _mask_u8(mask)
+    ps, T = _params(B, *params)
+    T = T if iter_num is None else iter_num
+    if saved.numel() != per * T * B * H * W:
+        raise PnpxError("saved does not belong to a forward of this shape / iteration count")
+    gin = torch.empty_like(g)
+    g0, g1, g2 = (torch.zeros(T, B, dtype=torch.float32, device=g.device) for _ in range(3))
+    if B and T:
+        work = torch.empty(4 * B * H * W, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(getattr(_lib.lib(), entry)(ctx.handle, _p(y0), _p(m), _p(ps[0]), _p(ps[1]), _p(ps[2]), ps[0].shape[1],
+                                             _p(saved), _p(g), _p(gin), _p(g0), _p(g1), _p(g2), _p(work), B, H, W, T,
+                                             int(ticket), _stream(g)))
+    elif B:
+        gin.copy_(g)
+    return gin, g0.t().contiguous(), g1.t().contiguous(), g2.t().contiguous()
+
+
+def csmri_apg_train(ctx, variables, y0, mask, sigma_d, tau, beta, iter_num=None):
+    """pnpx_csmri_apg_train: APGSolver_CSMRI.forward for autograd -> (next state [B,2,H,W,2], saved [4*T*B*H*W], ticket)."""
+    return _csmri_train3("pnpx_csmri_apg_train", 2, 4, ctx, variables, y0, mask, (sigma_d, tau, beta), iter_num)
 
 
 def csmri_apg_backward(ctx, y0, mask, sigma_d, tau, beta, saved, grad_out, iter_num=None, ticket=0):
     """pnpx_csmri_apg_backward -> (grad variables [B,2,H,W,2], grad sigma_d, grad tau, grad beta, each [B,T])."""
-    g = _vars(grad_out, 2, True)
-    B, _, H, W, _ = g.shape
-    y0, m = _f32(y0, "y0"), _mask_u8(mask)
-    ps, T = _params(B, sigma_d, tau, beta)
-    T = T if iter_num is None else iter_num
-    if saved.numel() != 4 * T * B * H * W:
-        raise PnpxError("saved does not belong to a forward of this shape / iteration count")
-    gin = torch.empty_like(g)
-    gs, gt, gb = (torch.zeros(T, B, dtype=torch.float32, device=g.device) for _ in range(3))
-    if B and T:
-        work = torch.empty(4 * B * H * W, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
-            check(_lib.lib().pnpx_csmri_apg_backward(ctx.handle, _p(y0), _p(m), _p(ps[0]), _p(ps[1]), _p(ps[2]),
-                                                     ps[0].shape[1], _p(saved), _p(g), _p(gin), _p(gs), _p(gt), _p(gb),
-                                                     _p(work), B, H, W, T, int(ticket), _stream(g)))
-    elif B:
-        gin.copy_(g)
-    return gin, gs.t().contiguous(), gt.t().contiguous(), gb.t().contiguous()
+    return _csmri_backward3("pnpx_csmri_apg_backward", 2, 4, ctx, y0, mask, (sigma_d, tau, beta), saved, grad_out, iter_num,
+                            ticket)
+
+
+def csmri_redadmm_train(ctx, variables, y0, mask, sigma_d, mu, lamda, iter_num=None):
+    """pnpx_csmri_redadmm_train: REDADMMSolver_CSMRI.forward for autograd -> (next state [B,3,H,W,2], saved [7*T*B*H*W],
+    ticket)."""
+    return _csmri_train3("pnpx_csmri_redadmm_train", 3, 7, ctx, variables, y0, mask, (sigma_d, mu, lamda), iter_num)
+
+
+def csmri_redadmm_backward(ctx, y0, mask, sigma_d, mu, lamda, saved, grad_out, iter_num=None, ticket=0):
+    """pnpx_csmri_redadmm_backward -> (grad variables [B,3,H,W,2], grad sigma_d, grad mu, grad lamda, each [B,T])."""
+    return _csmri_backward3("pnpx_csmri_redadmm_backward", 3, 7, ctx, y0, mask, (sigma_d, mu, lamda), saved, grad_out,
+                            iter_num, ticket)
 
 
 def csmri_hqs(ctx, variables, y0, mask, sigma_d, mu, iter_num=None):

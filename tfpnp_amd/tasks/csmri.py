@@ -134,17 +134,24 @@ class REDADMMSolver_CSMRI(CSMRIMixin, REDADMMSolver):
     def forward(self, inputs, parameters, iter_num=None):
         variables, (y0, mask) = inputs
         sigma_d, mu, lamda = parameters
-        if A.needs_grad(variables, sigma_d, mu, lamda):
-            x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
-            B, m = x.shape[0], (mask != 0).unsqueeze(-1)
-            for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):      # tasks/csmri/solver.py:183-200
-                _mu, _la = _v5(mu[:, i], B), _v5(lamda[:, i], B)
-                x_half = A.r2c(self.prox_mapping(A.c2r(x), sigma_d[:, i]))
-                x = (_la * x_half + _mu * (z - u)) / (_mu + _la)
-                z = A.fft2(_blend(A.fft2(x + u), y0, m, _mu), inverse=True)
-                u = u + x - z
-            return torch.cat([x, z, u], dim=1)
+        if A.needs_grad(variables, sigma_d, mu, lamda):      # training path: native forward + fused native VJP (csmri.hip)
+            return T.call("csmri_redadmm_train", variables, y0, mask, sigma_d, mu, lamda,
+                          -1 if iter_num is None else iter_num, self._ctx(variables).cid)[0]
         return T.call("csmri_redadmm", variables, y0, mask, sigma_d, mu, lamda, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
+
+
+    def _forward_autograd(self, variables, y0, mask, sigma_d, mu, lamda, iter_num):
+        """The reference's loop (tasks/csmri/solver.py:183-200) from differentiable building blocks: what the fused native VJP
+        (pnpx_csmri_redadmm_backward) is tested against."""
+        x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
+        B, m = x.shape[0], (mask != 0).unsqueeze(-1)
+        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
+            _mu, _la = _v5(mu[:, i], B), _v5(lamda[:, i], B)
+            x_half = A.r2c(self.prox_mapping(A.c2r(x), sigma_d[:, i]))
+            x = (_la * x_half + _mu * (z - u)) / (_mu + _la)
+            z = A.fft2(_blend(A.fft2(x + u), y0, m, _mu), inverse=True)
+            u = u + x - z
+        return torch.cat([x, z, u], dim=1)
 
 
 class AMPSolver_CSMRI(CSMRIMixin, AMPSolver):

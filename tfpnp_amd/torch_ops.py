@@ -487,6 +487,62 @@ def _apg_train_bwd(ctx, g_out, _g_saved, _g_ticket):
 csmri_apg_train.register_autograd(_apg_train_bwd, setup_context=_apg_train_setup)
 
 
+@_lib_def("pnpx::csmri_redadmm_train", mutates_args=(), device_types="cuda")
+def csmri_redadmm_train(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, lamda: Tensor,
+                    iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """Differentiable REDADMMSolver_CSMRI.forward (tasks/csmri/solver.py:172-204); autograd = pnpx_csmri_redadmm_backward."""
+    out, saved, ticket = ops.csmri_redadmm_train(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, lamda, _it(iter_num))
+    return out, saved, torch.tensor([ticket], dtype=torch.int64)
+
+
+@csmri_redadmm_train.register_fake
+def _(variables, y0, mask, sigma_d, mu, lamda, iter_num, ctx):
+    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
+    B, _, H, W, _ = variables.shape
+    return (torch.empty_like(variables, memory_format=torch.contiguous_format),
+            torch.empty((7 * T * B * H * W,), dtype=variables.dtype, device=variables.device),
+            torch.empty((1,), dtype=torch.int64))
+
+
+@_lib_def("pnpx::csmri_redadmm_backward", mutates_args=(), device_types="cuda")
+def csmri_redadmm_backward(y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, lamda: Tensor, saved: Tensor, ticket: Tensor,
+                       grad_out: Tensor, iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """VJP of csmri_redadmm_train wrt (variables, sigma_d[:, :T], mu[:, :T], lamda[:, :T])."""
+    return ops.csmri_redadmm_backward(_ctx(ctx, grad_out), y0, mask, sigma_d, mu, lamda, saved, grad_out, _it(iter_num),
+                                  ticket=int(ticket[0]))
+
+
+@csmri_redadmm_backward.register_fake
+def _(y0, mask, sigma_d, mu, lamda, saved, ticket, grad_out, iter_num, ctx):
+    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
+    B = grad_out.shape[0]
+    e = lambda: torch.empty((B, T), dtype=grad_out.dtype, device=grad_out.device)
+    return torch.empty_like(grad_out, memory_format=torch.contiguous_format), e(), e(), e()
+
+
+def _redadmm_train_setup(ctx, inputs, output):
+    _, y0, mask, sigma_d, mu, lamda, ctx.iter_num, cid = inputs
+    _pin(ctx, cid, y0)
+    ctx.save_for_backward(y0, mask, sigma_d, mu, lamda, output[1], output[2])
+
+
+def _redadmm_train_bwd(ctx, g_out, _g_saved, _g_ticket):
+    y0, mask, sigma_d, mu, lamda, saved, ticket = ctx.saved_tensors
+    gv, gs, gm, gl = torch.ops.pnpx.csmri_redadmm_backward(y0, mask, sigma_d, mu, lamda, saved, ticket, g_out.contiguous(),
+                                                       ctx.iter_num, ctx.cid)
+
+    def like(g, p):
+        full = torch.zeros_like(p)
+        if p.numel():
+            full.view(p.shape[0], -1)[:, :g.shape[1]] = g
+        return full
+
+    return gv, None, None, like(gs, sigma_d), like(gm, mu), like(gl, lamda), None, None
+
+
+csmri_redadmm_train.register_autograd(_redadmm_train_bwd, setup_context=_redadmm_train_setup)
+
+
 @_lib_def("pnpx::csmri_hqs", mutates_args=(), device_types="cuda")
 def csmri_hqs(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int, ctx: int) -> Tensor:
     """HQSSolver_CSMRI.forward (tasks/csmri/solver.py:64-89)."""
