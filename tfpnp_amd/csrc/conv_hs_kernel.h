@@ -904,7 +904,10 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
 #endif
   if (grid > ntiles) grid = ntiles;
   if (grid >= 8) grid -= grid % 8;          // whole XCD groups (the kernel falls back to a plain walk otherwise)
-  if (a.nct > 1 && (grid / 8) % a.nct != 0 && grid >= 8 * a.nct) grid -= grid % (8 * a.nct);
+  // the XCD-grouped walk (>= 32 pixel regions) wants nct | grid / 8 so that a workgroup keeps its cout tile; the plain walk of
+  // small launches has no such need, and rounding there would leave CUs idle (192 tiles on 128 workgroups: 2 rounds instead of 1)
+  const bool grouped = (long long)a.tilesX * a.tilesY * a.B >= 32;
+  if (grouped && a.nct > 1 && (grid / 8) % a.nct != 0 && grid >= 8 * a.nct) grid -= grid % (8 * a.nct);
 #ifdef PNPX_TUNING   // PNPX_HS_WGT=<file>: per-workgroup start / end stamps of every launch (tools/wg_spread.py)
   static unsigned long long* wbuf = nullptr;
   const char* wfile = getenv("PNPX_HS_WGT");

@@ -6,8 +6,10 @@ from tfpnp_amd.pnp import UNetDenoiser2D
 from tfpnp_amd.tasks import csmri
 dev = torch.device("cuda:0")
 den = UNetDenoiser2D(state_dict=synth.make_unet_params(0))
+if os.environ.get("CHAINS"):
+    den.context(dev).set_option("chains", int(os.environ["CHAINS"]))
 g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-for (B, H) in [(1, 128), (1, 256), (4, 128), (4, 256), (12, 256)]:
+for (B, H) in [(1, 128), (1, 256), (4, 128), (4, 256), (6, 256), (12, 256), (24, 256)]:
     d = synth.make_csmri_batch(B, H, H)
     sol = csmri.ADMMSolver_CSMRI(den); v0 = sol.reset({"x0": g(d["x0"])})
     par = (torch.full((B, 5), 0.1, device=dev), torch.full((B, 5), 0.5, device=dev))

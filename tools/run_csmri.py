@@ -12,6 +12,8 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 48
 dev = torch.device("cuda:0")
 den = UNetDenoiser2D(state_dict=synth.make_unet_params(0))
 den.context(dev).set_option("fft_affine", aff)
+if os.environ.get("CHAINS"):
+    den.context(dev).set_option("chains", int(os.environ["CHAINS"]))
 if os.environ.get("FFT_TILE"):
     den.context(dev).set_option("fft_tile", int(os.environ["FFT_TILE"]))
 g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
