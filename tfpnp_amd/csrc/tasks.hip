@@ -180,11 +180,17 @@ __global__ void psnr_final_kernel(const float* __restrict__ part, float* __restr
 // (cos, sin) pairs computed on the host in double precision.
 // EIGHT lanes per ray (b, view, detector): lane dk of a ray takes the samples k0 + dk, k0 + dk + 8, ...; a wave is 8
 // adjacent detector bins x 8 consecutive steps, i.e. one gather instruction touches an 8 x 8-pixel rotated patch (<= ~12
-// image rows) instead of a 64-pixel line segment (up to 45 rows): the kernel is bound by cache lines per gather, not by
-// bytes (r2: 302 us at 32 x 256^2 x 30 views with one lane per ray).  The eight partial sums are combined by a fixed
+// image rows) instead of a 64-pixel line segment (up to 45 rows).  The image is read from two zero-bordered copies made per call
+// (radon_pad_kernel: plain and transposed, RADON_PAD pixels of border): with the border standing in for "outside the image"
+// a sample needs no validity masks or clamped addresses (an outside pixel contributes v * w = +0, exactly the oracle's skipped
+// term), and its two horizontally adjacent pixels come from ONE 8-byte load -- 2 gathers and ~32 vector instructions per sample
+// instead of 4 and ~60.  History at 32 x 256^2 x 30 views: one lane per ray 302 us (r2), eight lanes per ray 192 + 6 us (r3a),
+// an LDS-staged 48 x 48 bounding box per 32 x 32-sample patch 269 us (the box of a rotated square is twice its area and its
+// fill costs more instructions than it saves), this form: see DESIGN.md.  The eight partial sums are combined by a fixed
 // xor-butterfly, so results are deterministic (summation order differs from the oracle's sequential one: ~1e-7).
 constexpr int RADON_LPR = 8;   // lanes per ray
-__global__ void radon_forward_kernel(const float* __restrict__ img, size_t istride, const float* __restrict__ imgT,
+constexpr int RADON_PAD = 4;   // zero border of the padded copies: the k interval is computed loosely (widened by 2 steps)
+__global__ void radon_forward_kernel(const float* __restrict__ imgP, const float* __restrict__ imgPT,
                                      const float* __restrict__ sub, float* __restrict__ sino,
                                      const float2* __restrict__ cs, int R, int V, int det, int B) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,17 +206,20 @@ __global__ void radon_forward_kernel(const float* __restrict__ img, size_t istri
   const float sp = subr((float)s, half);
   // adjacent lanes are adjacent bins: their samples lie 1 px apart along (c, sn).  Read the transposed copy when
   // that direction is closer to the y axis, so a wave's loads stay within few cache lines.
-  const bool tr = imgT && fabsf(sn) > fabsf(c);
-  const float* im = tr ? imgT + (size_t)b * R * R : img + (size_t)b * istride;
+  const bool tr = fabsf(sn) > fabsf(c);
+  const int RP = R + 2 * RADON_PAD;
+  const float* im = (tr ? imgPT : imgP) + (size_t)b * RP * RP + (size_t)RADON_PAD * RP + RADON_PAD;
   const float sc = mulr(sp, c), ss = mulr(sp, sn);
   // Only samples with px, py in [-1, R) touch the image.  Both coordinates are affine in k, so the contributing k
-  // form one interval; it is computed loosely (widened by 2) and every sample still carries its exact validity
-  // mask, so the sum is the oracle's term by term (skipped samples add +0).  The loop body is branch-free with
-  // clamped addresses so that the loads of several samples can be in flight together.
+  // form one interval; it is computed loosely (widened by 2: still inside the zero border) and a coordinate that does not
+  // move with k (an axis-parallel ray) is checked once.
   int k0 = 0, k1 = det;
   {
     auto clip = [&](float base, float slope) {   // base + (k - half) * slope in [-1, R)
-      if (fabsf(slope) < 1e-6f) return;
+      if (fabsf(slope) < 1e-6f) {
+        if (!(base >= -1.f && base < (float)R)) k1 = 0;
+        return;
+      }
       const float ka = (-1.f - base) / slope + half, kb = ((float)R - base) / slope + half;
       const float lo = fminf(ka, kb), hi = fmaxf(ka, kb);
       k0 = max(k0, (int)floorf(lo) - 2);
@@ -219,8 +228,12 @@ __global__ void radon_forward_kernel(const float* __restrict__ img, size_t istri
     clip(sc + off, -sn);
     clip(ss + off, c);
   }
+  typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
   float acc = 0.f;
-#pragma unroll 2
+#ifndef RADON_UNROLL
+#define RADON_UNROLL 2
+#endif
+#pragma unroll RADON_UNROLL
   for (int k = k0 + dk; k < k1; k += RADON_LPR) {
     const float t = subr((float)k, half);
     const float px = addr(subr(sc, mulr(t, sn)), off);
@@ -229,21 +242,16 @@ __global__ void radon_forward_kernel(const float* __restrict__ img, size_t istri
     const int x0 = (int)fx0, y0 = (int)fy0;
     const float fx = subr(px, fx0), fy = subr(py, fy0);
     const float wx0 = subr(1.f, fx), wy0 = subr(1.f, fy);
-    const bool in = !(x0 < -1 || x0 >= R || y0 < -1 || y0 >= R);
-    const bool xa = in && x0 >= 0, xb = in && x0 + 1 < R, ya = y0 >= 0, yb = y0 + 1 < R;
-    const int cx0 = min(max(x0, 0), R - 1), cx1 = min(max(x0 + 1, 0), R - 1);
-    const int cy0 = min(max(y0, 0), R - 1), cy1 = min(max(y0 + 1, 0), R - 1);
-    const int r0 = tr ? cx0 : cy0, r1 = tr ? cx1 : cy1, q0 = tr ? cy0 : cx0, q1 = tr ? cy1 : cx1;
-    // (row, col) = (y, x) in the image, (x, y) in its transpose: v[y][x] for y in {0,1}, x in {0,1}
-    const float v00 = im[r0 * R + q0];
-    const float v01 = tr ? im[r1 * R + q0] : im[r0 * R + q1];
-    const float v10 = tr ? im[r0 * R + q1] : im[r1 * R + q0];
-    const float v11 = im[r1 * R + q1];
+    // plain copy: row y0 holds (v00, v01), row y0 + 1 (v10, v11); transposed copy: row x0 holds (v00, v10), row x0 + 1 (v01, v11)
+    const float* p = tr ? im + x0 * RP + y0 : im + y0 * RP + x0;
+    const f32x2u r0 = *reinterpret_cast<const f32x2u*>(p);
+    const f32x2u r1 = *reinterpret_cast<const f32x2u*>(p + RP);
+    const float v00 = r0[0], v01 = tr ? r1[0] : r0[1], v10 = tr ? r0[1] : r1[0], v11 = r1[1];
     float sm = 0.f;
-    sm = addr(sm, (ya && xa) ? mulr(v00, mulr(wx0, wy0)) : 0.f);
-    sm = addr(sm, (ya && xb) ? mulr(v01, mulr(fx, wy0)) : 0.f);
-    sm = addr(sm, (yb && xa) ? mulr(v10, mulr(wx0, fy)) : 0.f);
-    sm = addr(sm, (yb && xb) ? mulr(v11, mulr(fx, fy)) : 0.f);
+    sm = addr(sm, mulr(v00, mulr(wx0, wy0)));
+    sm = addr(sm, mulr(v01, mulr(fx, wy0)));
+    sm = addr(sm, mulr(v10, mulr(wx0, fy)));
+    sm = addr(sm, mulr(v11, mulr(fx, fy)));
     acc = addr(acc, sm);
   }
   acc = addr(acc, __shfl_xor(acc, 1, 64));
@@ -251,28 +259,35 @@ __global__ void radon_forward_kernel(const float* __restrict__ img, size_t istri
   acc = addr(acc, __shfl_xor(acc, 4, 64));
   if (live && dk == 0) sino[i] = sub ? subr(acc, sub[i]) : acc;
 }
-// [B][R][R] -> transposed copy (32x32 LDS tiles).  The projector reads it for the views whose detector axis is
-// closer to vertical than to horizontal, so that the 64 lanes of a wave (adjacent bins) always walk along the
-// contiguous dimension: 0.49 -> see DESIGN.md (L1 line-rate bound: lines touched per load ~ 64*min(|sin|,|cos|)).
-__global__ __launch_bounds__(256) void transpose_image_kernel(const float* __restrict__ img, size_t istride,
-                                                              float* __restrict__ out, int R) {
+// [B][R][R] -> zero-bordered plain and transposed copies [B][R + 2 PAD][R + 2 PAD] (32 x 32 LDS tiles over the padded grid).
+__global__ __launch_bounds__(256) void radon_pad_kernel(const float* __restrict__ img, size_t istride,
+                                                        float* __restrict__ outP, float* __restrict__ outPT, int R) {
   __shared__ float tile[32][33];
-  const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const int RP = R + 2 * RADON_PAD;
+  const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;   // padded coordinates
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float* im = img + (size_t)b * istride;
-  for (int r = ty; r < 32; r += 8)
-    if (y0 + r < R && x0 + tx < R) tile[r][tx] = im[(size_t)(y0 + r) * R + x0 + tx];
+  float* oP = outP + (size_t)b * RP * RP;
+  float* oT = outPT + (size_t)b * RP * RP;
+  for (int r = ty; r < 32; r += 8) {
+    const int y = y0 + r - RADON_PAD, x = x0 + tx - RADON_PAD;
+    const float val = (y >= 0 && y < R && x >= 0 && x < R) ? im[(size_t)y * R + x] : 0.f;
+    tile[r][tx] = val;
+    if (y0 + r < RP && x0 + tx < RP) oP[(size_t)(y0 + r) * RP + x0 + tx] = val;
+  }
   __syncthreads();
-  float* o = out + (size_t)b * R * R;
   for (int r = ty; r < 32; r += 8)
-    if (x0 + r < R && y0 + tx < R) o[(size_t)(x0 + r) * R + y0 + tx] = tile[tx][r];
+    if (x0 + r < RP && y0 + tx < RP) oT[(size_t)(x0 + r) * RP + y0 + tx] = tile[tx][r];
 }
+// padded copies: 2 * B * (R + 2 PAD)^2 floats at `pad`
+static size_t radon_pad_floats(int B, int R) { return 2 * (size_t)B * (R + 2 * RADON_PAD) * (R + 2 * RADON_PAD); }
 static void launch_radon_forward(const float* img, size_t istride, const float* sub, float* sino, const float2* cs,
-                                 float* imgT, int R, int V, int det, int B, hipStream_t s) {
-  hipLaunchKernelGGL(transpose_image_kernel, dim3((R + 31) / 32, (R + 31) / 32, B), dim3(256), 0, s, img, istride, imgT,
-                     R);
-  hipLaunchKernelGGL(radon_forward_kernel, dim3((unsigned)(((size_t)B * V * det * RADON_LPR + 255) / 256)), dim3(256), 0, s, img,
-                     istride, imgT, sub, sino, cs, R, V, det, B);
+                                 float* pad, int R, int V, int det, int B, hipStream_t s) {
+  const int RP = R + 2 * RADON_PAD;
+  float* padT = pad + (size_t)B * RP * RP;
+  hipLaunchKernelGGL(radon_pad_kernel, dim3((RP + 31) / 32, (RP + 31) / 32, B), dim3(256), 0, s, img, istride, pad, padT, R);
+  hipLaunchKernelGGL(radon_forward_kernel, dim3((unsigned)(((size_t)B * V * det * RADON_LPR + 255) / 256)), dim3(256), 0, s, pad,
+                     padT, sub, sino, cs, R, V, det, B);
 }
 // Pixel-driven backprojection: one thread per pixel, linear interpolation along the detector.
 __global__ void radon_backproject_kernel(const float* __restrict__ sino, float* __restrict__ img,
@@ -527,12 +542,12 @@ int pnpx_radon_forward(pnpx_ctx* ctx, const float* img, float* sino, int B, int 
   REQUIRE(img && sino && B > 0 && R > 0 && n_view > 0, "pnpx_radon_forward: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
   void* p;
-  PNPX_TRY(ctx_scratch(ctx, sizeof(float2) * n_view + (size_t)B * R * R * sizeof(float) + 8192, &p));
+  PNPX_TRY(ctx_scratch(ctx, sizeof(float2) * n_view + radon_pad_floats(B, R) * sizeof(float) + 8192, &p));
   Carver cv{static_cast<char*>(p)};
   const float2* cs;
   int det;
   PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &cs, &det));
-  float* imgT = cv.take<float>((size_t)B * R * R);
+  float* imgT = cv.take<float>(radon_pad_floats(B, R));
   launch_radon_forward(img, (size_t)R * R, nullptr, sino, cs, imgT, R, n_view, det, B, s);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
@@ -571,7 +586,7 @@ int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
   }
   const int det = pnpx_radon_det_count(R);
   void* p;
-  PNPX_TRY(ctx_scratch(ctx, (4 * n + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 16384, &p));
+  PNPX_TRY(ctx_scratch(ctx, (3 * n + radon_pad_floats(B, R) + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 16384, &p));
   Carver cv{static_cast<char*>(p)};
   const float2* cs;
   int det2;
@@ -580,7 +595,7 @@ int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
   float* xr = cv.take<float>(n);
   float* g = cv.take<float>(n);
   float* sino = cv.take<float>((size_t)B * n_view * det);
-  float* imgT = cv.take<float>(n);
+  float* imgT = cv.take<float>(radon_pad_floats(B, R));
   const float op2 = (float)((double)opnorm * (double)opnorm);  // backprojection / opnorm**2   transforms.py:476-477
   hipLaunchKernelGGL(real_diff_slots_kernel, g1(n), dim3(256), 0, s, vars_in + HW, vars_in + 2 * HW, is, d, HW, B);
   PNPX_LAUNCH_CHECK();
@@ -616,7 +631,7 @@ int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float
   }
   const int det = pnpx_radon_det_count(R);
   void* p;
-  PNPX_TRY(ctx_scratch(ctx, (3 * n + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 16384, &p));
+  PNPX_TRY(ctx_scratch(ctx, (2 * n + radon_pad_floats(B, R) + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 16384, &p));
   Carver cv{static_cast<char*>(p)};
   const float2* cs;
   int det2;
@@ -624,7 +639,7 @@ int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float
   float* d = cv.take<float>(n);
   float* g = cv.take<float>(n);
   float* sino = cv.take<float>((size_t)B * n_view * det);
-  float* imgT = cv.take<float>(n);
+  float* imgT = cv.take<float>(radon_pad_floats(B, R));
   const float op2 = (float)((double)opnorm * (double)opnorm);
   for (int i = 0; i < T; ++i) {
     const float* xi = (i == 0) ? vars_in : vars_out;
