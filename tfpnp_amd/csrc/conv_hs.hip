@@ -69,7 +69,10 @@ HsChoice hs_choose(int mt, const ConvHsArgs& a, int B) {
       c.nbw = rows / 4;
     }
   }
-  if (mt == 32 && a.w_mt == 32) c.nbw = 4;
+  if (mt == 32 && a.w_mt == 32) {   // 32-cout layers: 16-row tiles unless a half-empty last round makes 8-row tiles cheaper
+    const double c16 = (double)((blocks(16) + 255) / 256) * 4.3, c8 = (double)((blocks(8) + 255) / 256) * 2.3;
+    c.nbw = (c8 < 0.9 * c16) ? 2 : 4;
+  }
   // two waves per SIMD (same tile, half the blocks per wave) once every workgroup has at least two tiles to walk
   if (c.nbw >= 2 && blocks(4 * c.nbw) >= 512 && !(a.pool_out && c.nbw < 4)) c = HsChoice{c.nbw / 2, 8};
 #ifdef PNPX_TUNING
@@ -196,7 +199,10 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   if (fuse.wreg && L.mt == 32 && L.cout == 32 && G0 == 4 && G1 == 0 && W >= 32) {
     const bool w8 = fuse.wreg == 2;
     const long long tiles = (long long)((W + 31) / 32) * ((H + 15) / 16) * B;   // both shapes: 16-row tiles
-    if (tiles >= 256) {
+    // (a half-empty last round costs more than the registers buy: 384 tiles on 256 workgroups run 25 % longer than they should,
+    // the generic path then picks 8-row tiles)
+    const bool full_rounds = tiles * 100 >= ((tiles + 255) / 256) * 256 * 85;
+    if (tiles >= 256 && full_rounds) {
       if (a.outc_w) return w8 ? launch_hs_cfg<32, 2, 32, 8, EPI_OUTC, 0, 1>(a, B, s) : launch_hs_cfg<32, 4, 32, 4, EPI_OUTC, 0, 1>(a, B, s);
       return w8 ? launch_hs_cfg<32, 2, 32, 8, EPI_ACT, 0, 1>(a, B, s) : launch_hs_cfg<32, 4, 32, 4, EPI_ACT, 0, 1>(a, B, s);
     }
