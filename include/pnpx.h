@@ -291,6 +291,16 @@ int pnpx_csmri_redadmm_backward(pnpx_ctx* ctx, const float* y0, const uint8_t* m
 int pnpx_pr_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0,
                   const float* mask, const float* sigma_d, const float* mu, const float* tau,
                   int param_stride, int B, int S, int H, int W, int T, void* stream);
+/* Training path of IADMMSolver_PR.forward (same contract): `saved` = (2*S + 5)*T*B*H*W floats (denoiser inputs, the S
+ * k-space images before the residual, g + mu (z - (x + u)) and z - (x + u) as complex); grads wrt (cat(x, z, u), sigma_d,
+ * mu, tau), each hyper-parameter gradient [T][B]; work = 4*B*H*W floats.  ticket as in pnpx_csmri_admm_train. */
+int pnpx_pr_iadmm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const float* mask,
+                        const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int S,
+                        int H, int W, int T, float* saved, unsigned long long* ticket, void* stream);
+int pnpx_pr_iadmm_backward(pnpx_ctx* ctx, const float* y0, const float* mask, const float* sigma_d, const float* mu,
+                           const float* tau, int param_stride, const float* saved, const float* grad_vars_out,
+                           float* grad_vars_in, float* grad_sigma_d, float* grad_mu, float* grad_tau, float* work,
+                           int B, int S, int H, int W, int T, unsigned long long ticket, void* stream);
 /* ADMMSolver_SPI.forward (tasks/spi/solver.py:17-52).
  * vars [B,3,H,W] real; x0 [B,1,H,W]; Kmap [B,1,H,W] (K/10 broadcast, only [b,0,0,0] is read). */
 int pnpx_spi_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* x0,

@@ -518,6 +518,41 @@ def test_pr_solver_gradients(den, oden32, oden64):
         assert e < 2e-2, key
 
 
+def test_pr_fused_vjp_vs_composed_autograd(den):
+    """IADMMSolver_PR under autograd: pnpx_pr_iadmm_train / _backward against the composed path (the |Az| Jacobian of the
+    data step evaluated at the saved k-space images; three hyper-parameters)."""
+    from tfpnp_amd.tasks import pr
+    sol = pr.IADMMSolver_PR(den)
+    B, H, W, S, T = 3, 32, 32, 4, 3
+    d = synth.make_pr_batch(B, H, W, S=S, alpha=9.0, seed=81)
+    a = csmri_actions(B, 4, 82, ("sigma_d", "mu", "tau"))
+    a["tau"] = (a["tau"] * 0.5).astype(np.float32)
+    v0 = sol.reset({"x0": g(d["x0"])})
+    v0 = v0 + 0.05 * torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(7))
+    wts = torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(8))
+    y0, m = g(d["y0"]), g(d["mask"])
+
+    def grads(fn):
+        leaves = [v0.clone().requires_grad_(True), g(a["sigma_d"], True), g(a["mu"], True), g(a["tau"], True)]
+        out = fn(*leaves)
+        (out * wts).sum().backward()
+        return out.detach(), [l.grad for l in leaves]
+
+    out_f, gf = grads(lambda v, s_, m_, t_: sol((v, (y0, m)), (s_, m_, t_), iter_num=T))
+    out_c, gc = grads(lambda v, s_, m_, t_: sol._forward_autograd(v, y0, m, s_, m_, t_, T))
+    with torch.no_grad():
+        assert rel(out_f, sol((v0, (y0, m)), (g(a["sigma_d"]), g(a["mu"]), g(a["tau"])), iter_num=T)) < 1e-6
+    assert rel(out_f, out_c) < 1e-5
+    for n, x, y in zip(("variables", "sigma_d", "mu", "tau"), gf, gc):
+        print(f"  PR fused vs composed d/d{n}: {rel(x, y):.2e}")
+        assert rel(x, y) < 2e-2 and x.shape == y.shape, n
+    assert float(gf[0][:, 0].abs().max()) == 0.0          # an iteration never reads its x
+    for k in (1, 2, 3):
+        assert float(gf[k][:, T:].abs().max()) == 0.0 and float(gf[k][:, :T].abs().min()) > 0
+    _, gf2 = grads(lambda v, s_, m_, t_: sol((v, (y0, m)), (s_, m_, t_), iter_num=T))
+    assert all(torch.equal(x, y) for x, y in zip(gf, gf2))
+
+
 def test_spi_solver_gradients(den, oden32):
     """One iteration from the same state (the bisection prox is discontinuous, see test_spi_golden)."""
     from oracle import pnp_oracle as O

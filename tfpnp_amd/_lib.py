@@ -89,6 +89,10 @@ _SIGNATURES = {
     "pnpx_csmri_redadmm_backward": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P] +
                                     [C.c_int] * 4 + [C.c_ulonglong, c_void_p]),
     "pnpx_csmri_redadmm": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, _P, _P] + [C.c_int] * 5 + [c_void_p]),
+    "pnpx_pr_iadmm_train": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, _P, _P] + [C.c_int] * 6 +
+                            [_P, C.POINTER(C.c_ulonglong), c_void_p]),
+    "pnpx_pr_iadmm_backward": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P] + [C.c_int] * 5 +
+                               [C.c_ulonglong, c_void_p]),
     "pnpx_pr_iadmm": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, _P, _P] + [C.c_int] * 6 + [c_void_p]),
     "pnpx_spi_admm": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, _P] + [C.c_int] * 5 + [c_void_p]),
     "pnpx_radon_det_count": (C.c_int, [C.c_int]),

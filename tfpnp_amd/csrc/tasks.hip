@@ -82,6 +82,120 @@ __global__ void pr_update_kernel(const float2* __restrict__ I, const float2* __r
   d[i] = subr(zn.x, un.x);
   if (write_x) xout[(size_t)b * istride + r] = make_float2(xv, 0.f);
 }
+// ---- training path of IADMMSolver_PR (pnpx_pr_iadmm_train / _backward)
+struct MidPrResidualSave {  // MidPrResidual that also keeps w = F(mask_s z) of every (item, s)
+  const float* y0;
+  float2* wsave;   // [B*S][HW]
+  int W, HW;
+  __device__ float2 operator()(int img, int ky, int kx, float2 v) const {
+    const size_t o = (size_t)img * HW + (size_t)ky * W + kx;
+    wsave[o] = v;
+    const float yh = sqrtf(addr(mulr(v.x, v.x), mulr(v.y, v.y)));
+    const float q = divr(subr(yh, y0[o]), yh);
+    return make_float2(mulr(q, v.x), mulr(q, v.y));
+  }
+};
+// Adjoint of r = w - y0 w / |w| at the saved w (the Jacobian is symmetric): h = c - y0 (c - wh (wh . c)) / |w|, wh = w / |w|
+struct MidPrResidualAdjoint {
+  const float* y0;
+  const float2* wsave;
+  int W, HW;
+  __device__ float2 operator()(int img, int ky, int kx, float2 c) const {
+    const size_t o = (size_t)img * HW + (size_t)ky * W + kx;
+    const float2 w = wsave[o];
+    const float yh = sqrtf(w.x * w.x + w.y * w.y);
+    const float2 wh = make_float2(w.x / yh, w.y / yh);
+    const float dot = wh.x * c.x + wh.y * c.y;
+    const float f = y0[o] / yh;
+    return make_float2(c.x - f * (c.x - wh.x * dot), c.y - f * (c.y - wh.y * dot));
+  }
+};
+struct LoadCdpDiff {  // complex_mul(a[b] - c[b], mask[b,s]): the cotangent e = gz' - gu' entering the data step's adjoint
+  const float2 *a, *c;
+  size_t xstride;
+  const float2* mask;
+  int S, W, HW;
+  __device__ float2 operator()(int img, int y, int xx) const {
+    const int b = img / S;
+    const size_t r = (size_t)y * W + xx;
+    const float2 p = a[(size_t)b * xstride + r], q = c[(size_t)b * xstride + r], m = mask[(size_t)img * HW + r];
+    const float2 e = make_float2(p.x - q.x, p.y - q.y);
+    return make_float2(e.x * m.x - e.y * m.y, e.x * m.y + e.y * m.x);
+  }
+};
+// pr_update_kernel of the training forward: also keeps G = g + mu (z - (x + u)) (= (z - z') / tau) and q2 = z - (x + u)
+__global__ void pr_update_save_kernel(const float2* __restrict__ I, const float2* __restrict__ mask,
+                                      const float* __restrict__ xr, const float2* zin, const float2* uin, float2* xout,
+                                      float2* zout, float2* uout, size_t istride, float* __restrict__ d,
+                                      const float* __restrict__ mu, const float* __restrict__ tau, int stride, int S, int HW,
+                                      int B, int write_x, float2* __restrict__ Gs, float2* __restrict__ q2s) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const int b = (int)(i / HW);
+  const size_t r = i - (size_t)b * HW;
+  const float2 g = cdp_adjoint_px(I, mask, b, S, HW, r);
+  const float m = mu[(size_t)b * stride], t = tau[(size_t)b * stride];
+  const float2 z = zin[(size_t)b * istride + r], u = uin[(size_t)b * istride + r];
+  const float xv = xr[i];
+  const float2 q2 = make_float2(subr(z.x, addr(xv, u.x)), subr(z.y, addr(0.f, u.y)));
+  const float2 G = make_float2(addr(g.x, mulr(m, q2.x)), addr(g.y, mulr(m, q2.y)));
+  const float2 zn = make_float2(subr(z.x, mulr(t, G.x)), subr(z.y, mulr(t, G.y)));
+  const float2 un = make_float2(subr(addr(u.x, xv), zn.x), subr(addr(u.y, 0.f), zn.y));
+  zout[(size_t)b * istride + r] = zn;
+  uout[(size_t)b * istride + r] = un;
+  d[i] = subr(zn.x, un.x);
+  if (write_x) xout[(size_t)b * istride + r] = make_float2(xv, 0.f);
+  Gs[i] = G;
+  q2s[i] = q2;
+}
+// Backward of one PR iteration after the data step's adjoint I' (per (item, s), image domain), J = mean_s conj(mask_s) I'_s:
+//   e = gz' - gu';  gz = (1 - tau mu) e - tau J;  t = tau mu e;  cotangent of the denoiser output = Re(gx' + gu' + t);
+//   gu = gu' + t;  gx = 0 (an iteration never reads its x);  d/d tau = -<e, G>;  d/d mu = -tau <e, q2>
+__global__ void pr_adjoint_kernel(const float2* __restrict__ I, const float2* __restrict__ mask, float2* g, size_t istride,
+                                  const float2* __restrict__ Gs, const float2* __restrict__ q2s,
+                                  const float* __restrict__ mu, const float* __restrict__ tau, int stride, int S, int HW, int B,
+                                  float* __restrict__ gxr, float* __restrict__ c_tau, float* __restrict__ c_mu) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const int b = (int)(i / HW);
+  const size_t r = i - (size_t)b * HW;
+  const float2 J = cdp_adjoint_px(I, mask, b, S, HW, r);
+  const float m = mu[(size_t)b * stride], t = tau[(size_t)b * stride];
+  float2* gi = g + (size_t)b * istride + r;
+  const float2 gx = gi[0], gz = gi[HW], gu = gi[2 * HW];
+  const float2 e = make_float2(gz.x - gu.x, gz.y - gu.y);
+  const float tm = t * m;
+  const float2 G = Gs[i], q2 = q2s[i];
+  c_tau[i] = -(e.x * G.x + e.y * G.y);
+  c_mu[i] = -t * (e.x * q2.x + e.y * q2.y);
+  gxr[i] = gx.x + gu.x + tm * e.x;
+  gi[0] = make_float2(0.f, 0.f);
+  gi[HW] = make_float2((1.f - tm) * e.x - t * J.x, (1.f - tm) * e.y - t * J.y);
+  gi[2 * HW] = make_float2(gu.x + tm * e.x, gu.y + tm * e.y);
+}
+// ... and after the denoiser's VJP gd (d = Re(z - u)): gz.x += gd, gu.x -= gd
+__global__ void pr_adjoint_finish_kernel(const float* __restrict__ gd, float2* g, size_t istride, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  float2* gi = g + b * istride + r;
+  gi[HW].x += gd[i];
+  gi[2 * HW].x -= gd[i];
+}
+// out[b] = sum of the HW values of item b, fixed summation order (deterministic)
+__global__ void __launch_bounds__(256) pr_item_sum_kernel(const float* __restrict__ c, float* __restrict__ out, int HW) {
+  __shared__ float sh[256];
+  const float* p = c + (size_t)blockIdx.x * HW;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) a += p[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
 __global__ void real_of_diff_kernel(const float2* __restrict__ a, const float2* __restrict__ c, size_t istride,
                                     float* __restrict__ d, int HW, int B) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -417,14 +531,15 @@ int pnpx_cdp_backward(pnpx_ctx* ctx, const float* y, const float* mask, float* o
   return PNPX_OK;
 }
 
-int pnpx_pr_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const float* mask,
-                  const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int S, int H, int W,
-                  int T, void* stream) {
-  LOCK_CTX(ctx);
-  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+// IADMMSolver_PR.forward; `saved` != NULL (training path): per iteration the denoiser input d_i [T][n], w = F(mask_s z) before the
+// residual [T][S n][2], G = g + mu (z - (x + u)) [T][n][2], q2 = z - (x + u) [T][n][2]  (n = B*H*W); activations parked
+// (ticket + i).
+static int pr_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const float* mask,
+                      const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int S, int H, int W,
+                      int T, float* saved, unsigned long long* ticket_out, hipStream_t s) {
   REQUIRE(vars_in && vars_out && y0 && mask && sigma_d && mu && tau && B > 0 && S > 0 && T >= 0 && param_stride >= T,
           "pnpx_pr_iadmm: bad argument");
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ticket_out) *ticket_out = 0;
   const int HW = H * W;
   const size_t is = 3 * (size_t)HW, n = (size_t)HW * B;
   const float2* vin = reinterpret_cast<const float2*>(vars_in);
@@ -443,21 +558,115 @@ int pnpx_pr_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
   PNPX_TRY(make_fft_plan(ctx, B * S, H, W, false, &P));
   StoreC kst{k, H, W};
   LoadC kld{k, H, W};
+  float* sv_d = saved;
+  float2* sv_w = saved ? reinterpret_cast<float2*>(saved + (size_t)T * n) : nullptr;
+  float2* sv_G = saved ? reinterpret_cast<float2*>(saved + (size_t)T * n * (1 + 2 * S)) : nullptr;
+  float2* sv_q = saved ? reinterpret_cast<float2*>(saved + (size_t)T * n * (3 + 2 * S)) : nullptr;
   hipLaunchKernelGGL(real_of_diff_kernel, g1(n), dim3(256), 0, s, vin + HW, vin + 2 * HW, is, d, HW, B);
   PNPX_LAUNCH_CHECK();
   for (int i = 0; i < T; ++i) {
-    PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, xr, nullptr, B, H, W, s, nullptr));
+    if (saved) {
+      PNPX_HIP(hipMemcpyAsync(sv_d + (size_t)i * n, d, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+      unsigned long long tk = 0;
+      PNPX_TRY(unet_denoise_train(ctx, d, sigma_d + i, param_stride, xr, B, H, W, s, &tk));
+      if (i == 0 && ticket_out) *ticket_out = tk;
+    } else {
+      PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, xr, nullptr, B, H, W, s, nullptr));
+    }
     const float2* zi = (i == 0 ? vin : vout) + HW;
     const float2* ui = (i == 0 ? vin : vout) + 2 * HW;
     LoadCdp ld{zi, is, reinterpret_cast<const float2*>(mask), S, W, HW};
     PNPX_TRY((launch_rows<false>(P, ld, kst, s)));
-    PNPX_TRY((launch_cols<false, true>(P, kld, MidPrResidual{y0, W, HW}, kst, s)));
+    if (saved) {
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidPrResidualSave{y0, sv_w + (size_t)i * n * S, W, HW}, kst, s)));
+    } else {
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidPrResidual{y0, W, HW}, kst, s)));
+    }
     PNPX_TRY((launch_rows<true>(P, kld, kst, s)));
-    hipLaunchKernelGGL(pr_update_kernel, g1(n), dim3(256), 0, s, k, reinterpret_cast<const float2*>(mask), xr, zi, ui,
-                       vout, vout + HW, vout + 2 * HW, is, d, mu + i, tau + i, param_stride, S, HW, B, i == T - 1);
+    if (saved) {
+      hipLaunchKernelGGL(pr_update_save_kernel, g1(n), dim3(256), 0, s, k, reinterpret_cast<const float2*>(mask), xr, zi, ui,
+                         vout, vout + HW, vout + 2 * HW, is, d, mu + i, tau + i, param_stride, S, HW, B, i == T - 1,
+                         sv_G + (size_t)i * n, sv_q + (size_t)i * n);
+    } else {
+      hipLaunchKernelGGL(pr_update_kernel, g1(n), dim3(256), 0, s, k, reinterpret_cast<const float2*>(mask), xr, zi, ui,
+                         vout, vout + HW, vout + 2 * HW, is, d, mu + i, tau + i, param_stride, S, HW, B, i == T - 1);
+    }
     PNPX_LAUNCH_CHECK();
   }
   return PNPX_OK;
+}
+
+int pnpx_pr_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const float* mask,
+                  const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int S, int H, int W,
+                  int T, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return pr_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, mu, tau, param_stride, B, S, H, W, T, nullptr, nullptr, s);
+  });
+}
+
+int pnpx_pr_iadmm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, const float* mask,
+                        const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int S, int H,
+                        int W, int T, float* saved, unsigned long long* ticket, void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE((saved || T == 0) && ticket, "pnpx_pr_iadmm_train: saved / ticket is null");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return pr_forward(ctx, vars_in, vars_out, y0, mask, sigma_d, mu, tau, param_stride, B, S, H, W, T, saved, ticket, s);
+  });
+}
+
+// VJP of the T-iteration PR map wrt (cat(x, z, u), sigma_d, mu, tau), iterations walked in reverse:
+//   forward i:   x' = r2c(D(Re(z - u), sigma_i));  w_s = F(mask_s z);  g = mean_s conj(mask_s) F^-1((|w_s| - y0_s) / |w_s| w_s);
+//                z' = z - tau (g + mu (z - (x' + u)));  u' = u + x' - z'
+//   backward i:  e = gz' - gu';  I'_s = F^-1 J_s^T F(mask_s e) with the saved w_s;  pr_adjoint_kernel (above);  denoiser VJP;
+//                pr_adjoint_finish_kernel
+int pnpx_pr_iadmm_backward(pnpx_ctx* ctx, const float* y0, const float* mask, const float* sigma_d, const float* mu,
+                           const float* tau, int param_stride, const float* saved, const float* grad_vars_out,
+                           float* grad_vars_in, float* grad_sigma_d, float* grad_mu, float* grad_tau, float* work, int B,
+                           int S, int H, int W, int T, unsigned long long ticket, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    REQUIRE(y0 && mask && sigma_d && mu && tau && grad_vars_out && grad_vars_in && B > 0 && S > 0 && T >= 0 &&
+                param_stride >= T && (T == 0 || (saved && grad_sigma_d && grad_mu && grad_tau && work)),
+            "pnpx_pr_iadmm_backward: bad argument");
+    const int HW = H * W;
+    const size_t is = 3 * (size_t)HW, n = (size_t)HW * B;
+    PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
+    if (T == 0) return PNPX_OK;
+    void* p;
+    PNPX_TRY(ctx_scratch(ctx, n * S * sizeof(float2) + 4096, &p));
+    Carver cv{static_cast<char*>(p)};
+    float2* k = cv.take<float2>(n * S);
+    FftPlan2D P;
+    PNPX_TRY(make_fft_plan(ctx, B * S, H, W, false, &P));
+    StoreC kst{k, H, W};
+    LoadC kld{k, H, W};
+    float2* g = reinterpret_cast<float2*>(grad_vars_in);
+    const float2* mk = reinterpret_cast<const float2*>(mask);
+    float *gxr = work, *gd = work + n, *c_tau = work + 2 * n, *c_mu = work + 3 * n;
+    const float* sv_d = saved;
+    const float2* sv_w = reinterpret_cast<const float2*>(saved + (size_t)T * n);
+    const float2* sv_G = reinterpret_cast<const float2*>(saved + (size_t)T * n * (1 + 2 * S));
+    const float2* sv_q = reinterpret_cast<const float2*>(saved + (size_t)T * n * (3 + 2 * S));
+    for (int i = T - 1; i >= 0; --i) {
+      PNPX_TRY((launch_rows<false>(P, LoadCdpDiff{g + HW, g + 2 * HW, is, mk, S, W, HW}, kst, s)));
+      PNPX_TRY((launch_cols<false, true>(P, kld, MidPrResidualAdjoint{y0, sv_w + (size_t)i * n * S, W, HW}, kst, s)));
+      PNPX_TRY((launch_rows<true>(P, kld, kst, s)));
+      hipLaunchKernelGGL(pr_adjoint_kernel, g1(n), dim3(256), 0, s, k, mk, g, is, sv_G + (size_t)i * n, sv_q + (size_t)i * n,
+                         mu + i, tau + i, param_stride, S, HW, B, gxr, c_tau, c_mu);
+      PNPX_LAUNCH_CHECK();
+      hipLaunchKernelGGL(pr_item_sum_kernel, dim3(B), dim3(256), 0, s, c_tau, grad_tau + (size_t)i * B, HW);
+      hipLaunchKernelGGL(pr_item_sum_kernel, dim3(B), dim3(256), 0, s, c_mu, grad_mu + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(unet_denoise_backward_ticket(ctx, sv_d + (size_t)i * n, sigma_d + i, param_stride, gxr, gd,
+                                            grad_sigma_d + (size_t)i * B, B, H, W, s, ticket ? ticket + i : 0));
+      hipLaunchKernelGGL(pr_adjoint_finish_kernel, g1(n), dim3(256), 0, s, gd, g, is, HW, B);
+      PNPX_LAUNCH_CHECK();
+    }
+    return PNPX_OK;
   });
 }
 

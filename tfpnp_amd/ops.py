@@ -568,6 +568,55 @@ def pr_iadmm(ctx, variables, y0, mask, sigma_d, mu, tau, iter_num=None):
     return out
 
 
+def _pr_args(variables, y0, mask):
+    v = _vars(variables, 3, True)
+    B, _, H, W, _ = v.shape
+    y0, mask = _f32(y0, "y0"), _f32(mask, "mask")
+    S = mask.shape[1]
+    if tuple(mask.shape) != (B, S, H, W, 2) or tuple(y0.shape) != (B, S, H, W):
+        raise PnpxError("pr_iadmm: y0 must be [B,S,H,W] and mask [B,S,H,W,2]")
+    return v, y0, mask, B, S, H, W
+
+
+def pr_iadmm_train(ctx, variables, y0, mask, sigma_d, mu, tau, iter_num=None):
+    """pnpx_pr_iadmm_train: IADMMSolver_PR.forward for autograd -> (next state [B,3,H,W,2], saved [(2S+5)*T*B*H*W], ticket)."""
+    v, y0, mask, B, S, H, W = _pr_args(variables, y0, mask)
+    ps, T = _params(B, sigma_d, mu, tau)
+    if iter_num is not None:
+        if iter_num > T:
+            raise PnpxError(f"iter_num {iter_num} exceeds the {T} hyper-parameter columns provided")
+        T = iter_num
+    out = torch.empty_like(v)
+    saved = torch.empty((2 * S + 5) * T * B * H * W, dtype=torch.float32, device=v.device)
+    if B == 0:
+        return out, saved, 0
+    ticket = C.c_ulonglong(0)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().pnpx_pr_iadmm_train(ctx.handle, _p(v), _p(out), _p(y0), _p(mask), *[_p(p) for p in ps],
+                                             ps[0].shape[1], B, S, H, W, T, _p(saved), C.byref(ticket), _stream(v)))
+    return out, saved, int(ticket.value)
+
+
+def pr_iadmm_backward(ctx, y0, mask, sigma_d, mu, tau, saved, grad_out, iter_num=None, ticket=0):
+    """pnpx_pr_iadmm_backward -> (grad variables [B,3,H,W,2], grad sigma_d, grad mu, grad tau, each [B,T])."""
+    g, y0, mask, B, S, H, W = _pr_args(grad_out, y0, mask)
+    ps, T = _params(B, sigma_d, mu, tau)
+    T = T if iter_num is None else iter_num
+    if saved.numel() != (2 * S + 5) * T * B * H * W:
+        raise PnpxError("saved does not belong to a forward of this shape / iteration count")
+    gin = torch.empty_like(g)
+    g0, g1, g2 = (torch.zeros(T, B, dtype=torch.float32, device=g.device) for _ in range(3))
+    if B and T:
+        work = torch.empty(4 * B * H * W, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(_lib.lib().pnpx_pr_iadmm_backward(ctx.handle, _p(y0), _p(mask), *[_p(p) for p in ps], ps[0].shape[1],
+                                                    _p(saved), _p(g), _p(gin), _p(g0), _p(g1), _p(g2), _p(work), B, S, H, W,
+                                                    T, int(ticket), _stream(g)))
+    elif B:
+        gin.copy_(g)
+    return gin, g0.t().contiguous(), g1.t().contiguous(), g2.t().contiguous()
+
+
 def spi_admm(ctx, variables, x0, Kmap, sigma_d, mu, iter_num=None):
     v = _vars(variables, 3, False)
     B, _, H, W = v.shape

@@ -581,6 +581,62 @@ def csmri_redadmm(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, 
 csmri_redadmm.register_fake(_same)
 
 
+@_lib_def("pnpx::pr_iadmm_train", mutates_args=(), device_types="cuda")
+def pr_iadmm_train(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, tau: Tensor,
+                    iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """Differentiable IADMMSolver_PR.forward (tasks/pr/solver.py:37-76); autograd = pnpx_pr_iadmm_backward."""
+    out, saved, ticket = ops.pr_iadmm_train(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, tau, _it(iter_num))
+    return out, saved, torch.tensor([ticket], dtype=torch.int64)
+
+
+@pr_iadmm_train.register_fake
+def _(variables, y0, mask, sigma_d, mu, tau, iter_num, ctx):
+    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
+    B, _, H, W, _ = variables.shape
+    return (torch.empty_like(variables, memory_format=torch.contiguous_format),
+            torch.empty(((2 * mask.shape[1] + 5) * T * B * H * W,), dtype=variables.dtype, device=variables.device),
+            torch.empty((1,), dtype=torch.int64))
+
+
+@_lib_def("pnpx::pr_iadmm_backward", mutates_args=(), device_types="cuda")
+def pr_iadmm_backward(y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, tau: Tensor, saved: Tensor, ticket: Tensor,
+                       grad_out: Tensor, iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """VJP of pr_iadmm_train wrt (variables, sigma_d[:, :T], mu[:, :T], tau[:, :T])."""
+    return ops.pr_iadmm_backward(_ctx(ctx, grad_out), y0, mask, sigma_d, mu, tau, saved, grad_out, _it(iter_num),
+                                  ticket=int(ticket[0]))
+
+
+@pr_iadmm_backward.register_fake
+def _(y0, mask, sigma_d, mu, tau, saved, ticket, grad_out, iter_num, ctx):
+    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
+    B = grad_out.shape[0]
+    e = lambda: torch.empty((B, T), dtype=grad_out.dtype, device=grad_out.device)
+    return torch.empty_like(grad_out, memory_format=torch.contiguous_format), e(), e(), e()
+
+
+def _pr_train_setup(ctx, inputs, output):
+    _, y0, mask, sigma_d, mu, tau, ctx.iter_num, cid = inputs
+    _pin(ctx, cid, y0)
+    ctx.save_for_backward(y0, mask, sigma_d, mu, tau, output[1], output[2])
+
+
+def _pr_train_bwd(ctx, g_out, _g_saved, _g_ticket):
+    y0, mask, sigma_d, mu, tau, saved, ticket = ctx.saved_tensors
+    gv, gs, gm, gt = torch.ops.pnpx.pr_iadmm_backward(y0, mask, sigma_d, mu, tau, saved, ticket, g_out.contiguous(),
+                                                       ctx.iter_num, ctx.cid)
+
+    def like(g, p):
+        full = torch.zeros_like(p)
+        if p.numel():
+            full.view(p.shape[0], -1)[:, :g.shape[1]] = g
+        return full
+
+    return gv, None, None, like(gs, sigma_d), like(gm, mu), like(gt, tau), None, None
+
+
+pr_iadmm_train.register_autograd(_pr_train_bwd, setup_context=_pr_train_setup)
+
+
 @_lib_def("pnpx::pr_iadmm", mutates_args=(), device_types="cuda")
 def pr_iadmm(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, tau: Tensor, iter_num: int,
              ctx: int) -> Tensor:
