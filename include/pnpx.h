@@ -306,6 +306,16 @@ int pnpx_pr_iadmm_backward(pnpx_ctx* ctx, const float* y0, const float* mask, co
 int pnpx_spi_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* x0,
                   const float* Kmap, const float* sigma_d, const float* mu, int param_stride, int B, int H,
                   int W, int T, void* stream);
+/* Training path of ADMMSolver_SPI.forward (same contract): `saved` = 2*T*B*H*W floats (x + u and the denoiser inputs); grads
+ * wrt (cat(x, z, u), sigma_d, mu), hyper-parameter gradients [T][B]; work = 3*B*H*W floats.  As in the reference the bisection
+ * branch of spi_inverse carries no gradient (transforms.py:404-439), only its K1 == 0 branch does. */
+int pnpx_spi_admm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* x0, const float* Kmap,
+                        const float* sigma_d, const float* mu, int param_stride, int B, int H, int W, int T,
+                        float* saved, unsigned long long* ticket, void* stream);
+int pnpx_spi_admm_backward(pnpx_ctx* ctx, const float* x0, const float* Kmap, const float* sigma_d, const float* mu,
+                           int param_stride, const float* saved, const float* grad_vars_out, float* grad_vars_in,
+                           float* grad_sigma_d, float* grad_mu, float* work, int B, int H, int W, int T,
+                           unsigned long long ticket, void* stream);
 
 /* ---- CT: Radon pair standing in for torch_radon (tfpnp/utils/transforms.py:465-508) -------------- */
 /* Parallel beam, angles = linspace(0, 179/180*pi, n_view), det = ceil(sqrt(2)*R), unit spacing
@@ -319,10 +329,27 @@ int pnpx_radon_backprojection(pnpx_ctx* ctx, const float* sino, float* img, int 
 int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view,
                   float opnorm, const float* sigma_d, const float* mu, const float* tau, int param_stride,
                   int B, int R, int T, void* stream);
+/* Training path of IADMMSolver_CT.forward: `saved` = 3*T*B*R*R floats; grads wrt (cat(x, z, u), sigma_d, mu, tau);
+ * work = 6*B*R*R floats. */
+int pnpx_ct_iadmm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view,
+                        float opnorm, const float* sigma_d, const float* mu, const float* tau, int param_stride, int B,
+                        int R, int T, float* saved, unsigned long long* ticket, void* stream);
+int pnpx_ct_iadmm_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float* sigma_d, const float* mu,
+                           const float* tau, int param_stride, const float* saved, const float* grad_vars_out,
+                           float* grad_vars_in, float* grad_sigma_d, float* grad_mu, float* grad_tau, float* work,
+                           int B, int R, int T, unsigned long long ticket, void* stream);
 /* PGSolver_CT.forward (tasks/ct/solver.py:61-87).  vars [B,1,R,R]. */
 int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view,
                float opnorm, const float* sigma_d, const float* tau, int param_stride, int B, int R, int T,
                void* stream);
+/* Training path of PGSolver_CT.forward: `saved` = 2*T*B*R*R floats; grads wrt (x, sigma_d, tau); work = 3*B*R*R floats. */
+int pnpx_ct_pg_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
+                     const float* sigma_d, const float* tau, int param_stride, int B, int R, int T, float* saved,
+                     unsigned long long* ticket, void* stream);
+int pnpx_ct_pg_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float* sigma_d, const float* tau,
+                        int param_stride, const float* saved, const float* grad_vars_out, float* grad_vars_in,
+                        float* grad_sigma_d, float* grad_tau, float* work, int B, int R, int T,
+                        unsigned long long ticket, void* stream);
 
 #ifdef __cplusplus
 }

@@ -587,6 +587,82 @@ def test_spi_solver_gradients(den, oden32):
         assert e < 2e-2, n
 
 
+def _fused_vs_composed(sol, v0, aux, acts, composed, T, names, tol=2e-2, zero_slot=None):
+    """Gradients of the fused native training path of `sol` against `composed` (the reference's loop from differentiable ops)."""
+    wts = torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(12))
+
+    def grads(fn):
+        leaves = [v0.clone().requires_grad_(True)] + [g(p, True) for p in acts]
+        out = fn(*leaves)
+        (out * wts).sum().backward()
+        return out.detach(), [l.grad for l in leaves]
+
+    out_f, gf = grads(lambda v, *p: sol((v, aux), tuple(p), iter_num=T))
+    out_c, gc = grads(lambda v, *p: composed(v, *p))
+    with torch.no_grad():
+        assert rel(out_f, sol((v0, aux), tuple(g(p) for p in acts), iter_num=T)) < 1e-6
+    assert rel(out_f, out_c) < 1e-5
+    for n, x, y in zip(names, gf, gc):
+        e = rel(x, y) if float(y.abs().max()) > 0 else float(x.abs().max())
+        print(f"  {type(sol).__name__} fused vs composed d/d{n}: {e:.2e}")
+        assert e < tol and x.shape == y.shape, n
+    if zero_slot is not None:
+        assert float(gf[0][:, zero_slot].abs().max()) == 0.0
+    for k in range(1, len(gf)):
+        assert float(gf[k][:, T:].abs().max()) == 0.0
+    _, gf2 = grads(lambda v, *p: sol((v, aux), tuple(p), iter_num=T))
+    assert all(torch.equal(x, y) for x, y in zip(gf, gf2))
+
+
+def test_spi_fused_vjp_vs_composed_autograd(den):
+    """ADMMSolver_SPI under autograd (pnpx_spi_admm_train / _backward): one and two iterations; K1 == 0 pixels (the only ones whose
+    prox carries a gradient, also wrt mu) are present in the batch."""
+    from tfpnp_amd.tasks import spi
+    sol = spi.ADMMSolver_SPI(den)
+    B, H, W = 3, 32, 32
+    d = synth.make_spi_batch(B, H, W, K=6, seed=83)
+    assert float((g(d["x0"]) == 0).float().mean()) > 0.01
+    rs = np.random.RandomState(84)
+    acts = [rs.uniform(15 / 255.0, 70 / 255.0, (B, 3)).astype(np.float32), rs.uniform(50, 120, (B, 3)).astype(np.float32)]
+    v0 = sol.reset({"x0": g(d["x0"])})
+    v0[:, 2] = 0.02 * torch.randn(v0[:, 2].shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(9))
+    aux = (g(d["x0"]), g(d["K"]))
+    for T in (1, 2):
+        _fused_vs_composed(sol, v0, aux, acts, lambda v, s_, m_: sol._forward_autograd(v, aux[0], aux[1], s_, m_, T), T,
+                           ("variables", "sigma_d", "mu"), tol=3e-2, zero_slot=1)
+
+
+def _ct_case(B=2, R=32, V=20, seed=95):
+    from tfpnp_amd.utils import transforms as Tr
+    gt = synth.phantom_batch(B, R, R, seed)
+    radon = Tr.Radon_norm(R, V, device=dev())
+    rs = np.random.RandomState(seed + 1)
+    sino = radon.forward(g(gt))
+    y0 = sino * (1 + 0.05 * g(rs.standard_normal(tuple(sino.shape)).astype(np.float32)))
+    x0 = radon.backprojection_norm(y0)
+    view = g(np.full((B, 1, R, R), V / 120.0, np.float32))
+    return y0, x0, view
+
+
+def test_ct_fused_vjp_vs_composed_autograd(den):
+    """IADMMSolver_CT and PGSolver_CT under autograd: pnpx_ct_{iadmm,pg}_train / _backward against the composed paths (the data
+    step's adjoint is A^T A / opnorm^2 with the projector pair standing in for each other's transpose)."""
+    from tfpnp_amd.tasks import ct
+    B, T = 2, 3
+    y0, x0, view = _ct_case(B)
+    a = csmri_actions(B, 4, 97, ("sigma_d", "mu", "tau"))
+    sol = ct.IADMMSolver_CT(den)
+    v0 = sol.reset({"x0": x0})
+    v0 = v0 + 0.02 * torch.randn(v0.shape, device=v0.device, generator=torch.Generator(v0.device).manual_seed(10))
+    _fused_vs_composed(sol, v0, (y0, view), [a["sigma_d"], a["mu"], a["tau"]],
+                       lambda v, s_, m_, t_: sol._forward_autograd(v, y0, s_, m_, t_, T), T,
+                       ("variables", "sigma_d", "mu", "tau"), zero_slot=0)
+    pg = ct.PGSolver_CT(den)
+    pg.radon_generator.opnorms = dict(sol.radon_generator.opnorms)
+    _fused_vs_composed(pg, pg.reset({"x0": x0}), (y0, view), [a["sigma_d"], a["tau"]],
+                       lambda v, s_, t_: pg._forward_autograd(v, y0, s_, t_, T), T, ("variables", "sigma_d", "tau"))
+
+
 def test_ct_solver_gradients(den, oden32, oden64, monkeypatch):
     """The Radon pair is unmatched and each operator is used as the other's VJP (torch_radon's convention); the
     oracle is given the same convention through autograd.Function wrappers for this test."""

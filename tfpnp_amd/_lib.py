@@ -94,10 +94,22 @@ _SIGNATURES = {
     "pnpx_pr_iadmm_backward": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P] + [C.c_int] * 5 +
                                [C.c_ulonglong, c_void_p]),
     "pnpx_pr_iadmm": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, _P, _P] + [C.c_int] * 6 + [c_void_p]),
+    "pnpx_spi_admm_train": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, _P] + [C.c_int] * 5 +
+                            [_P, C.POINTER(C.c_ulonglong), c_void_p]),
+    "pnpx_spi_admm_backward": (C.c_int, [c_void_p, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P] + [C.c_int] * 4 +
+                               [C.c_ulonglong, c_void_p]),
     "pnpx_spi_admm": (C.c_int, [c_void_p, _P, _P, _P, _P, _P, _P] + [C.c_int] * 5 + [c_void_p]),
     "pnpx_radon_det_count": (C.c_int, [C.c_int]),
     "pnpx_radon_forward": (C.c_int, [c_void_p, _P, _P, C.c_int, C.c_int, C.c_int, c_void_p]),
     "pnpx_radon_backprojection": (C.c_int, [c_void_p, _P, _P, C.c_int, C.c_int, C.c_int, c_void_p]),
+    "pnpx_ct_iadmm_train": (C.c_int, [c_void_p, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P] + [C.c_int] * 4 +
+                            [_P, C.POINTER(C.c_ulonglong), c_void_p]),
+    "pnpx_ct_iadmm_backward": (C.c_int, [c_void_p, C.c_int, C.c_float, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P] +
+                               [C.c_int] * 3 + [C.c_ulonglong, c_void_p]),
+    "pnpx_ct_pg_train": (C.c_int, [c_void_p, _P, _P, _P, C.c_int, C.c_float, _P, _P] + [C.c_int] * 4 +
+                         [_P, C.POINTER(C.c_ulonglong), c_void_p]),
+    "pnpx_ct_pg_backward": (C.c_int, [c_void_p, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P] +
+                            [C.c_int] * 3 + [C.c_ulonglong, c_void_p]),
     "pnpx_ct_iadmm": (C.c_int, [c_void_p, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P] + [C.c_int] * 4 + [c_void_p]),
     "pnpx_ct_pg": (C.c_int, [c_void_p, _P, _P, _P, C.c_int, C.c_float, _P, _P] + [C.c_int] * 4 + [c_void_p]),
 }

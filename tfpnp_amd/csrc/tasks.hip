@@ -261,6 +261,120 @@ __global__ void copy_real_slot_kernel(const float* __restrict__ src, float* __re
   dst[b * istride + r] = src[i];
 }
 
+// ---- training paths of ADMMSolver_SPI / IADMMSolver_CT / PGSolver_CT (pnpx_{spi_admm,ct_iadmm,ct_pg}_train / _backward)
+// spi_step_kernel that also keeps zt = x + u (the argument of spi_inverse)
+__global__ void spi_step_save_kernel(const float* xin, const float* uin, size_t istride, const float* __restrict__ x0,
+                                     const float* __restrict__ Kmap, float* zout, float* uout, float* __restrict__ d,
+                                     const float* __restrict__ mu, int stride, int HW, int B, float* __restrict__ zts) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  const float K = mulr(Kmap[b * HW], 10.f);
+  const float K1 = mulr(x0[i], mulr(K, K));
+  const float x = xin[b * istride + r], u = uin[b * istride + r];
+  const float zt = addr(x, u);
+  const float z = spi_inverse_px(zt, K1, K, mu[b * stride]);
+  const float un = subr(addr(u, x), z);
+  zout[b * istride + r] = z;
+  uout[b * istride + r] = un;
+  d[i] = subr(z, un);
+  zts[i] = zt;
+}
+// one slot of a [B][3][HW] state -> contiguous [B][HW]
+__global__ void slot_to_rows_kernel(const float* __restrict__ g, size_t istride, float* __restrict__ out, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  out[i] = g[b * istride + r];
+}
+// Backward of one SPI iteration after the denoiser's VJP gd (x' = D(z' - u')):
+//   gz't = gz' + gd;  gu't = gu' - gd;  (u' = u + x - z')  gx = gu = gu't,  h = gz't - gu't;
+//   z' = clamp(K1 == 0 ? zt - K0 / mu : bisection(zt), 0, 1): only the K1 == 0 branch carries a gradient (the bisection result is
+//   built from constants in the reference, transforms.py:404-439), inside the clamp's closed interval:
+//   gx += h, gu += h, d/d mu += h K0 / mu^2;  gz = 0 (an iteration never reads its z)
+__global__ void spi_adjoint_kernel(float* g, size_t istride, const float* __restrict__ gd, const float* __restrict__ zts,
+                                   const float* __restrict__ x0, const float* __restrict__ Kmap,
+                                   const float* __restrict__ mu, int stride, int HW, int B, float* __restrict__ c_mu) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  float* gi = g + b * istride + r;
+  const float gzt = gi[HW] + gd[i], gut = gi[2 * HW] - gd[i];
+  const float h = gzt - gut;
+  const float K = Kmap[b * HW] * 10.f, K1 = x0[i] * (K * K), m = mu[b * stride];
+  const float K0 = K * K - K1;
+  const float pre = zts[i] - K0 / m;
+  const bool pass = (K1 == 0.f) && pre >= 0.f && pre <= 1.f;
+  const float hz = pass ? h : 0.f;
+  c_mu[i] = pass ? h * K0 / (m * m) : 0.f;
+  gi[0] = gut + hz;
+  gi[HW] = 0.f;
+  gi[2 * HW] = gut + hz;
+}
+// ct_update_kernel of the training forward: also keeps G = g + mu (z - (x + u)) and q2 = z - (x + u)
+__global__ void ct_update_save_kernel(const float* __restrict__ g, const float* __restrict__ xr, const float* zin,
+                                      const float* uin, float* xout, float* zout, float* uout, size_t istride,
+                                      float* __restrict__ d, const float* __restrict__ mu, const float* __restrict__ tau,
+                                      int stride, int HW, int B, int write_x, float* __restrict__ Gs, float* __restrict__ q2s) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  const float m = mu[b * stride], t = tau[b * stride];
+  const float z = zin[b * istride + r], u = uin[b * istride + r], xv = xr[i];
+  const float q2 = subr(z, addr(xv, u));
+  const float G = addr(g[i], mulr(m, q2));
+  const float zn = subr(z, mulr(t, G));
+  const float un = subr(addr(u, xv), zn);
+  zout[b * istride + r] = zn;
+  uout[b * istride + r] = un;
+  d[i] = subr(zn, un);
+  if (write_x) xout[b * istride + r] = xv;
+  Gs[i] = G;
+  q2s[i] = q2;
+}
+// e = gz' - gu' as a contiguous image batch (the input of the data step's adjoint A^T A / opnorm^2)
+__global__ void ct_cotangent_kernel(const float* __restrict__ g, size_t istride, float* __restrict__ e, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  e[i] = g[b * istride + r + HW] - g[b * istride + r + 2 * HW];
+}
+// Backward of one CT iADMM iteration after J = A^T A e / opnorm^2 (the real-valued twin of pr_adjoint_kernel)
+__global__ void ct_adjoint_kernel(const float* __restrict__ e, const float* __restrict__ J, float* g, size_t istride,
+                                  const float* __restrict__ Gs, const float* __restrict__ q2s, const float* __restrict__ mu,
+                                  const float* __restrict__ tau, int stride, int HW, int B, float* __restrict__ gxr,
+                                  float* __restrict__ c_tau, float* __restrict__ c_mu) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  const float m = mu[b * stride], t = tau[b * stride], tm = t * m;
+  float* gi = g + b * istride + r;
+  const float ev = e[i], gu = gi[2 * HW];
+  c_tau[i] = -(ev * Gs[i]);
+  c_mu[i] = -t * (ev * q2s[i]);
+  gxr[i] = gi[0] + gu + tm * ev;
+  gi[0] = 0.f;
+  gi[HW] = (1.f - tm) * ev - t * J[i];
+  gi[2 * HW] = gu + tm * ev;
+}
+__global__ void ct_adjoint_finish_kernel(const float* __restrict__ gd, float* g, size_t istride, int HW, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const size_t b = i / HW, r = i - b * HW;
+  g[b * istride + r + HW] += gd[i];
+  g[b * istride + r + 2 * HW] -= gd[i];
+}
+// CT PG backward: gx = gd - tau J,  d/d tau = -<gd, g_i>
+__global__ void ct_pg_adjoint_kernel(const float* __restrict__ gd, const float* __restrict__ J, const float* __restrict__ gsave,
+                                     const float* __restrict__ tau, int stride, int HW, int B, float* __restrict__ gx,
+                                     float* __restrict__ c_tau) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)HW * B) return;
+  const float t = tau[(i / HW) * stride];
+  c_tau[i] = -(gd[i] * gsave[i]);
+  gx[i] = gd[i] - t * J[i];
+}
+
 // =================================================================================== PSNR
 // partial sums of (clamp(o,0,1) - g)^2 per item                            tfpnp/env/base.py:237-242
 constexpr int PSNR_CHUNKS = 32;
@@ -681,13 +795,13 @@ int pnpx_spi_inverse(pnpx_ctx* ctx, const float* ztilde, const float* K1, const 
   return PNPX_OK;
 }
 
-int pnpx_spi_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* x0, const float* Kmap,
-                  const float* sigma_d, const float* mu, int param_stride, int B, int H, int W, int T, void* stream) {
-  LOCK_CTX(ctx);
-  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+// ADMMSolver_SPI.forward; `saved` != NULL (training path): per iteration zt = x + u [T][n] and the denoiser input [T][n]
+static int spi_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* x0, const float* Kmap,
+                       const float* sigma_d, const float* mu, int param_stride, int B, int H, int W, int T, float* saved,
+                       unsigned long long* ticket_out, hipStream_t s) {
   REQUIRE(vars_in && vars_out && x0 && Kmap && sigma_d && mu && B > 0 && T >= 0 && param_stride >= T,
           "pnpx_spi_admm: bad argument");
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ticket_out) *ticket_out = 0;
   const int HW = H * W;
   const size_t is = 3 * (size_t)HW, n = (size_t)HW * B;
   if (T == 0) {
@@ -697,20 +811,80 @@ int pnpx_spi_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
   void* p;
   PNPX_TRY(ctx_scratch(ctx, 2 * n * sizeof(float) + 4096, &p));
   Carver cv{static_cast<char*>(p)};
-  float* d = cv.take<float>(n);
+  float* dscr = cv.take<float>(n);
   float* xr = cv.take<float>(n);
   for (int i = 0; i < T; ++i) {
     // x of iteration i: state x on the first pass, the previous denoiser output (already in the x slot) later
     const float* xin = (i == 0) ? vars_in : vars_out;
     const float* uin = ((i == 0) ? vars_in : vars_out) + 2 * HW;
-    hipLaunchKernelGGL(spi_step_kernel, g1(n), dim3(256), 0, s, xin, uin, is, x0, Kmap, vars_out + HW,
-                       vars_out + 2 * HW, d, mu + i, param_stride, HW, B);
-    PNPX_LAUNCH_CHECK();
-    PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, xr, nullptr, B, H, W, s, nullptr));
+    if (saved) {
+      float* d = saved + ((size_t)T + i) * n;
+      hipLaunchKernelGGL(spi_step_save_kernel, g1(n), dim3(256), 0, s, xin, uin, is, x0, Kmap, vars_out + HW,
+                         vars_out + 2 * HW, d, mu + i, param_stride, HW, B, saved + (size_t)i * n);
+      PNPX_LAUNCH_CHECK();
+      unsigned long long tk = 0;
+      PNPX_TRY(unet_denoise_train(ctx, d, sigma_d + i, param_stride, xr, B, H, W, s, &tk));
+      if (i == 0 && ticket_out) *ticket_out = tk;
+    } else {
+      hipLaunchKernelGGL(spi_step_kernel, g1(n), dim3(256), 0, s, xin, uin, is, x0, Kmap, vars_out + HW,
+                         vars_out + 2 * HW, dscr, mu + i, param_stride, HW, B);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(unet_denoise(ctx, dscr, sigma_d + i, param_stride, xr, nullptr, B, H, W, s, nullptr));
+    }
     hipLaunchKernelGGL(copy_real_slot_kernel, g1(n), dim3(256), 0, s, xr, vars_out, is, HW, B);
     PNPX_LAUNCH_CHECK();
   }
   return PNPX_OK;
+}
+
+int pnpx_spi_admm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* x0, const float* Kmap,
+                  const float* sigma_d, const float* mu, int param_stride, int B, int H, int W, int T, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return spi_forward(ctx, vars_in, vars_out, x0, Kmap, sigma_d, mu, param_stride, B, H, W, T, nullptr, nullptr, s);
+  });
+}
+
+int pnpx_spi_admm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* x0, const float* Kmap,
+                        const float* sigma_d, const float* mu, int param_stride, int B, int H, int W, int T, float* saved,
+                        unsigned long long* ticket, void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE((saved || T == 0) && ticket, "pnpx_spi_admm_train: saved / ticket is null");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return spi_forward(ctx, vars_in, vars_out, x0, Kmap, sigma_d, mu, param_stride, B, H, W, T, saved, ticket, s);
+  });
+}
+
+// VJP of the T-iteration SPI map wrt (cat(x, z, u), sigma_d, mu): per iteration (reverse order) the denoiser VJP of the x slot's
+// cotangent, then spi_adjoint_kernel.  work = 3*B*H*W floats.
+int pnpx_spi_admm_backward(pnpx_ctx* ctx, const float* x0, const float* Kmap, const float* sigma_d, const float* mu,
+                           int param_stride, const float* saved, const float* grad_vars_out, float* grad_vars_in,
+                           float* grad_sigma_d, float* grad_mu, float* work, int B, int H, int W, int T,
+                           unsigned long long ticket, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    REQUIRE(x0 && Kmap && sigma_d && mu && grad_vars_out && grad_vars_in && B > 0 && T >= 0 && param_stride >= T &&
+                (T == 0 || (saved && grad_sigma_d && grad_mu && work)),
+            "pnpx_spi_admm_backward: bad argument");
+    const int HW = H * W;
+    const size_t is = 3 * (size_t)HW, n = (size_t)HW * B;
+    PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float) * is * B, hipMemcpyDeviceToDevice, s));
+    float *gxr = work, *gd = work + n, *c_mu = work + 2 * n;
+    for (int i = T - 1; i >= 0; --i) {
+      hipLaunchKernelGGL(slot_to_rows_kernel, g1(n), dim3(256), 0, s, grad_vars_in, is, gxr, HW, B);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(unet_denoise_backward_ticket(ctx, saved + ((size_t)T + i) * n, sigma_d + i, param_stride, gxr, gd,
+                                            grad_sigma_d + (size_t)i * B, B, H, W, s, ticket ? ticket + i : 0));
+      hipLaunchKernelGGL(spi_adjoint_kernel, g1(n), dim3(256), 0, s, grad_vars_in, is, gd, saved + (size_t)i * n, x0, Kmap,
+                         mu + i, param_stride, HW, B, c_mu);
+      PNPX_LAUNCH_CHECK();
+      hipLaunchKernelGGL(pr_item_sum_kernel, dim3(B), dim3(256), 0, s, c_mu, grad_mu + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+    }
+    return PNPX_OK;
   });
 }
 
@@ -778,89 +952,231 @@ int pnpx_radon_backprojection(pnpx_ctx* ctx, const float* sino, float* img, int 
   return PNPX_OK;
 }
 
-int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
-                  const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int R, int T,
-                  void* stream) {
-  LOCK_CTX(ctx);
-  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+// scratch shared by the CT loops: (cos, sin) table, sinogram, the projector's padded copies and `extra` image-sized buffers
+struct CtScratch {
+  const float2* cs;
+  float *sino, *pad, *img[4];
+  int det;
+};
+static int ct_scratch(pnpx_ctx* ctx, int B, int R, int n_view, int extra, hipStream_t s, CtScratch* C) {
+  const size_t n = (size_t)R * R * B;
+  const int det = pnpx_radon_det_count(R);
+  void* p;
+  PNPX_TRY(ctx_scratch(ctx, (extra * n + radon_pad_floats(B, R) + (size_t)B * n_view * det) * sizeof(float) +
+                                sizeof(float2) * n_view + 16384, &p));
+  Carver cv{static_cast<char*>(p)};
+  int det2;
+  PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &C->cs, &det2));
+  for (int k = 0; k < extra; ++k) C->img[k] = cv.take<float>(n);
+  C->sino = cv.take<float>((size_t)B * n_view * det);
+  C->pad = cv.take<float>(radon_pad_floats(B, R));
+  C->det = det;
+  return PNPX_OK;
+}
+// out = A^T (A img - sub) / op2 for a contiguous image batch
+static int ct_normal_op(const CtScratch& C, const float* img, size_t istride, const float* sub, float* out, float op2, int R,
+                        int n_view, int B, hipStream_t s) {
+  launch_radon_forward(img, istride, sub, C.sino, C.cs, C.pad, R, n_view, C.det, B, s);
+  PNPX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(radon_backproject_kernel, g1((size_t)R * R * B), dim3(256), 0, s, C.sino, out, C.cs, R, n_view, C.det, B,
+                     op2);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+
+// IADMMSolver_CT.forward; `saved` != NULL (training path): per iteration the denoiser input [T][n], G = g + mu (z - (x + u))
+// [T][n] and q2 = z - (x + u) [T][n]
+static int ct_iadmm_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
+                            const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int R, int T,
+                            float* saved, unsigned long long* ticket_out, hipStream_t s) {
   REQUIRE(vars_in && vars_out && y0 && sigma_d && mu && tau && B > 0 && R > 0 && n_view > 0 && T >= 0 &&
               param_stride >= T && opnorm > 0.f,
           "pnpx_ct_iadmm: bad argument");
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ticket_out) *ticket_out = 0;
   const int HW = R * R;
   const size_t is = 3 * (size_t)HW, n = (size_t)HW * B;
   if (T == 0) {
     PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float) * is * B, hipMemcpyDeviceToDevice, s));
     return PNPX_OK;
   }
-  const int det = pnpx_radon_det_count(R);
-  void* p;
-  PNPX_TRY(ctx_scratch(ctx, (3 * n + radon_pad_floats(B, R) + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 16384, &p));
-  Carver cv{static_cast<char*>(p)};
-  const float2* cs;
-  int det2;
-  PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &cs, &det2));
-  float* d = cv.take<float>(n);
-  float* xr = cv.take<float>(n);
-  float* g = cv.take<float>(n);
-  float* sino = cv.take<float>((size_t)B * n_view * det);
-  float* imgT = cv.take<float>(radon_pad_floats(B, R));
+  CtScratch C;
+  PNPX_TRY(ct_scratch(ctx, B, R, n_view, 3, s, &C));
+  float *d = C.img[0], *xr = C.img[1], *g = C.img[2];
   const float op2 = (float)((double)opnorm * (double)opnorm);  // backprojection / opnorm**2   transforms.py:476-477
   hipLaunchKernelGGL(real_diff_slots_kernel, g1(n), dim3(256), 0, s, vars_in + HW, vars_in + 2 * HW, is, d, HW, B);
   PNPX_LAUNCH_CHECK();
   for (int i = 0; i < T; ++i) {
-    PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, xr, nullptr, B, R, R, s, nullptr));
+    if (saved) {
+      PNPX_HIP(hipMemcpyAsync(saved + (size_t)i * n, d, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+      unsigned long long tk = 0;
+      PNPX_TRY(unet_denoise_train(ctx, d, sigma_d + i, param_stride, xr, B, R, R, s, &tk));
+      if (i == 0 && ticket_out) *ticket_out = tk;
+    } else {
+      PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, xr, nullptr, B, R, R, s, nullptr));
+    }
     const float* zi = ((i == 0) ? vars_in : vars_out) + HW;
     const float* ui = ((i == 0) ? vars_in : vars_out) + 2 * HW;
-    launch_radon_forward(zi, is, y0, sino, cs, imgT, R, n_view, det, B, s);
-    PNPX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(radon_backproject_kernel, g1(n), dim3(256), 0, s, sino, g, cs, R, n_view, det, B, op2);
-    PNPX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ct_update_kernel, g1(n), dim3(256), 0, s, g, xr, zi, ui, vars_out, vars_out + HW,
-                       vars_out + 2 * HW, is, d, mu + i, tau + i, param_stride, HW, B, i == T - 1);
+    PNPX_TRY(ct_normal_op(C, zi, is, y0, g, op2, R, n_view, B, s));
+    if (saved) {
+      hipLaunchKernelGGL(ct_update_save_kernel, g1(n), dim3(256), 0, s, g, xr, zi, ui, vars_out, vars_out + HW,
+                         vars_out + 2 * HW, is, d, mu + i, tau + i, param_stride, HW, B, i == T - 1,
+                         saved + ((size_t)T + i) * n, saved + (2 * (size_t)T + i) * n);
+    } else {
+      hipLaunchKernelGGL(ct_update_kernel, g1(n), dim3(256), 0, s, g, xr, zi, ui, vars_out, vars_out + HW,
+                         vars_out + 2 * HW, is, d, mu + i, tau + i, param_stride, HW, B, i == T - 1);
+    }
     PNPX_LAUNCH_CHECK();
   }
   return PNPX_OK;
+}
+
+int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
+                  const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int R, int T,
+                  void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return ct_iadmm_forward(ctx, vars_in, vars_out, y0, n_view, opnorm, sigma_d, mu, tau, param_stride, B, R, T, nullptr,
+                            nullptr, s);
   });
 }
 
-int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
-               const float* sigma_d, const float* tau, int param_stride, int B, int R, int T, void* stream) {
+int pnpx_ct_iadmm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
+                        const float* sigma_d, const float* mu, const float* tau, int param_stride, int B, int R, int T,
+                        float* saved, unsigned long long* ticket, void* stream) {
   LOCK_CTX(ctx);
-  return pnpx::guarded(ctx, static_cast<hipStream_t>(stream), [&]() -> int {
+  REQUIRE((saved || T == 0) && ticket, "pnpx_ct_iadmm_train: saved / ticket is null");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return ct_iadmm_forward(ctx, vars_in, vars_out, y0, n_view, opnorm, sigma_d, mu, tau, param_stride, B, R, T, saved,
+                            ticket, s);
+  });
+}
+
+// VJP of the T-iteration CT iADMM map wrt (cat(x, z, u), sigma_d, mu, tau); the data step's adjoint is A^T A / opnorm^2 with the
+// projector pair standing in for each other's transpose (as in the composed path and in torch_radon).  work = 6*B*R*R floats.
+int pnpx_ct_iadmm_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float* sigma_d, const float* mu, const float* tau,
+                           int param_stride, const float* saved, const float* grad_vars_out, float* grad_vars_in,
+                           float* grad_sigma_d, float* grad_mu, float* grad_tau, float* work, int B, int R, int T,
+                           unsigned long long ticket, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    REQUIRE(sigma_d && mu && tau && grad_vars_out && grad_vars_in && B > 0 && R > 0 && n_view > 0 && T >= 0 &&
+                param_stride >= T && opnorm > 0.f && (T == 0 || (saved && grad_sigma_d && grad_mu && grad_tau && work)),
+            "pnpx_ct_iadmm_backward: bad argument");
+    const int HW = R * R;
+    const size_t is = 3 * (size_t)HW, n = (size_t)HW * B;
+    PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float) * is * B, hipMemcpyDeviceToDevice, s));
+    if (T == 0) return PNPX_OK;
+    CtScratch C;
+    PNPX_TRY(ct_scratch(ctx, B, R, n_view, 0, s, &C));
+    const float op2 = (float)((double)opnorm * (double)opnorm);
+    float *e = work, *J = work + n, *gxr = work + 2 * n, *gd = work + 3 * n, *c_tau = work + 4 * n, *c_mu = work + 5 * n;
+    for (int i = T - 1; i >= 0; --i) {
+      hipLaunchKernelGGL(ct_cotangent_kernel, g1(n), dim3(256), 0, s, grad_vars_in, is, e, HW, B);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(ct_normal_op(C, e, (size_t)HW, nullptr, J, op2, R, n_view, B, s));
+      hipLaunchKernelGGL(ct_adjoint_kernel, g1(n), dim3(256), 0, s, e, J, grad_vars_in, is, saved + ((size_t)T + i) * n,
+                         saved + (2 * (size_t)T + i) * n, mu + i, tau + i, param_stride, HW, B, gxr, c_tau, c_mu);
+      PNPX_LAUNCH_CHECK();
+      hipLaunchKernelGGL(pr_item_sum_kernel, dim3(B), dim3(256), 0, s, c_tau, grad_tau + (size_t)i * B, HW);
+      hipLaunchKernelGGL(pr_item_sum_kernel, dim3(B), dim3(256), 0, s, c_mu, grad_mu + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(unet_denoise_backward_ticket(ctx, saved + (size_t)i * n, sigma_d + i, param_stride, gxr, gd,
+                                            grad_sigma_d + (size_t)i * B, B, R, R, s, ticket ? ticket + i : 0));
+      hipLaunchKernelGGL(ct_adjoint_finish_kernel, g1(n), dim3(256), 0, s, gd, grad_vars_in, is, HW, B);
+      PNPX_LAUNCH_CHECK();
+    }
+    return PNPX_OK;
+  });
+}
+
+// PGSolver_CT.forward; `saved` != NULL (training path): per iteration the denoiser input [T][n] and g = A^T(A x - y0) / opnorm^2 [T][n]
+static int ct_pg_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
+                         const float* sigma_d, const float* tau, int param_stride, int B, int R, int T, float* saved,
+                         unsigned long long* ticket_out, hipStream_t s) {
   REQUIRE(vars_in && vars_out && y0 && sigma_d && tau && B > 0 && R > 0 && n_view > 0 && T >= 0 &&
               param_stride >= T && opnorm > 0.f,
           "pnpx_ct_pg: bad argument");
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (ticket_out) *ticket_out = 0;
   const int HW = R * R;
   const size_t n = (size_t)HW * B;
   if (T == 0) {
     PNPX_HIP(hipMemcpyAsync(vars_out, vars_in, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
     return PNPX_OK;
   }
-  const int det = pnpx_radon_det_count(R);
-  void* p;
-  PNPX_TRY(ctx_scratch(ctx, (2 * n + radon_pad_floats(B, R) + (size_t)B * n_view * det) * sizeof(float) + sizeof(float2) * n_view + 16384, &p));
-  Carver cv{static_cast<char*>(p)};
-  const float2* cs;
-  int det2;
-  PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &cs, &det2));
-  float* d = cv.take<float>(n);
-  float* g = cv.take<float>(n);
-  float* sino = cv.take<float>((size_t)B * n_view * det);
-  float* imgT = cv.take<float>(radon_pad_floats(B, R));
+  CtScratch C;
+  PNPX_TRY(ct_scratch(ctx, B, R, n_view, 2, s, &C));
   const float op2 = (float)((double)opnorm * (double)opnorm);
   for (int i = 0; i < T; ++i) {
     const float* xi = (i == 0) ? vars_in : vars_out;
-    launch_radon_forward(xi, (size_t)HW, y0, sino, cs, imgT, R, n_view, det, B, s);
-    PNPX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(radon_backproject_kernel, g1(n), dim3(256), 0, s, sino, g, cs, R, n_view, det, B, op2);
-    PNPX_LAUNCH_CHECK();
+    float* d = saved ? saved + (size_t)i * n : C.img[0];
+    float* g = saved ? saved + ((size_t)T + i) * n : C.img[1];
+    PNPX_TRY(ct_normal_op(C, xi, (size_t)HW, y0, g, op2, R, n_view, B, s));
     hipLaunchKernelGGL(ct_pg_step_kernel, g1(n), dim3(256), 0, s, g, xi, d, tau + i, param_stride, HW, B);
     PNPX_LAUNCH_CHECK();
-    PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, vars_out, nullptr, B, R, R, s, nullptr));
+    if (saved) {
+      unsigned long long tk = 0;
+      PNPX_TRY(unet_denoise_train(ctx, d, sigma_d + i, param_stride, vars_out, B, R, R, s, &tk));
+      if (i == 0 && ticket_out) *ticket_out = tk;
+    } else {
+      PNPX_TRY(unet_denoise(ctx, d, sigma_d + i, param_stride, vars_out, nullptr, B, R, R, s, nullptr));
+    }
   }
   return PNPX_OK;
+}
+
+int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
+               const float* sigma_d, const float* tau, int param_stride, int B, int R, int T, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return ct_pg_forward(ctx, vars_in, vars_out, y0, n_view, opnorm, sigma_d, tau, param_stride, B, R, T, nullptr, nullptr, s);
+  });
+}
+
+int pnpx_ct_pg_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
+                     const float* sigma_d, const float* tau, int param_stride, int B, int R, int T, float* saved,
+                     unsigned long long* ticket, void* stream) {
+  LOCK_CTX(ctx);
+  REQUIRE((saved || T == 0) && ticket, "pnpx_ct_pg_train: saved / ticket is null");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    return ct_pg_forward(ctx, vars_in, vars_out, y0, n_view, opnorm, sigma_d, tau, param_stride, B, R, T, saved, ticket, s);
+  });
+}
+
+// VJP of the T-iteration CT PG map x' = D(x - tau g(x)) wrt (x, sigma_d, tau): gd = D^T gx';  d/d tau = -<gd, g_i>;
+// gx = gd - tau A^T A gd / opnorm^2.  work = 3*B*R*R floats.
+int pnpx_ct_pg_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float* sigma_d, const float* tau, int param_stride,
+                        const float* saved, const float* grad_vars_out, float* grad_vars_in, float* grad_sigma_d,
+                        float* grad_tau, float* work, int B, int R, int T, unsigned long long ticket, void* stream) {
+  LOCK_CTX(ctx);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return pnpx::guarded(ctx, s, [&]() -> int {
+    REQUIRE(sigma_d && tau && grad_vars_out && grad_vars_in && B > 0 && R > 0 && n_view > 0 && T >= 0 &&
+                param_stride >= T && opnorm > 0.f && (T == 0 || (saved && grad_sigma_d && grad_tau && work)),
+            "pnpx_ct_pg_backward: bad argument");
+    const int HW = R * R;
+    const size_t n = (size_t)HW * B;
+    PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
+    if (T == 0) return PNPX_OK;
+    CtScratch C;
+    PNPX_TRY(ct_scratch(ctx, B, R, n_view, 0, s, &C));
+    const float op2 = (float)((double)opnorm * (double)opnorm);
+    float *gd = work, *J = work + n, *c_tau = work + 2 * n;
+    for (int i = T - 1; i >= 0; --i) {
+      PNPX_TRY(unet_denoise_backward_ticket(ctx, saved + (size_t)i * n, sigma_d + i, param_stride, grad_vars_in, gd,
+                                            grad_sigma_d + (size_t)i * B, B, R, R, s, ticket ? ticket + i : 0));
+      PNPX_TRY(ct_normal_op(C, gd, (size_t)HW, nullptr, J, op2, R, n_view, B, s));
+      hipLaunchKernelGGL(ct_pg_adjoint_kernel, g1(n), dim3(256), 0, s, gd, J, saved + ((size_t)T + i) * n, tau + i,
+                         param_stride, HW, B, grad_vars_in, c_tau);
+      PNPX_LAUNCH_CHECK();
+      hipLaunchKernelGGL(pr_item_sum_kernel, dim3(B), dim3(256), 0, s, c_tau, grad_tau + (size_t)i * B, HW);
+      PNPX_LAUNCH_CHECK();
+    }
+    return PNPX_OK;
   });
 }
 

@@ -635,6 +635,60 @@ def spi_admm(ctx, variables, x0, Kmap, sigma_d, mu, iter_num=None):
     return out
 
 
+def _train_T(B, params, iter_num):
+    ps, T = _params(B, *params)
+    if iter_num is not None:
+        if iter_num > T:
+            raise PnpxError(f"iter_num {iter_num} exceeds the {T} hyper-parameter columns provided")
+        T = iter_num
+    return ps, T
+
+
+def _hyper_grads(T, B, k, device):
+    return [torch.zeros(T, B, dtype=torch.float32, device=device) for _ in range(k)]
+
+
+def spi_admm_train(ctx, variables, x0, Kmap, sigma_d, mu, iter_num=None):
+    """pnpx_spi_admm_train: ADMMSolver_SPI.forward for autograd -> (next state [B,3,H,W], saved [2*T*B*H*W], ticket)."""
+    v = _vars(variables, 3, False)
+    B, _, H, W = v.shape
+    x0, Kmap = _f32(x0, "x0"), _f32(Kmap, "K")
+    if x0.numel() != B * H * W or Kmap.numel() != B * H * W:
+        raise PnpxError("spi_admm: x0 and K must be [B,1,H,W]")
+    ps, T = _train_T(B, (sigma_d, mu), iter_num)
+    out = torch.empty_like(v)
+    saved = torch.empty(2 * T * B * H * W, dtype=torch.float32, device=v.device)
+    if B == 0:
+        return out, saved, 0
+    ticket = C.c_ulonglong(0)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().pnpx_spi_admm_train(ctx.handle, _p(v), _p(out), _p(x0), _p(Kmap), *[_p(p) for p in ps],
+                                             ps[0].shape[1], B, H, W, T, _p(saved), C.byref(ticket), _stream(v)))
+    return out, saved, int(ticket.value)
+
+
+def spi_admm_backward(ctx, x0, Kmap, sigma_d, mu, saved, grad_out, iter_num=None, ticket=0):
+    """pnpx_spi_admm_backward -> (grad variables [B,3,H,W], grad sigma_d, grad mu, each [B,T])."""
+    g = _vars(grad_out, 3, False)
+    B, _, H, W = g.shape
+    x0, Kmap = _f32(x0, "x0"), _f32(Kmap, "K")
+    ps, T = _params(B, sigma_d, mu)
+    T = T if iter_num is None else iter_num
+    if saved.numel() != 2 * T * B * H * W:
+        raise PnpxError("saved does not belong to a forward of this shape / iteration count")
+    gin = torch.empty_like(g)
+    gs = _hyper_grads(T, B, 2, g.device)
+    if B and T:
+        work = torch.empty(3 * B * H * W, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(_lib.lib().pnpx_spi_admm_backward(ctx.handle, _p(x0), _p(Kmap), _p(ps[0]), _p(ps[1]), ps[0].shape[1],
+                                                    _p(saved), _p(g), _p(gin), _p(gs[0]), _p(gs[1]), _p(work), B, H, W, T,
+                                                    int(ticket), _stream(g)))
+    elif B:
+        gin.copy_(g)
+    return (gin, *[x.t().contiguous() for x in gs])
+
+
 # ------------------------------------------------------------------------------------------------- CT
 def radon_det_count(R):
     return int(_lib.lib().pnpx_radon_det_count(int(R)))
@@ -701,6 +755,84 @@ def ct_pg(ctx, variables, y0, n_view, opnorm, sigma_d, tau, iter_num=None):
         check(_lib.lib().pnpx_ct_pg(ctx.handle, _p(v), _p(out), _p(y0), int(n_view), float(opnorm),
                                     *[_p(p) for p in ps], ps[0].shape[1], B, R, T, _stream(v)))
     return out
+
+
+def ct_iadmm_train(ctx, variables, y0, n_view, opnorm, sigma_d, mu, tau, iter_num=None):
+    """pnpx_ct_iadmm_train: IADMMSolver_CT.forward for autograd -> (next state [B,3,R,R], saved [3*T*B*R*R], ticket)."""
+    v = _vars(variables, 3, False)
+    B, _, R, _ = v.shape
+    y0 = _ct_sino(y0, B, R, n_view)
+    ps, T = _train_T(B, (sigma_d, mu, tau), iter_num)
+    out = torch.empty_like(v)
+    saved = torch.empty(3 * T * B * R * R, dtype=torch.float32, device=v.device)
+    if B == 0:
+        return out, saved, 0
+    ticket = C.c_ulonglong(0)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().pnpx_ct_iadmm_train(ctx.handle, _p(v), _p(out), _p(y0), int(n_view), float(opnorm),
+                                             *[_p(p) for p in ps], ps[0].shape[1], B, R, T, _p(saved), C.byref(ticket),
+                                             _stream(v)))
+    return out, saved, int(ticket.value)
+
+
+def ct_iadmm_backward(ctx, n_view, opnorm, sigma_d, mu, tau, saved, grad_out, iter_num=None, ticket=0):
+    """pnpx_ct_iadmm_backward -> (grad variables [B,3,R,R], grad sigma_d, grad mu, grad tau, each [B,T])."""
+    g = _vars(grad_out, 3, False)
+    B, _, R, _ = g.shape
+    ps, T = _params(B, sigma_d, mu, tau)
+    T = T if iter_num is None else iter_num
+    if saved.numel() != 3 * T * B * R * R:
+        raise PnpxError("saved does not belong to a forward of this shape / iteration count")
+    gin = torch.empty_like(g)
+    gs = _hyper_grads(T, B, 3, g.device)
+    if B and T:
+        work = torch.empty(6 * B * R * R, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(_lib.lib().pnpx_ct_iadmm_backward(ctx.handle, int(n_view), float(opnorm), *[_p(p) for p in ps],
+                                                    ps[0].shape[1], _p(saved), _p(g), _p(gin), *[_p(x) for x in gs], _p(work),
+                                                    B, R, T, int(ticket), _stream(g)))
+    elif B:
+        gin.copy_(g)
+    return (gin, *[x.t().contiguous() for x in gs])
+
+
+def ct_pg_train(ctx, variables, y0, n_view, opnorm, sigma_d, tau, iter_num=None):
+    """pnpx_ct_pg_train: PGSolver_CT.forward for autograd -> (next x [B,1,R,R], saved [2*T*B*R*R], ticket)."""
+    v = _vars(variables, 1, False)
+    B, _, R, _ = v.shape
+    y0 = _ct_sino(y0, B, R, n_view)
+    ps, T = _train_T(B, (sigma_d, tau), iter_num)
+    out = torch.empty_like(v)
+    saved = torch.empty(2 * T * B * R * R, dtype=torch.float32, device=v.device)
+    if B == 0:
+        return out, saved, 0
+    ticket = C.c_ulonglong(0)
+    with torch.cuda.device(v.device):
+        check(_lib.lib().pnpx_ct_pg_train(ctx.handle, _p(v), _p(out), _p(y0), int(n_view), float(opnorm),
+                                          *[_p(p) for p in ps], ps[0].shape[1], B, R, T, _p(saved), C.byref(ticket),
+                                          _stream(v)))
+    return out, saved, int(ticket.value)
+
+
+def ct_pg_backward(ctx, n_view, opnorm, sigma_d, tau, saved, grad_out, iter_num=None, ticket=0):
+    """pnpx_ct_pg_backward -> (grad x [B,1,R,R], grad sigma_d, grad tau, each [B,T])."""
+    g = _vars(grad_out, 1, False)
+    B, _, R, _ = g.shape
+    ps, T = _params(B, sigma_d, tau)
+    T = T if iter_num is None else iter_num
+    if saved.numel() != 2 * T * B * R * R:
+        raise PnpxError("saved does not belong to a forward of this shape / iteration count")
+    gin = torch.empty_like(g)
+    gs = _hyper_grads(T, B, 2, g.device)
+    if B and T:
+        work = torch.empty(3 * B * R * R, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(_lib.lib().pnpx_ct_pg_backward(ctx.handle, int(n_view), float(opnorm), *[_p(p) for p in ps], ps[0].shape[1],
+                                                 _p(saved), _p(g), _p(gin), *[_p(x) for x in gs], _p(work), B, R, T,
+                                                 int(ticket), _stream(g)))
+    elif B:
+        gin.copy_(g)
+    return (gin, *[x.t().contiguous() for x in gs])
 
 
 # ------------------------------------------------------------------------------------- episode orchestration (env.hip)

@@ -647,6 +647,88 @@ def pr_iadmm(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: T
 pr_iadmm.register_fake(_same)
 
 
+def _solver_train_ops(name, aux, hypers, train_fn, backward_fn, saved_per_pixel, bwd_takes_aux=True):
+    """Register `pnpx::<name>_train` (+ `_backward` and the autograd formula) for a solver whose native training entry follows the
+    common contract: (variables, *aux, *hyper-parameters, iter_num, ctx) -> (next state, saved, ticket).  `aux` = [(name, schema
+    type)]; non-tensor aux entries (view count, operator norm) travel on the autograd node."""
+    n_aux, n_h = len(aux), len(hypers)
+    aux_sig = [f"{t} {n}" for n, t in aux]
+    hyp_sig = [f"Tensor {h}" for h in hypers]
+    fwd_schema = "(" + ", ".join(["Tensor variables"] + aux_sig + hyp_sig + ["int iter_num", "int ctx"]) + ") -> (Tensor, Tensor, Tensor)"
+    bwd_schema = ("(" + ", ".join(aux_sig + hyp_sig + ["Tensor saved", "Tensor ticket", "Tensor grad_out", "int iter_num", "int ctx"]) +
+                  ") -> (" + ", ".join(["Tensor"] * (1 + n_h)) + ")")
+
+    def n_iter(h0, iter_num):
+        return (h0.shape[1] if h0.dim() == 2 else 1) if iter_num < 0 else iter_num
+
+    def fwd(*a):
+        variables, auxv, hv, (iter_num, cid) = a[0], a[1:1 + n_aux], a[1 + n_aux:1 + n_aux + n_h], a[-2:]
+        out, saved, ticket = train_fn(_ctx(cid, variables), variables, *auxv, *hv, _it(iter_num))
+        return out, saved, torch.tensor([ticket], dtype=torch.int64)
+
+    def fwd_fake(*a):
+        variables, hv, iter_num = a[0], a[1 + n_aux:1 + n_aux + n_h], a[-2]
+        n_px = variables.numel() // variables.shape[1] // (2 if variables.dim() == 5 else 1)
+        return (torch.empty_like(variables, memory_format=torch.contiguous_format),
+                torch.empty((saved_per_pixel * n_iter(hv[0], iter_num) * n_px,), dtype=variables.dtype, device=variables.device),
+                torch.empty((1,), dtype=torch.int64))
+
+    def bwd(*a):
+        auxv, hv = a[:n_aux], a[n_aux:n_aux + n_h]
+        saved, ticket, grad_out, iter_num, cid = a[n_aux + n_h:]
+        lead = auxv if bwd_takes_aux else tuple(v for v, (_, t) in zip(auxv, aux) if t != "Tensor")
+        return backward_fn(_ctx(cid, grad_out), *lead, *hv, saved, grad_out, _it(iter_num), ticket=int(ticket[0]))
+
+    def bwd_fake(*a):
+        hv, grad_out, iter_num = a[n_aux:n_aux + n_h], a[-3], a[-2]
+        e = lambda: torch.empty((grad_out.shape[0], n_iter(hv[0], iter_num)), dtype=grad_out.dtype, device=grad_out.device)
+        return (torch.empty_like(grad_out, memory_format=torch.contiguous_format), *[e() for _ in range(n_h)])
+
+    op_f = _lib_def(f"pnpx::{name}_train", fwd, mutates_args=(), device_types="cuda", schema=fwd_schema)
+    op_f.register_fake(fwd_fake)
+    op_b = _lib_def(f"pnpx::{name}_backward", bwd, mutates_args=(), device_types="cuda", schema=bwd_schema)
+    op_b.register_fake(bwd_fake)
+    tensor_aux = [k for k, (_, t) in enumerate(aux) if t == "Tensor"]
+
+    def setup(ctx, inputs, output):
+        auxv, hv = inputs[1:1 + n_aux], inputs[1 + n_aux:1 + n_aux + n_h]
+        ctx.iter_num, cid = inputs[-2:]
+        _pin(ctx, cid, inputs[0])
+        ctx.plain_aux = {k: v for k, v in enumerate(auxv) if k not in tensor_aux}
+        ctx.save_for_backward(*[auxv[k] for k in tensor_aux], *hv, output[1], output[2])
+
+    def backward(ctx, g_out, _g_saved, _g_ticket):
+        t = ctx.saved_tensors
+        auxv = [None] * n_aux
+        for j, k in enumerate(tensor_aux):
+            auxv[k] = t[j]
+        for k, v in ctx.plain_aux.items():
+            auxv[k] = v
+        hv = t[len(tensor_aux):len(tensor_aux) + n_h]
+        res = getattr(torch.ops.pnpx, f"{name}_backward")(*auxv, *hv, t[-2], t[-1], g_out.contiguous(), ctx.iter_num, ctx.cid)
+
+        def like(g, p):
+            full = torch.zeros_like(p)
+            if p.numel():
+                full.view(p.shape[0], -1)[:, :g.shape[1]] = g
+            return full
+
+        return (res[0], *[None] * n_aux, *[like(g, p) for g, p in zip(res[1:], hv)], None, None)
+
+    op_f.register_autograd(backward, setup_context=setup)
+    return op_f, op_b
+
+
+spi_admm_train, spi_admm_backward = _solver_train_ops(
+    "spi_admm", [("x0", "Tensor"), ("Kmap", "Tensor")], ("sigma_d", "mu"), ops.spi_admm_train, ops.spi_admm_backward, 2)
+ct_iadmm_train, ct_iadmm_backward = _solver_train_ops(
+    "ct_iadmm", [("y0", "Tensor"), ("n_view", "int"), ("opnorm", "float")], ("sigma_d", "mu", "tau"), ops.ct_iadmm_train,
+    ops.ct_iadmm_backward, 3, bwd_takes_aux=False)
+ct_pg_train, ct_pg_backward = _solver_train_ops(
+    "ct_pg", [("y0", "Tensor"), ("n_view", "int"), ("opnorm", "float")], ("sigma_d", "tau"), ops.ct_pg_train, ops.ct_pg_backward, 2,
+    bwd_takes_aux=False)
+
+
 @_lib_def("pnpx::spi_admm", mutates_args=(), device_types="cuda")
 def spi_admm(variables: Tensor, x0: Tensor, Kmap: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int, ctx: int) -> Tensor:
     """ADMMSolver_SPI.forward (tasks/spi/solver.py:17-52)."""
