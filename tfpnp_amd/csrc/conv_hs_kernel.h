@@ -60,7 +60,9 @@ constexpr int hs_nth_tap(int mask, int i) {   // the i-th set bit
     }
   return 0;
 }
-template <int MT, int NBW, int MBW, int NW, int WREG = 0, int TAPS = 0x1FF>
+// NSTG = LDS stages of the software pipeline: 2 = the DMA of step s+1 is in flight while step s is multiplied; 3 / 4 = two /
+// three steps ahead (small-tile instances whose steps are shorter than the DMA latency: deep levels at small batches)
+template <int MT, int NBW, int MBW, int NW, int WREG = 0, int TAPS = 0x1FF, int NSTG = 2>
 struct HsGeom {
   static constexpr int NTAPS = hs_ntaps(TAPS);
   static constexpr int CPS = WREG ? 2 : 1;              // K-chunks per pipeline step
@@ -82,12 +84,13 @@ struct HsGeom {
   static constexpr int W_INSTR = W_BYTES / 1024;
   static constexpr int NWJ = (W_INSTR + NW - 1) / NW;
   static constexpr int STAGE = IN_BYTES + W_BYTES;
-  static constexpr int BIAS_OFF = 2 * STAGE;
+  static constexpr int BIAS_OFF = NSTG * STAGE;
   static constexpr int BIAS_BYTES = WREG ? 256 : HS_BIAS_BYTES;   // WREG: one 32-cout tile
   static constexpr int XWIN_W = TW + 4, XWIN_H = TH + 4;          // WREG == 2: fp32 network-input window of a tile
-  static constexpr int XWIN_OFF = 2 * STAGE + BIAS_BYTES;
+  static constexpr int XWIN_OFF = NSTG * STAGE + BIAS_BYTES;
   static constexpr int XWIN_BYTES = WREG == 2 ? ((XWIN_W * XWIN_H * 4 + 255) & ~255) : 0;
-  static constexpr int LDS_USED = 2 * STAGE + BIAS_BYTES + XWIN_BYTES;
+  static constexpr int DUMMY_OFF = NSTG * STAGE + BIAS_BYTES + XWIN_BYTES;   // NSTG > 2: landing pad of the padding DMA slots
+  static constexpr int LDS_USED = NSTG * STAGE + BIAS_BYTES + XWIN_BYTES + (NSTG > 2 ? 1024 : 0);
   // One workgroup per CU BY CONSTRUCTION: the request is padded past half of the 160 KiB so that two workgroups can
   // never be co-resident (see DESIGN.md "co-residency"); the persistent grid is <= 256 workgroups.
   static constexpr int LDS_BYTES = LDS_USED > 82 * 1024 ? LDS_USED : 82 * 1024;
@@ -95,8 +98,8 @@ struct HsGeom {
   static constexpr int NS = NI + NWJ;
   static constexpr int NST = MTB * NBW * 4;             // 16-byte record stores per wave and tile
   static constexpr int NST_POOL = MTB * (NBW / 2) * 4;  // ... of the fused pool output
-  static_assert(LDS_USED <= 160 * 1024, "tile does not fit the LDS");
-  static_assert(NST + NST_POOL <= 63, "vmcnt is a 6-bit counter");
+  // checked where an instance is actually compiled (conv_hs_kernel), so that shapes can be probed (hs_deep_stages)
+  static constexpr bool FITS = LDS_USED <= 160 * 1024 && (NSTG - 2) * NS + NST + NST_POOL <= 63;   // LDS; vmcnt is a 6-bit counter
 };
 
 // lo halves of a hi/lo pair: f16(v0 - hi.lo16) | f16(v1 - hi.hi16) << 16, straight from the packed hi register
@@ -144,9 +147,11 @@ struct HsUpsGeom {   // low-resolution window feeding one (TH+2) x (TW+2) halo
   static constexpr int BYTES = INSTR * 1024;
 };
 
-template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF>
+template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF, int PIPE = 2>
 __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES * UPS) / 4) void conv_hs_kernel(ConvHsArgs a) {
-  using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS>;
+  using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS, PIPE>;
+  static_assert(PIPE == 2 || (PIPE >= 3 && PIPE <= 4 && !UPS && !WREG), "deep pipelines: generic instances only");
+  static_assert(G::FITS, "tile does not fit the LDS, or more DMA instructions in flight than the 6-bit vmcnt can count");
   static_assert(TAPS == 0x1FF || (!WREG && !UPS), "sparse-tap layers: generic instances only");
   static_assert(!(WREG && UPS) && (!WREG || MT == 32), "WREG: 32-cout single-source layers only");
   constexpr bool FIRST = (WREG == 2);   // the layer's input halo is computed from the fp32 network input (no halo DMA)
@@ -199,9 +204,19 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
 #endif
   }
 
+  // Weight slices are packed [cout / w_mt][chunk][tap][hi,lo][kg][w_mt] x 16 B.  A 32-cout instance may run over a
+  // 64-cout packing ("half tiles": twice the tiles for batches that do not fill the chip, same K order -> same bits):
+  // its slice is then every other 512-byte run of the 64-cout slice, gathered by the DMA's per-lane source address.
+  const bool half_tiles = (MT == 32) && (a.w_mt == 64);
+  // A tile carries its three base addresses (first / second source at the tile's halo origin, weight slice of its cout tile),
+  // computed once where the walk is decoded: a pipeline step then costs one multiply-add per operand instead of the whole
+  // 64-bit index arithmetic (one wave per SIMD has nothing to hide ~400 clocks of scalar code per step behind: tools/trace_conv.py)
   struct Tile {
     int ct, b, x0, y0;
+    const char *s0, *s1, *w;
   };
+  const size_t plane_bytes = (size_t)HpWp * 32;                         // one channel group of one image
+  const size_t w_step = half_tiles ? 2 * (size_t)G::W_BYTES : (size_t)G::W_BYTES;   // weight bytes per K-chunk of a cout tile
   auto fdiv = [](unsigned n, const HsFastDiv& f) { return f.d > 1 ? __umulhi(n, f.m) : n; };
   auto valid = [&](int j) { return nx * (int)fdiv(j, a.div_nct) + xcd < nregions; };
   auto decode = [&](int j) {
@@ -216,26 +231,27 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     T.b = t2;
     T.x0 = tx * G::TW;
     T.y0 = ty * G::TH;
+    const size_t pix = ((size_t)T.y0 * a.Wp + T.x0) * 32;
+    T.s0 = a.in0 + (size_t)T.b * a.G0t * plane_bytes + pix;
+    T.s1 = a.in1 + ((size_t)T.b * a.G1) * plane_bytes + pix - (size_t)a.G0 * plane_bytes;   // + g0 * plane_bytes for g0 >= G0
+    T.w = half_tiles ? a.wpk + (size_t)(T.ct >> 1) * nch * w_step + (T.ct & 1) * 512 : a.wpk + (size_t)T.ct * nch * w_step;
     return T;
   };
   auto chunk_src = [&](const Tile& T, int chunk) -> const char* {   // chunk = pipeline step (CPS K-chunks)
     const int g0 = chunk * 2 * G::CPS;
-    const char* src = (g0 < a.G0) ? a.in0 + ((size_t)T.b * a.G0t + g0) * HpWp * 32
-                                  : a.in1 + ((size_t)T.b * a.G1 + (g0 - a.G0)) * HpWp * 32;
 #ifdef PNPX_TUNING
-    if (a.abl & 4) return src + ((size_t)T.y0 * a.Wp + T.x0) * 16;
-    if (a.abl & 16) return a.in0 + (size_t)g0 * HpWp * 32 + (size_t)(blockIdx.x & 7) * a.Wp * 32;   // ablation 16 (invalid results): every tile reads the same cache-resident halo
+    if (a.abl & (4 | 16)) {
+      const char* src = (g0 < a.G0) ? a.in0 + ((size_t)T.b * a.G0t + g0) * HpWp * 32
+                                    : a.in1 + ((size_t)T.b * a.G1 + (g0 - a.G0)) * HpWp * 32;
+      if (a.abl & 4) return src + ((size_t)T.y0 * a.Wp + T.x0) * 16;
+      return a.in0 + (size_t)g0 * HpWp * 32 + (size_t)(blockIdx.x & 7) * a.Wp * 32;   // ablation 16 (invalid results): every tile reads the same cache-resident halo
+    }
 #endif
-    return src + ((size_t)T.y0 * a.Wp + T.x0) * 32;
+    return ((g0 < a.G0) ? T.s0 : T.s1) + (size_t)g0 * plane_bytes;
   };
-  // Weight slices are packed [cout / w_mt][chunk][tap][hi,lo][kg][w_mt] x 16 B.  A 32-cout instance may run over a
-  // 64-cout packing ("half tiles": twice the tiles for batches that do not fill the chip, same K order -> same bits):
-  // its slice is then every other 512-byte run of the 64-cout slice, gathered by the DMA's per-lane source address.
-  const bool half_tiles = (MT == 32) && (a.w_mt == 64);
   auto chunk_w = [&](const Tile& T, int chunk) -> const char* {
     if constexpr (WREG) return a.wpk;   // unused: no weight DMA
-    if (half_tiles) return a.wpk + ((size_t)(T.ct >> 1) * nch + chunk) * (2 * G::W_BYTES) + (T.ct & 1) * 512;
-    return a.wpk + ((size_t)T.ct * nch + chunk) * G::W_BYTES;
+    return T.w + (size_t)chunk * w_step;
   };
   bool next_halo_by_dma = true;   // UPS: false while the next step's chunk comes from the low-resolution source
   auto issue_slot = [&](int slot, const char* src, const char* wsrc, char* lstage) {
@@ -245,12 +261,14 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
       if (UPS && !next_halo_by_dma) return;
       const int instr = wave + NW * slot;
       if (NW * slot + NW - 1 < G::IN_INSTR || instr < G::IN_INSTR) glds16b(src + ioff[slot], lstage + instr * 1024);
+      else if constexpr (PIPE > 2) glds16b(src, lds + G::DUMMY_OFF);   // every wave issues exactly NS DMAs per step (counted waits)
     } else {
       const int j = wave + NW * (slot - G::NI);
       if (NW * (slot - G::NI) + NW - 1 < G::W_INSTR || j < G::W_INSTR)
         // 16-byte piece i = j*64 + lane of the slice: row r = i / 32 (tap, half, kg), cout m = i % 32
         glds16b(wsrc + (half_tiles ? (j * 2 + (lane >> 5)) * 1024 + (lane & 31) * 16 : j * 1024 + lane * 16),
                 lstage + G::IN_BYTES + j * 1024);
+      else if constexpr (PIPE > 2) glds16b(src, lds + G::DUMMY_OFF);
     }
   };
 
@@ -312,10 +330,10 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     }
   };
   // KIND: 0 = nothing follows, 1 = the next step's halo + weights come by DMA
-  auto body = [&](auto kind_tag, int stage, const char* nsrc, const char* nw) {
+  auto body = [&](auto kind_tag, int stage, int dst_stage, const char* nsrc, const char* nw) {
     constexpr int KIND = decltype(kind_tag)::value;
     constexpr bool MORE = (KIND == 1);
-    char* nstage = lds + (stage ^ 1) * G::STAGE;
+    char* nstage = lds + dst_stage * G::STAGE;
     const char* lb = lds + stage * G::STAGE + b_lane;
     const char* la = lds + stage * G::STAGE + a_lane;
     constexpr int NTAP = G::NTAPS * G::CPS;                       // (chunk, tap) pairs of one step
@@ -757,11 +775,37 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   Tile cur = decode(tile);
   int ch = 0, stage = 0;
   if constexpr (FIRST) xwin_fetch(cur);
+  // prefetch cursor: the step whose DMA is issued next, PIPE - 1 steps ahead of the step being multiplied
+  [[maybe_unused]] int ptile = tile, pch = 0, inflight = 0;
+  [[maybe_unused]] Tile pT = cur;
+  [[maybe_unused]] bool pvalid = true;
+  [[maybe_unused]] auto padvance = [&]() {
+    if (++pch == nch) {
+      pch = 0;
+      ptile += nslot;
+      pvalid = valid(ptile);
+      if (pvalid) pT = decode(ptile);
+    }
+  };
   if (!producer) {
-    const char* src = chunk_src(cur, 0);
-    const char* w = chunk_w(cur, 0);
+    if constexpr (PIPE == 2) {
+      const char* src = chunk_src(cur, 0);
+      const char* w = chunk_w(cur, 0);
 #pragma unroll
-    for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, w, lds);
+      for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, w, lds);
+    } else {
+#pragma unroll
+      for (int k = 0; k < PIPE - 1; ++k) {
+        if (pvalid) {
+          const char* src = chunk_src(pT, pch);
+          const char* w = chunk_w(pT, pch);
+#pragma unroll
+          for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, w, lds + k * G::STAGE);
+          ++inflight;
+          padvance();
+        }
+      }
+    }
   } else if (2 < nch && chunk_is_up(2)) {
     lr_issue(cur, 2, lr_base + 2 * U::BYTES);   // the window of step 2 (its (A) would have been in step -1)
   }
@@ -780,13 +824,30 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     // this step's operands have landed (every wave waits for its own DMA, then the barrier publishes them); stores
     // of the tile finished in the previous step stay in flight
     mark(1);
-    if (EPI != EPI_OUTC && stores_behind) {
-      if (pool_on)
-        wait_vmcnt<G::NST + G::NST_POOL>();
-      else
-        wait_vmcnt<G::NST>();
+    if constexpr (PIPE == 2) {
+      if (EPI != EPI_OUTC && stores_behind) {
+        if (pool_on)
+          wait_vmcnt<G::NST + G::NST_POOL>();
+        else
+          wait_vmcnt<G::NST>();
+      } else {
+        wait_vmcnt<0>();
+      }
     } else {
-      wait_vmcnt<0>();
+      // younger than this step's DMA: the DMA of the inflight - 1 steps issued after it (NS instructions per wave each) and the
+      // record stores of the tile finished in the previous step
+      static_assert(EPI == EPI_ACT || EPI == EPI_DMASK, "deep pipelines: record-store epilogues only");
+      const int st = stores_behind ? (pool_on ? 2 : 1) : 0;
+      auto wait_for = [&](auto ahead_tag) {
+        constexpr int A = decltype(ahead_tag)::value * G::NS;
+        if (st == 0) wait_vmcnt<A>();
+        else if (st == 1) wait_vmcnt<A + G::NST>();
+        else wait_vmcnt<A + G::NST + G::NST_POOL>();
+      };
+      if (inflight <= 1) wait_for(std::integral_constant<int, 0>{});
+      else if (inflight == 2 || PIPE == 3) wait_for(std::integral_constant<int, 1>{});
+      else wait_for(std::integral_constant<int, PIPE == 3 ? 1 : 2>{});
+      --inflight;
     }
     mark(2);
     __builtin_amdgcn_s_barrier();
@@ -823,10 +884,21 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     if constexpr (EPI == EPI_DMASK) {
       if (ch == 0) fetch_masks(cur);
     }
-    if (!has_next) {
-      body(std::integral_constant<int, 0>{}, stage, nullptr, nullptr);
+    if constexpr (PIPE == 2) {
+      if (!has_next) {
+        body(std::integral_constant<int, 0>{}, stage, 0, nullptr, nullptr);
+      } else {
+        body(std::integral_constant<int, 1>{}, stage, stage ^ 1, chunk_src(nxt, nchk), chunk_w(nxt, nchk));
+      }
     } else {
-      body(std::integral_constant<int, 1>{}, stage, chunk_src(nxt, nchk), chunk_w(nxt, nchk));
+      // the stage read in the previous step (every wave has passed this step's barrier) takes the step PIPE - 1 ahead
+      if (!pvalid) {
+        body(std::integral_constant<int, 0>{}, stage, 0, nullptr, nullptr);
+      } else {
+        body(std::integral_constant<int, 1>{}, stage, stage == 0 ? PIPE - 1 : stage - 1, chunk_src(pT, pch), chunk_w(pT, pch));
+        ++inflight;
+        padvance();
+      }
     }
     mark(4);
     stores_behind = false;
@@ -852,7 +924,7 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     tile = ntile;
     ch = nchk;
     cur = nxt;
-    stage ^= 1;
+    stage = (PIPE == 2) ? (stage ^ 1) : (stage + 1 == PIPE ? 0 : stage + 1);
   }
 #ifdef PNPX_TUNING
   if (a.wgt && tid == 0) {
@@ -883,12 +955,12 @@ inline int ensure_dyn_lds(const void* func, int bytes) {
   return PNPX_OK;
 }
 
-template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF>
+template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF, int PIPE = 2>
 static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
-  using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS>;
+  using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS, PIPE>;
   constexpr int LDS_REQ = G::LDS_BYTES + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES;
   static_assert(G::LDS_USED + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES <= 160 * 1024, "no LDS room for the low-resolution windows");
-  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS>), LDS_REQ));
+  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS, PIPE>), LDS_REQ));
   ConvHsArgs a = a0;
   a.tilesX = (a.W + G::TW - 1) / G::TW;
   a.tilesY = (a.H + G::TH - 1) / G::TH;
@@ -944,7 +1016,7 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
     a.trace = tbuf;
   }
 #endif
-  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS>), dim3((unsigned)grid),
+  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS, PIPE>), dim3((unsigned)grid),
                      dim3((NW + HS_UPS_WAVES * UPS) * 64), lds_req, s, a);
   PNPX_LAUNCH_CHECK();
 #ifdef PNPX_TUNING
@@ -990,10 +1062,31 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
 
 struct HsChoice {
   int nbw, nw;
+  bool deep = false;   // use the 3 / 4-stage instance of this shape if there is one
 };
+
+// deepest pipeline (stages) whose LDS fits, for the shapes that have deep instances: four waves, 16- / 32-pixel-wide blocks,
+// one or two block rows per wave, plain activation epilogue, all nine taps
+template <int MT, int NBW, int MBW>
+constexpr int hs_deep_stages() {
+  if (MBW != 16 && MBW != 32) return 2;
+  if (NBW > 2) return 2;
+  if (HsGeom<MT, NBW, MBW, 4, 0, 0x1FF, 4>::FITS) return 4;
+  if (HsGeom<MT, NBW, MBW, 4, 0, 0x1FF, 3>::FITS) return 3;
+  return 2;
+}
+template <int MT, int NBW, int MBW, int EPI, int TAPS>
+static int launch_hs_nw4(const ConvHsArgs& a, int B, bool deep, hipStream_t s) {
+  if constexpr (EPI == EPI_ACT && TAPS == 0x1FF && hs_deep_stages<MT, NBW, MBW>() > 2) {
+    if (deep) return launch_hs_cfg<MT, NBW, MBW, 4, EPI, 0, 0, TAPS, hs_deep_stages<MT, NBW, MBW>()>(a, B, s);
+  }
+  return launch_hs_cfg<MT, NBW, MBW, 4, EPI, 0, 0, TAPS>(a, B, s);
+}
 
 template <int MT, int MBW, int EPI, int TAPS = 0x1FF>
 static int launch_hs_mbw(const ConvHsArgs& a, int B, HsChoice c, hipStream_t s) {
+  if (c.nw == 4 && c.nbw == 2) return launch_hs_nw4<MT, 2, MBW, EPI, TAPS>(a, B, c.deep, s);
+  if (c.nw == 4 && c.nbw == 1) return launch_hs_nw4<MT, 1, MBW, EPI, TAPS>(a, B, c.deep, s);
   if (c.nw == 8) {
     if (c.nbw >= 2) return launch_hs_cfg<MT, 2, MBW, 8, EPI, 0, 0, TAPS>(a, B, s);
     return launch_hs_cfg<MT, 1, MBW, 8, EPI, 0, 0, TAPS>(a, B, s);
