@@ -170,7 +170,15 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
     const int mbw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
     const int th = c64.nw * c64.nbw * (32 / mbw);
     const long long tiles64 = (long long)a.nct * ((W + mbw - 1) / mbw) * ((H + th - 1) / th) * B;
-    if (tiles64 <= 128) {
+    bool half = tiles64 <= 128;
+#ifdef PNPX_TUNING   // PNPX_HS_HALF_<W>=1 / 0: force half tiles on / off at that width
+    {
+      char key[64];
+      snprintf(key, sizeof(key), "PNPX_HS_HALF_%d", W);
+      if (const char* e = getenv(key)) half = atoi(e) != 0;
+    }
+#endif
+    if (half) {
       mt_run = 32;
       a.nct = L.cout / 32;
     }
