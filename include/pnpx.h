@@ -64,9 +64,6 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *      re-compute.  "train_cache_release" (any value): give the ring's memory back now, budget unchanged.
  *  "wreg" (default 2): weights-in-registers instances of the 32 -> 32 channel convolutions (0 = generic kernel, 1 = four
  *      waves x four pixel blocks, 2 = eight waves x two pixel blocks); bit-identical results.
- *  "deep_pipe" (default 1): three / four LDS stages (DMA two / three steps ahead) for the small-tile convolution launches of
- *      deep levels when a workgroup has at most two tiles to hide the load latency behind (small batches); 0 = off, 2 = always;
- *      bit-identical results.
  *  "chains" (default 0 = automatic): run a denoiser forward as n independent launch chains over slices of the batch on
  *      side streams (pays for small batches whose launches cannot fill the chip; bit-identical per image).
  *  "fft_affine" (default 1), "fft_tile" (default 0 = 1024 points): XCD-affine image mapping and tile size of the FFT passes.

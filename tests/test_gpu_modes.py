@@ -291,14 +291,13 @@ def test_fold_first_option_is_bit_identical(unet_params):
 
 
 def test_round3_execution_options_are_bit_identical(unet_params):
-    """wreg (weights-in-registers instances), chains (independent launch chains over slices of the batch), deep_pipe (3 / 4-stage
-    LDS pipelines of the small-tile instances), fft_affine / fft_tile (FFT pass mapping and tile size) only change HOW the work
-    is scheduled: outputs must not move by a bit."""
+    """wreg (weights-in-registers instances), chains (independent launch chains over slices of the batch), fft_affine /
+    fft_tile (FFT pass mapping and tile size) only change HOW the work is scheduled: outputs must not move by a bit."""
     from tfpnp_amd.pnp import UNetDenoiser2D
     from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
     den = UNetDenoiser2D(state_dict=unet_params)
     ctx = den.context(dev())
-    defaults = {k: ctx.get_option(k) for k in ("wreg", "chains", "fft_affine", "fft_tile", "deep_pipe")}
+    defaults = {k: ctx.get_option(k) for k in ("wreg", "chains", "fft_affine", "fft_tile")}
     try:
         for (B, H, W) in [(24, 256, 256), (7, 128, 160), (6, 256, 256), (1, 64, 48), (3, 32, 32)]:
             x, s = denoiser_inputs(B, H, W, 91)
@@ -311,12 +310,6 @@ def test_round3_execution_options_are_bit_identical(unet_params):
                     pre = den.forward_preclamp(x, s)[1]
                     ref = pre.clone() if ref is None else ref
                     assert torch.equal(pre, ref), (B, H, W, wreg, chains)
-            ctx.set_option("wreg", defaults["wreg"])
-            for deep in (0, 2, 1):        # never / whenever an instance exists / automatic (<= 2 tiles per workgroup)
-                for chains in (1, 2):
-                    ctx.set_option("deep_pipe", deep)
-                    ctx.set_option("chains", chains)
-                    assert torch.equal(den.forward_preclamp(x, s)[1], ref), (B, H, W, "deep_pipe", deep, chains)
         ctx.set_option("wreg", defaults["wreg"])
         ctx.set_option("chains", defaults["chains"])
         d = synth.make_csmri_batch(9, 256, 256, ratio=4, seed=17)      # 9 images: one full XCD group + a plain-mapped image

@@ -220,10 +220,6 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_chains = value;
     return PNPX_OK;
   }
-  if (is("deep_pipe") && value >= 0 && value <= 2) {
-    ctx->opt_deep_pipe = value;
-    return PNPX_OK;
-  }
   if (is("wreg") && value >= 0 && value <= 2) {
     ctx->opt_wreg = value;
     return PNPX_OK;
@@ -270,7 +266,6 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fuse_first")) *value = ctx->opt_fuse_first;
   else if (is("fuse_up")) *value = ctx->opt_fuse_up;
   else if (is("wreg")) *value = ctx->opt_wreg;
-  else if (is("deep_pipe")) *value = ctx->opt_deep_pipe;
   else if (is("chains")) *value = ctx->opt_chains;
   else if (is("fold_first")) *value = ctx->opt_fold_first;
   else if (is("policy_s2_hs")) *value = ctx->opt_policy_s2_hs;

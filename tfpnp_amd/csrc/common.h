@@ -150,7 +150,6 @@ struct pnpx_ctx {
   std::vector<hipStream_t> side_streams;
   std::vector<hipEvent_t> side_joins;
   hipEvent_t side_fork = nullptr;
-  int opt_deep_pipe = 1;           // 3 / 4-stage LDS pipelines for small-tile launches that leave <= 2 tiles per workgroup (0 off, 1 auto, 2 always)
   int opt_wreg = 2;                // weights-in-registers instances for the 32 -> 32 channel layers (0 off, 1 / 2 = shape)
   int opt_range_guard = 1;         // 0 off, 1 sticky flag + latch to conv_mode 0, 2 strict (sync + transparent re-run)
   int opt_train_cache_gb = -1;     // training path: keep the activations of up to this many GiB of denoiser forwards for

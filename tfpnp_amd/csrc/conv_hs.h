@@ -28,7 +28,6 @@ inline HsFastDiv hs_fastdiv(unsigned d) {
 }
 
 struct ConvHsArgs {
-  int deep_pipe = 0;   // host side only: ConvHsFuse::deep_pipe (hs_choose)
   const char* in0;   // HS8 tensor, G0 groups of 8 channels
   const char* in1;   // second source (channel concat), G1 groups
   const char* wpk;
@@ -93,10 +92,6 @@ struct ConvHsFuse {       // optional fused work
   // cin = cout = 32 single-source layers: weights in registers, one pipeline step per tile (conv_hs_kernel.h WREG):
   // 0 = generic kernel, 1 = four waves x four pixel blocks, 2 = eight waves x two pixel blocks.  Same K order: same bits.
   int wreg = 2;
-  // small-tile launches (16- / 32-pixel-wide blocks, four waves) whose steps are shorter than the DMA latency: prefetch two or
-  // three steps ahead through 3 / 4 LDS stages (conv_hs_kernel.h PIPE).  0 = never, 1 = when a workgroup has <= 2 tiles to
-  // amortise the latency over (deep levels of small batches), 2 = whenever such an instance exists.  Same K order: same bits.
-  int deep_pipe = 1;
   // sparse-tap layers (EPI_ACT only): bit mask of the 3x3 taps the layer was PACKED with (pack_conv_weights_hs_taps);
   // 0x1FF = ordinary 3x3.  in0_groups: channel groups per image of the in0 tensor when the layer reads only its first G0.
   int taps = 0x1FF;

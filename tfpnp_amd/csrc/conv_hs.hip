@@ -79,9 +79,6 @@ HsChoice hs_choose(int mt, const ConvHsArgs& a, int B) {
   tuning_override(mt, a.W, &c);
 #endif
   if (a.pool_out && c.nbw < 2) c.nbw = 2;   // the fused 2x2 pool pairs two rows held by one wave
-  // deep-pipeline instances (four waves, 16- / 32-pixel blocks): when a workgroup has at most two tiles the DMA latency of every
-  // step is exposed (16 x 16 level at B = 6: 32 steps of 0.36 us of MFMA work against ~1.4 us of load latency)
-  c.deep = c.nw == 4 && (a.deep_pipe == 2 || (a.deep_pipe == 1 && blocks(4 * c.nbw) <= 512));
   return c;
 }
 
@@ -132,7 +129,6 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.range_flag = fuse.range_flag;
   a.trace = nullptr;
   a.wgt = nullptr;
-  a.deep_pipe = fuse.deep_pipe;
   a.abl = 0;
 #ifdef PNPX_TUNING
   if (const char* e = getenv("PNPX_HS_ABL")) a.abl = atoi(e);

@@ -60,9 +60,7 @@ constexpr int hs_nth_tap(int mask, int i) {   // the i-th set bit
     }
   return 0;
 }
-// NSTG = LDS stages of the software pipeline: 2 = the DMA of step s+1 is in flight while step s is multiplied; 3 / 4 = two /
-// three steps ahead (small-tile instances whose steps are shorter than the DMA latency: deep levels at small batches)
-template <int MT, int NBW, int MBW, int NW, int WREG = 0, int TAPS = 0x1FF, int NSTG = 2>
+template <int MT, int NBW, int MBW, int NW, int WREG = 0, int TAPS = 0x1FF>
 struct HsGeom {
   static constexpr int NTAPS = hs_ntaps(TAPS);
   static constexpr int CPS = WREG ? 2 : 1;              // K-chunks per pipeline step
@@ -84,13 +82,12 @@ struct HsGeom {
   static constexpr int W_INSTR = W_BYTES / 1024;
   static constexpr int NWJ = (W_INSTR + NW - 1) / NW;
   static constexpr int STAGE = IN_BYTES + W_BYTES;
-  static constexpr int BIAS_OFF = NSTG * STAGE;
+  static constexpr int BIAS_OFF = 2 * STAGE;
   static constexpr int BIAS_BYTES = WREG ? 256 : HS_BIAS_BYTES;   // WREG: one 32-cout tile
   static constexpr int XWIN_W = TW + 4, XWIN_H = TH + 4;          // WREG == 2: fp32 network-input window of a tile
-  static constexpr int XWIN_OFF = NSTG * STAGE + BIAS_BYTES;
+  static constexpr int XWIN_OFF = 2 * STAGE + BIAS_BYTES;
   static constexpr int XWIN_BYTES = WREG == 2 ? ((XWIN_W * XWIN_H * 4 + 255) & ~255) : 0;
-  static constexpr int DUMMY_OFF = NSTG * STAGE + BIAS_BYTES + XWIN_BYTES;   // NSTG > 2: landing pad of the padding DMA slots
-  static constexpr int LDS_USED = NSTG * STAGE + BIAS_BYTES + XWIN_BYTES + (NSTG > 2 ? 1024 : 0);
+  static constexpr int LDS_USED = 2 * STAGE + BIAS_BYTES + XWIN_BYTES;
   // One workgroup per CU BY CONSTRUCTION: the request is padded past half of the 160 KiB so that two workgroups can
   // never be co-resident (see DESIGN.md "co-residency"); the persistent grid is <= 256 workgroups.
   static constexpr int LDS_BYTES = LDS_USED > 82 * 1024 ? LDS_USED : 82 * 1024;
@@ -98,8 +95,8 @@ struct HsGeom {
   static constexpr int NS = NI + NWJ;
   static constexpr int NST = MTB * NBW * 4;             // 16-byte record stores per wave and tile
   static constexpr int NST_POOL = MTB * (NBW / 2) * 4;  // ... of the fused pool output
-  // checked where an instance is actually compiled (conv_hs_kernel), so that shapes can be probed (hs_deep_stages)
-  static constexpr bool FITS = LDS_USED <= 160 * 1024 && (NSTG - 2) * NS + NST + NST_POOL <= 63;   // LDS; vmcnt is a 6-bit counter
+  static_assert(LDS_USED <= 160 * 1024, "tile does not fit the LDS");
+  static_assert(NST + NST_POOL <= 63, "vmcnt is a 6-bit counter");
 };
 
 // lo halves of a hi/lo pair: f16(v0 - hi.lo16) | f16(v1 - hi.hi16) << 16, straight from the packed hi register
@@ -147,11 +144,13 @@ struct HsUpsGeom {   // low-resolution window feeding one (TH+2) x (TW+2) halo
   static constexpr int BYTES = INSTR * 1024;
 };
 
-template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF, int PIPE = 2>
-__global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES * UPS) / 4) void conv_hs_kernel(ConvHsArgs a) {
-  using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS, PIPE>;
-  static_assert(PIPE == 2 || (PIPE >= 3 && PIPE <= 4 && !UPS && !WREG), "deep pipelines: generic instances only");
-  static_assert(G::FITS, "tile does not fit the LDS, or more DMA instructions in flight than the 6-bit vmcnt can count");
+template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF>
+// (register budget: four-wave instances with at most four 32 x 32 accumulators per wave are compiled for 256 registers like the
+// eight-wave ones -- with the 512-register budget of one wave per SIMD the compiler keeps the accumulators in VGPRs across the
+// loop and copies them to AGPRs and back around every step's MFMAs: 64 v_accvgpr moves per step.  Occupancy is set by LDS.)
+__global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64,
+                             (NW == 4 && !UPS && !WREG && (MT / 32) * NBW <= (EPI == EPI_DMASK ? 2 : 4)) ? 2 : (NW + HS_UPS_WAVES * UPS) / 4) void conv_hs_kernel(ConvHsArgs a) {
+  using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS>;
   static_assert(TAPS == 0x1FF || (!WREG && !UPS), "sparse-tap layers: generic instances only");
   static_assert(!(WREG && UPS) && (!WREG || MT == 32), "WREG: 32-cout single-source layers only");
   constexpr bool FIRST = (WREG == 2);   // the layer's input halo is computed from the fp32 network input (no halo DMA)
@@ -210,7 +209,7 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   const bool half_tiles = (MT == 32) && (a.w_mt == 64);
   // A tile carries its three base addresses (first / second source at the tile's halo origin, weight slice of its cout tile),
   // computed once where the walk is decoded: a pipeline step then costs one multiply-add per operand instead of the whole
-  // 64-bit index arithmetic (one wave per SIMD has nothing to hide ~400 clocks of scalar code per step behind: tools/trace_conv.py)
+  // 64-bit index arithmetic (one wave per SIMD has nothing to hide scalar code behind)
   struct Tile {
     int ct, b, x0, y0;
     const char *s0, *s1, *w;
@@ -261,14 +260,12 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
       if (UPS && !next_halo_by_dma) return;
       const int instr = wave + NW * slot;
       if (NW * slot + NW - 1 < G::IN_INSTR || instr < G::IN_INSTR) glds16b(src + ioff[slot], lstage + instr * 1024);
-      else if constexpr (PIPE > 2) glds16b(src, lds + G::DUMMY_OFF);   // every wave issues exactly NS DMAs per step (counted waits)
     } else {
       const int j = wave + NW * (slot - G::NI);
       if (NW * (slot - G::NI) + NW - 1 < G::W_INSTR || j < G::W_INSTR)
         // 16-byte piece i = j*64 + lane of the slice: row r = i / 32 (tap, half, kg), cout m = i % 32
         glds16b(wsrc + (half_tiles ? (j * 2 + (lane >> 5)) * 1024 + (lane & 31) * 16 : j * 1024 + lane * 16),
                 lstage + G::IN_BYTES + j * 1024);
-      else if constexpr (PIPE > 2) glds16b(src, lds + G::DUMMY_OFF);
     }
   };
 
@@ -330,10 +327,10 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     }
   };
   // KIND: 0 = nothing follows, 1 = the next step's halo + weights come by DMA
-  auto body = [&](auto kind_tag, int stage, int dst_stage, const char* nsrc, const char* nw) {
+  auto body = [&](auto kind_tag, int stage, const char* nsrc, const char* nw) {
     constexpr int KIND = decltype(kind_tag)::value;
     constexpr bool MORE = (KIND == 1);
-    char* nstage = lds + dst_stage * G::STAGE;
+    char* nstage = lds + (stage ^ 1) * G::STAGE;
     const char* lb = lds + stage * G::STAGE + b_lane;
     const char* la = lds + stage * G::STAGE + a_lane;
     constexpr int NTAP = G::NTAPS * G::CPS;                       // (chunk, tap) pairs of one step
@@ -775,37 +772,11 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
   Tile cur = decode(tile);
   int ch = 0, stage = 0;
   if constexpr (FIRST) xwin_fetch(cur);
-  // prefetch cursor: the step whose DMA is issued next, PIPE - 1 steps ahead of the step being multiplied
-  [[maybe_unused]] int ptile = tile, pch = 0, inflight = 0;
-  [[maybe_unused]] Tile pT = cur;
-  [[maybe_unused]] bool pvalid = true;
-  [[maybe_unused]] auto padvance = [&]() {
-    if (++pch == nch) {
-      pch = 0;
-      ptile += nslot;
-      pvalid = valid(ptile);
-      if (pvalid) pT = decode(ptile);
-    }
-  };
   if (!producer) {
-    if constexpr (PIPE == 2) {
-      const char* src = chunk_src(cur, 0);
-      const char* w = chunk_w(cur, 0);
+    const char* src = chunk_src(cur, 0);
+    const char* w = chunk_w(cur, 0);
 #pragma unroll
-      for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, w, lds);
-    } else {
-#pragma unroll
-      for (int k = 0; k < PIPE - 1; ++k) {
-        if (pvalid) {
-          const char* src = chunk_src(pT, pch);
-          const char* w = chunk_w(pT, pch);
-#pragma unroll
-          for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, w, lds + k * G::STAGE);
-          ++inflight;
-          padvance();
-        }
-      }
-    }
+    for (int sl = 0; sl < G::NS; ++sl) issue_slot(sl, src, w, lds);
   } else if (2 < nch && chunk_is_up(2)) {
     lr_issue(cur, 2, lr_base + 2 * U::BYTES);   // the window of step 2 (its (A) would have been in step -1)
   }
@@ -824,30 +795,13 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     // this step's operands have landed (every wave waits for its own DMA, then the barrier publishes them); stores
     // of the tile finished in the previous step stay in flight
     mark(1);
-    if constexpr (PIPE == 2) {
-      if (EPI != EPI_OUTC && stores_behind) {
-        if (pool_on)
-          wait_vmcnt<G::NST + G::NST_POOL>();
-        else
-          wait_vmcnt<G::NST>();
-      } else {
-        wait_vmcnt<0>();
-      }
+    if (EPI != EPI_OUTC && stores_behind) {
+      if (pool_on)
+        wait_vmcnt<G::NST + G::NST_POOL>();
+      else
+        wait_vmcnt<G::NST>();
     } else {
-      // younger than this step's DMA: the DMA of the inflight - 1 steps issued after it (NS instructions per wave each) and the
-      // record stores of the tile finished in the previous step
-      static_assert(EPI == EPI_ACT || EPI == EPI_DMASK, "deep pipelines: record-store epilogues only");
-      const int st = stores_behind ? (pool_on ? 2 : 1) : 0;
-      auto wait_for = [&](auto ahead_tag) {
-        constexpr int A = decltype(ahead_tag)::value * G::NS;
-        if (st == 0) wait_vmcnt<A>();
-        else if (st == 1) wait_vmcnt<A + G::NST>();
-        else wait_vmcnt<A + G::NST + G::NST_POOL>();
-      };
-      if (inflight <= 1) wait_for(std::integral_constant<int, 0>{});
-      else if (inflight == 2 || PIPE == 3) wait_for(std::integral_constant<int, 1>{});
-      else wait_for(std::integral_constant<int, PIPE == 3 ? 1 : 2>{});
-      --inflight;
+      wait_vmcnt<0>();
     }
     mark(2);
     __builtin_amdgcn_s_barrier();
@@ -884,21 +838,10 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     if constexpr (EPI == EPI_DMASK) {
       if (ch == 0) fetch_masks(cur);
     }
-    if constexpr (PIPE == 2) {
-      if (!has_next) {
-        body(std::integral_constant<int, 0>{}, stage, 0, nullptr, nullptr);
-      } else {
-        body(std::integral_constant<int, 1>{}, stage, stage ^ 1, chunk_src(nxt, nchk), chunk_w(nxt, nchk));
-      }
+    if (!has_next) {
+      body(std::integral_constant<int, 0>{}, stage, nullptr, nullptr);
     } else {
-      // the stage read in the previous step (every wave has passed this step's barrier) takes the step PIPE - 1 ahead
-      if (!pvalid) {
-        body(std::integral_constant<int, 0>{}, stage, 0, nullptr, nullptr);
-      } else {
-        body(std::integral_constant<int, 1>{}, stage, stage == 0 ? PIPE - 1 : stage - 1, chunk_src(pT, pch), chunk_w(pT, pch));
-        ++inflight;
-        padvance();
-      }
+      body(std::integral_constant<int, 1>{}, stage, chunk_src(nxt, nchk), chunk_w(nxt, nchk));
     }
     mark(4);
     stores_behind = false;
@@ -924,7 +867,7 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64, (NW + HS_UPS_WAVES 
     tile = ntile;
     ch = nchk;
     cur = nxt;
-    stage = (PIPE == 2) ? (stage ^ 1) : (stage + 1 == PIPE ? 0 : stage + 1);
+    stage ^= 1;
   }
 #ifdef PNPX_TUNING
   if (a.wgt && tid == 0) {
@@ -955,12 +898,12 @@ inline int ensure_dyn_lds(const void* func, int bytes) {
   return PNPX_OK;
 }
 
-template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF, int PIPE = 2>
+template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF>
 static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
-  using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS, PIPE>;
+  using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS>;
   constexpr int LDS_REQ = G::LDS_BYTES + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES;
   static_assert(G::LDS_USED + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES <= 160 * 1024, "no LDS room for the low-resolution windows");
-  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS, PIPE>), LDS_REQ));
+  PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS>), LDS_REQ));
   ConvHsArgs a = a0;
   a.tilesX = (a.W + G::TW - 1) / G::TW;
   a.tilesY = (a.H + G::TH - 1) / G::TH;
@@ -1016,7 +959,7 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
     a.trace = tbuf;
   }
 #endif
-  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS, PIPE>), dim3((unsigned)grid),
+  hipLaunchKernelGGL((conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS>), dim3((unsigned)grid),
                      dim3((NW + HS_UPS_WAVES * UPS) * 64), lds_req, s, a);
   PNPX_LAUNCH_CHECK();
 #ifdef PNPX_TUNING
@@ -1062,31 +1005,10 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
 
 struct HsChoice {
   int nbw, nw;
-  bool deep = false;   // use the 3 / 4-stage instance of this shape if there is one
 };
-
-// deepest pipeline (stages) whose LDS fits, for the shapes that have deep instances: four waves, 16- / 32-pixel-wide blocks,
-// one or two block rows per wave, plain activation epilogue, all nine taps
-template <int MT, int NBW, int MBW>
-constexpr int hs_deep_stages() {
-  if (MBW != 16 && MBW != 32) return 2;
-  if (NBW > 2) return 2;
-  if (HsGeom<MT, NBW, MBW, 4, 0, 0x1FF, 4>::FITS) return 4;
-  if (HsGeom<MT, NBW, MBW, 4, 0, 0x1FF, 3>::FITS) return 3;
-  return 2;
-}
-template <int MT, int NBW, int MBW, int EPI, int TAPS>
-static int launch_hs_nw4(const ConvHsArgs& a, int B, bool deep, hipStream_t s) {
-  if constexpr (EPI == EPI_ACT && TAPS == 0x1FF && hs_deep_stages<MT, NBW, MBW>() > 2) {
-    if (deep) return launch_hs_cfg<MT, NBW, MBW, 4, EPI, 0, 0, TAPS, hs_deep_stages<MT, NBW, MBW>()>(a, B, s);
-  }
-  return launch_hs_cfg<MT, NBW, MBW, 4, EPI, 0, 0, TAPS>(a, B, s);
-}
 
 template <int MT, int MBW, int EPI, int TAPS = 0x1FF>
 static int launch_hs_mbw(const ConvHsArgs& a, int B, HsChoice c, hipStream_t s) {
-  if (c.nw == 4 && c.nbw == 2) return launch_hs_nw4<MT, 2, MBW, EPI, TAPS>(a, B, c.deep, s);
-  if (c.nw == 4 && c.nbw == 1) return launch_hs_nw4<MT, 1, MBW, EPI, TAPS>(a, B, c.deep, s);
   if (c.nw == 8) {
     if (c.nbw >= 2) return launch_hs_cfg<MT, 2, MBW, 8, EPI, 0, 0, TAPS>(a, B, s);
     return launch_hs_cfg<MT, 1, MBW, 8, EPI, 0, 0, TAPS>(a, B, s);

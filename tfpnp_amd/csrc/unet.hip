@@ -415,7 +415,6 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
     ConvHsFuse fz = fuse;
     fz.range_flag = range_flag;
     fz.wreg = ctx->opt_wreg;
-    fz.deep_pipe = ctx->opt_deep_pipe;
     PNPX_TRY(launch_conv_hs(Lh, at(i0, b0), i0.C / 8, i1 ? at(*i1, b0) : nullptr, i1 ? i1->C / 8 : 0, at(o, b0), nb, o.H,
                             o.W, fz, s));
     return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * nb);
