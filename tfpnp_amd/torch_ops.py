@@ -257,400 +257,15 @@ radon_backprojection.register_autograd(
 
 
 # ------------------------------------------------------------------------------------------------- solver loops
-def _same(variables, *a):
-    return torch.empty_like(variables, memory_format=torch.contiguous_format)
-
-
-@_lib_def("pnpx::csmri_admm", mutates_args=(), device_types="cuda")
-def csmri_admm(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int, ctx: int) -> Tensor:
-    """ADMMSolver_CSMRI.forward (tasks/csmri/solver.py:29-57), all inner iterations in one native call."""
-    return ops.csmri_admm(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, _it(iter_num))
-
-
-csmri_admm.register_fake(_same)
-
-
-@_lib_def("pnpx::csmri_admm_train", mutates_args=(), device_types="cuda")
-def csmri_admm_train(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int,
-                     ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """Differentiable ADMMSolver_CSMRI.forward: same result as csmri_admm plus what its native VJP replays: the
-    per-iteration denoiser inputs and k-space images (`saved`) and the ticket of the context's activation cache (a
-    one-element int64 CPU tensor; see pnpx_csmri_admm_train).  What PnPEnv.forward calls under autograd
-    (tfpnp/env/base.py:193-206)."""
-    out, saved, ticket = ops.csmri_admm_train(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, _it(iter_num))
-    return out, saved, torch.tensor([ticket], dtype=torch.int64)
-
-
-@csmri_admm_train.register_fake
-def _(variables, y0, mask, sigma_d, mu, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B, _, H, W, _ = variables.shape
-    return (torch.empty_like(variables, memory_format=torch.contiguous_format),
-            torch.empty((3 * T * B * H * W,), dtype=variables.dtype, device=variables.device),
-            torch.empty((1,), dtype=torch.int64))
-
-
-@_lib_def("pnpx::csmri_admm_backward", mutates_args=(), device_types="cuda")
-def csmri_admm_backward(y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, saved: Tensor, ticket: Tensor,
-                        grad_out: Tensor, iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """VJP of csmri_admm_train wrt (variables, sigma_d[:, :T], mu[:, :T]): reverse walk of the T iterations, natively."""
-    return ops.csmri_admm_backward(_ctx(ctx, grad_out), y0, mask, sigma_d, mu, saved, grad_out, _it(iter_num),
-                                   ticket=int(ticket[0]))
-
-
-@csmri_admm_backward.register_fake
-def _(y0, mask, sigma_d, mu, saved, ticket, grad_out, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B = grad_out.shape[0]
-    e = lambda: torch.empty((B, T), dtype=grad_out.dtype, device=grad_out.device)
-    return torch.empty_like(grad_out, memory_format=torch.contiguous_format), e(), e()
-
-
-def _admm_train_setup(ctx, inputs, output):
-    _, y0, mask, sigma_d, mu, ctx.iter_num, cid = inputs
-    _pin(ctx, cid, y0)
-    ctx.save_for_backward(y0, mask, sigma_d, mu, output[1], output[2])
-
-
-def _admm_train_bwd(ctx, g_out, _g_saved, _g_ticket):
-    y0, mask, sigma_d, mu, saved, ticket = ctx.saved_tensors
-    gv, gs, gm = torch.ops.pnpx.csmri_admm_backward(y0, mask, sigma_d, mu, saved, ticket, g_out.contiguous(),
-                                                    ctx.iter_num, ctx.cid)
-
-    def like(g, p):      # gradients of the columns that were iterated; the rest of [B, action_pack] did not take part
-        full = torch.zeros_like(p)
-        if p.numel():
-            full.view(p.shape[0], -1)[:, :g.shape[1]] = g
-        return full
-
-    return gv, None, None, like(gs, sigma_d), like(gm, mu), None, None
-
-
-csmri_admm_train.register_autograd(_admm_train_bwd, setup_context=_admm_train_setup)
-
-
-@_lib_def("pnpx::csmri_hqs_train", mutates_args=(), device_types="cuda")
-def csmri_hqs_train(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int,
-                    ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """Differentiable HQSSolver_CSMRI.forward (tasks/csmri/solver.py:64-89): like csmri_admm_train for the 2-variable
-    state; its registered autograd formula is the fused native VJP pnpx_csmri_hqs_backward."""
-    out, saved, ticket = ops.csmri_hqs_train(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, _it(iter_num))
-    return out, saved, torch.tensor([ticket], dtype=torch.int64)
-
-
-@csmri_hqs_train.register_fake
-def _(variables, y0, mask, sigma_d, mu, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B, _, H, W, _ = variables.shape
-    return (torch.empty_like(variables, memory_format=torch.contiguous_format),
-            torch.empty((3 * T * B * H * W,), dtype=variables.dtype, device=variables.device),
-            torch.empty((1,), dtype=torch.int64))
-
-
-@_lib_def("pnpx::csmri_hqs_backward", mutates_args=(), device_types="cuda")
-def csmri_hqs_backward(y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, saved: Tensor, ticket: Tensor,
-                       grad_out: Tensor, iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """VJP of csmri_hqs_train wrt (variables, sigma_d[:, :T], mu[:, :T])."""
-    return ops.csmri_hqs_backward(_ctx(ctx, grad_out), y0, mask, sigma_d, mu, saved, grad_out, _it(iter_num),
-                                  ticket=int(ticket[0]))
-
-
-@csmri_hqs_backward.register_fake
-def _(y0, mask, sigma_d, mu, saved, ticket, grad_out, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B = grad_out.shape[0]
-    e = lambda: torch.empty((B, T), dtype=grad_out.dtype, device=grad_out.device)
-    return torch.empty_like(grad_out, memory_format=torch.contiguous_format), e(), e()
-
-
-def _hqs_train_bwd(ctx, g_out, _g_saved, _g_ticket):
-    y0, mask, sigma_d, mu, saved, ticket = ctx.saved_tensors
-    gv, gs, gm = torch.ops.pnpx.csmri_hqs_backward(y0, mask, sigma_d, mu, saved, ticket, g_out.contiguous(),
-                                                   ctx.iter_num, ctx.cid)
-
-    def like(g, p):
-        full = torch.zeros_like(p)
-        if p.numel():
-            full.view(p.shape[0], -1)[:, :g.shape[1]] = g
-        return full
-
-    return gv, None, None, like(gs, sigma_d), like(gm, mu), None, None
-
-
-csmri_hqs_train.register_autograd(_hqs_train_bwd, setup_context=_admm_train_setup)
-
-
-@_lib_def("pnpx::csmri_pg_train", mutates_args=(), device_types="cuda")
-def csmri_pg_train(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, tau: Tensor, iter_num: int,
-                   ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """Differentiable PGSolver_CSMRI.forward (tasks/csmri/solver.py:96-120); autograd = the fused native VJP
-    pnpx_csmri_pg_backward."""
-    out, saved, ticket = ops.csmri_pg_train(_ctx(ctx, variables), variables, y0, mask, sigma_d, tau, _it(iter_num))
-    return out, saved, torch.tensor([ticket], dtype=torch.int64)
-
-
-@csmri_pg_train.register_fake
-def _(variables, y0, mask, sigma_d, tau, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B, _, H, W, _ = variables.shape
-    return (torch.empty_like(variables, memory_format=torch.contiguous_format),
-            torch.empty((2 * T * B * H * W,), dtype=variables.dtype, device=variables.device),
-            torch.empty((1,), dtype=torch.int64))
-
-
-@_lib_def("pnpx::csmri_pg_backward", mutates_args=(), device_types="cuda")
-def csmri_pg_backward(y0: Tensor, mask: Tensor, sigma_d: Tensor, tau: Tensor, saved: Tensor, ticket: Tensor,
-                      grad_out: Tensor, iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """VJP of csmri_pg_train wrt (x, sigma_d[:, :T], tau[:, :T])."""
-    return ops.csmri_pg_backward(_ctx(ctx, grad_out), y0, mask, sigma_d, tau, saved, grad_out, _it(iter_num),
-                                 ticket=int(ticket[0]))
-
-
-@csmri_pg_backward.register_fake
-def _(y0, mask, sigma_d, tau, saved, ticket, grad_out, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B = grad_out.shape[0]
-    e = lambda: torch.empty((B, T), dtype=grad_out.dtype, device=grad_out.device)
-    return torch.empty_like(grad_out, memory_format=torch.contiguous_format), e(), e()
-
-
-def _pg_train_bwd(ctx, g_out, _g_saved, _g_ticket):
-    y0, mask, sigma_d, tau, saved, ticket = ctx.saved_tensors
-    gv, gs, gt = torch.ops.pnpx.csmri_pg_backward(y0, mask, sigma_d, tau, saved, ticket, g_out.contiguous(),
-                                                  ctx.iter_num, ctx.cid)
-
-    def like(g, p):
-        full = torch.zeros_like(p)
-        if p.numel():
-            full.view(p.shape[0], -1)[:, :g.shape[1]] = g
-        return full
-
-    return gv, None, None, like(gs, sigma_d), like(gt, tau), None, None
-
-
-csmri_pg_train.register_autograd(_pg_train_bwd, setup_context=_admm_train_setup)
-
-
-@_lib_def("pnpx::csmri_apg_train", mutates_args=(), device_types="cuda")
-def csmri_apg_train(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, tau: Tensor, beta: Tensor,
-                    iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """Differentiable APGSolver_CSMRI.forward (tasks/csmri/solver.py:127-165); autograd = pnpx_csmri_apg_backward."""
-    out, saved, ticket = ops.csmri_apg_train(_ctx(ctx, variables), variables, y0, mask, sigma_d, tau, beta, _it(iter_num))
-    return out, saved, torch.tensor([ticket], dtype=torch.int64)
-
-
-@csmri_apg_train.register_fake
-def _(variables, y0, mask, sigma_d, tau, beta, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B, _, H, W, _ = variables.shape
-    return (torch.empty_like(variables, memory_format=torch.contiguous_format),
-            torch.empty((4 * T * B * H * W,), dtype=variables.dtype, device=variables.device),
-            torch.empty((1,), dtype=torch.int64))
-
-
-@_lib_def("pnpx::csmri_apg_backward", mutates_args=(), device_types="cuda")
-def csmri_apg_backward(y0: Tensor, mask: Tensor, sigma_d: Tensor, tau: Tensor, beta: Tensor, saved: Tensor, ticket: Tensor,
-                       grad_out: Tensor, iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-    """VJP of csmri_apg_train wrt (variables, sigma_d[:, :T], tau[:, :T], beta[:, :T])."""
-    return ops.csmri_apg_backward(_ctx(ctx, grad_out), y0, mask, sigma_d, tau, beta, saved, grad_out, _it(iter_num),
-                                  ticket=int(ticket[0]))
-
-
-@csmri_apg_backward.register_fake
-def _(y0, mask, sigma_d, tau, beta, saved, ticket, grad_out, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B = grad_out.shape[0]
-    e = lambda: torch.empty((B, T), dtype=grad_out.dtype, device=grad_out.device)
-    return torch.empty_like(grad_out, memory_format=torch.contiguous_format), e(), e(), e()
-
-
-def _apg_train_setup(ctx, inputs, output):
-    _, y0, mask, sigma_d, tau, beta, ctx.iter_num, cid = inputs
-    _pin(ctx, cid, y0)
-    ctx.save_for_backward(y0, mask, sigma_d, tau, beta, output[1], output[2])
-
-
-def _apg_train_bwd(ctx, g_out, _g_saved, _g_ticket):
-    y0, mask, sigma_d, tau, beta, saved, ticket = ctx.saved_tensors
-    gv, gs, gt, gb = torch.ops.pnpx.csmri_apg_backward(y0, mask, sigma_d, tau, beta, saved, ticket, g_out.contiguous(),
-                                                       ctx.iter_num, ctx.cid)
-
-    def like(g, p):
-        full = torch.zeros_like(p)
-        if p.numel():
-            full.view(p.shape[0], -1)[:, :g.shape[1]] = g
-        return full
-
-    return gv, None, None, like(gs, sigma_d), like(gt, tau), like(gb, beta), None, None
-
-
-csmri_apg_train.register_autograd(_apg_train_bwd, setup_context=_apg_train_setup)
-
-
-@_lib_def("pnpx::csmri_redadmm_train", mutates_args=(), device_types="cuda")
-def csmri_redadmm_train(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, lamda: Tensor,
-                    iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """Differentiable REDADMMSolver_CSMRI.forward (tasks/csmri/solver.py:172-204); autograd = pnpx_csmri_redadmm_backward."""
-    out, saved, ticket = ops.csmri_redadmm_train(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, lamda, _it(iter_num))
-    return out, saved, torch.tensor([ticket], dtype=torch.int64)
-
-
-@csmri_redadmm_train.register_fake
-def _(variables, y0, mask, sigma_d, mu, lamda, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B, _, H, W, _ = variables.shape
-    return (torch.empty_like(variables, memory_format=torch.contiguous_format),
-            torch.empty((7 * T * B * H * W,), dtype=variables.dtype, device=variables.device),
-            torch.empty((1,), dtype=torch.int64))
-
-
-@_lib_def("pnpx::csmri_redadmm_backward", mutates_args=(), device_types="cuda")
-def csmri_redadmm_backward(y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, lamda: Tensor, saved: Tensor, ticket: Tensor,
-                       grad_out: Tensor, iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-    """VJP of csmri_redadmm_train wrt (variables, sigma_d[:, :T], mu[:, :T], lamda[:, :T])."""
-    return ops.csmri_redadmm_backward(_ctx(ctx, grad_out), y0, mask, sigma_d, mu, lamda, saved, grad_out, _it(iter_num),
-                                  ticket=int(ticket[0]))
-
-
-@csmri_redadmm_backward.register_fake
-def _(y0, mask, sigma_d, mu, lamda, saved, ticket, grad_out, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B = grad_out.shape[0]
-    e = lambda: torch.empty((B, T), dtype=grad_out.dtype, device=grad_out.device)
-    return torch.empty_like(grad_out, memory_format=torch.contiguous_format), e(), e(), e()
-
-
-def _redadmm_train_setup(ctx, inputs, output):
-    _, y0, mask, sigma_d, mu, lamda, ctx.iter_num, cid = inputs
-    _pin(ctx, cid, y0)
-    ctx.save_for_backward(y0, mask, sigma_d, mu, lamda, output[1], output[2])
-
-
-def _redadmm_train_bwd(ctx, g_out, _g_saved, _g_ticket):
-    y0, mask, sigma_d, mu, lamda, saved, ticket = ctx.saved_tensors
-    gv, gs, gm, gl = torch.ops.pnpx.csmri_redadmm_backward(y0, mask, sigma_d, mu, lamda, saved, ticket, g_out.contiguous(),
-                                                       ctx.iter_num, ctx.cid)
-
-    def like(g, p):
-        full = torch.zeros_like(p)
-        if p.numel():
-            full.view(p.shape[0], -1)[:, :g.shape[1]] = g
-        return full
-
-    return gv, None, None, like(gs, sigma_d), like(gm, mu), like(gl, lamda), None, None
-
-
-csmri_redadmm_train.register_autograd(_redadmm_train_bwd, setup_context=_redadmm_train_setup)
-
-
-@_lib_def("pnpx::csmri_hqs", mutates_args=(), device_types="cuda")
-def csmri_hqs(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int, ctx: int) -> Tensor:
-    """HQSSolver_CSMRI.forward (tasks/csmri/solver.py:64-89)."""
-    return ops.csmri_hqs(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, _it(iter_num))
-
-
-csmri_hqs.register_fake(_same)
-
-
-@_lib_def("pnpx::csmri_pg", mutates_args=(), device_types="cuda")
-def csmri_pg(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, tau: Tensor, iter_num: int, ctx: int) -> Tensor:
-    """PGSolver_CSMRI.forward (tasks/csmri/solver.py:96-120)."""
-    return ops.csmri_pg(_ctx(ctx, variables), variables, y0, mask, sigma_d, tau, _it(iter_num))
-
-
-csmri_pg.register_fake(_same)
-
-
-@_lib_def("pnpx::csmri_apg", mutates_args=(), device_types="cuda")
-def csmri_apg(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, tau: Tensor, beta: Tensor, iter_num: int,
-              ctx: int) -> Tensor:
-    """APGSolver_CSMRI.forward (tasks/csmri/solver.py:127-165)."""
-    return ops.csmri_apg(_ctx(ctx, variables), variables, y0, mask, sigma_d, tau, beta, _it(iter_num))
-
-
-csmri_apg.register_fake(_same)
-
-
-@_lib_def("pnpx::csmri_redadmm", mutates_args=(), device_types="cuda")
-def csmri_redadmm(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, lamda: Tensor, iter_num: int,
-                  ctx: int) -> Tensor:
-    """REDADMMSolver_CSMRI.forward (tasks/csmri/solver.py:172-204)."""
-    return ops.csmri_redadmm(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, lamda, _it(iter_num))
-
-
-csmri_redadmm.register_fake(_same)
-
-
-@_lib_def("pnpx::pr_iadmm_train", mutates_args=(), device_types="cuda")
-def pr_iadmm_train(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, tau: Tensor,
-                    iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """Differentiable IADMMSolver_PR.forward (tasks/pr/solver.py:37-76); autograd = pnpx_pr_iadmm_backward."""
-    out, saved, ticket = ops.pr_iadmm_train(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, tau, _it(iter_num))
-    return out, saved, torch.tensor([ticket], dtype=torch.int64)
-
-
-@pr_iadmm_train.register_fake
-def _(variables, y0, mask, sigma_d, mu, tau, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B, _, H, W, _ = variables.shape
-    return (torch.empty_like(variables, memory_format=torch.contiguous_format),
-            torch.empty(((2 * mask.shape[1] + 5) * T * B * H * W,), dtype=variables.dtype, device=variables.device),
-            torch.empty((1,), dtype=torch.int64))
-
-
-@_lib_def("pnpx::pr_iadmm_backward", mutates_args=(), device_types="cuda")
-def pr_iadmm_backward(y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, tau: Tensor, saved: Tensor, ticket: Tensor,
-                       grad_out: Tensor, iter_num: int, ctx: int) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-    """VJP of pr_iadmm_train wrt (variables, sigma_d[:, :T], mu[:, :T], tau[:, :T])."""
-    return ops.pr_iadmm_backward(_ctx(ctx, grad_out), y0, mask, sigma_d, mu, tau, saved, grad_out, _it(iter_num),
-                                  ticket=int(ticket[0]))
-
-
-@pr_iadmm_backward.register_fake
-def _(y0, mask, sigma_d, mu, tau, saved, ticket, grad_out, iter_num, ctx):
-    T = (sigma_d.shape[1] if sigma_d.dim() == 2 else 1) if iter_num < 0 else iter_num
-    B = grad_out.shape[0]
-    e = lambda: torch.empty((B, T), dtype=grad_out.dtype, device=grad_out.device)
-    return torch.empty_like(grad_out, memory_format=torch.contiguous_format), e(), e(), e()
-
-
-def _pr_train_setup(ctx, inputs, output):
-    _, y0, mask, sigma_d, mu, tau, ctx.iter_num, cid = inputs
-    _pin(ctx, cid, y0)
-    ctx.save_for_backward(y0, mask, sigma_d, mu, tau, output[1], output[2])
-
-
-def _pr_train_bwd(ctx, g_out, _g_saved, _g_ticket):
-    y0, mask, sigma_d, mu, tau, saved, ticket = ctx.saved_tensors
-    gv, gs, gm, gt = torch.ops.pnpx.pr_iadmm_backward(y0, mask, sigma_d, mu, tau, saved, ticket, g_out.contiguous(),
-                                                       ctx.iter_num, ctx.cid)
-
-    def like(g, p):
-        full = torch.zeros_like(p)
-        if p.numel():
-            full.view(p.shape[0], -1)[:, :g.shape[1]] = g
-        return full
-
-    return gv, None, None, like(gs, sigma_d), like(gm, mu), like(gt, tau), None, None
-
-
-pr_iadmm_train.register_autograd(_pr_train_bwd, setup_context=_pr_train_setup)
-
-
-@_lib_def("pnpx::pr_iadmm", mutates_args=(), device_types="cuda")
-def pr_iadmm(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, tau: Tensor, iter_num: int,
-             ctx: int) -> Tensor:
-    """IADMMSolver_PR.forward (tasks/pr/solver.py:37-76)."""
-    return ops.pr_iadmm(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, tau, _it(iter_num))
-
-
-pr_iadmm.register_fake(_same)
-
-
+# ------------------------------------------------------------------------------------------------- solver training ops
 def _solver_train_ops(name, aux, hypers, train_fn, backward_fn, saved_per_pixel, bwd_takes_aux=True):
     """Register `pnpx::<name>_train` (+ `_backward` and the autograd formula) for a solver whose native training entry follows the
-    common contract: (variables, *aux, *hyper-parameters, iter_num, ctx) -> (next state, saved, ticket).  `aux` = [(name, schema
-    type)]; non-tensor aux entries (view count, operator norm) travel on the autograd node."""
+    common contract: (variables, *aux, *hyper-parameters, iter_num, ctx) -> (next state, saved, ticket) -- the same result as the
+    inference op plus what the native VJP replays (`saved`: per-iteration denoiser inputs and data-step intermediates, include/pnpx.h)
+    and the ticket of the context's activation cache (a one-element int64 CPU tensor).  This is what PnPEnv.forward reaches under
+    autograd (tfpnp/env/base.py:193-206).  `aux` = [(name, schema type)]; non-tensor aux entries (view count, operator norm)
+    travel on the autograd node; `saved_per_pixel` = floats per pixel and iteration (a number, or a function of the aux tuple).
+    The backward op returns gradients for the hyper-parameter columns that were iterated; the rest of [B, action_pack] gets zeros."""
     n_aux, n_h = len(aux), len(hypers)
     aux_sig = [f"{t} {n}" for n, t in aux]
     hyp_sig = [f"Tensor {h}" for h in hypers]
@@ -669,8 +284,9 @@ def _solver_train_ops(name, aux, hypers, train_fn, backward_fn, saved_per_pixel,
     def fwd_fake(*a):
         variables, hv, iter_num = a[0], a[1 + n_aux:1 + n_aux + n_h], a[-2]
         n_px = variables.numel() // variables.shape[1] // (2 if variables.dim() == 5 else 1)
+        per = saved_per_pixel(a[1:1 + n_aux]) if callable(saved_per_pixel) else saved_per_pixel
         return (torch.empty_like(variables, memory_format=torch.contiguous_format),
-                torch.empty((saved_per_pixel * n_iter(hv[0], iter_num) * n_px,), dtype=variables.dtype, device=variables.device),
+                torch.empty((per * n_iter(hv[0], iter_num) * n_px,), dtype=variables.dtype, device=variables.device),
                 torch.empty((1,), dtype=torch.int64))
 
     def bwd(*a):
@@ -719,6 +335,20 @@ def _solver_train_ops(name, aux, hypers, train_fn, backward_fn, saved_per_pixel,
     return op_f, op_b
 
 
+_MRI_AUX = [("y0", "Tensor"), ("mask", "Tensor")]
+csmri_admm_train, csmri_admm_backward = _solver_train_ops(
+    "csmri_admm", _MRI_AUX, ("sigma_d", "mu"), ops.csmri_admm_train, ops.csmri_admm_backward, 3)
+csmri_hqs_train, csmri_hqs_backward = _solver_train_ops(
+    "csmri_hqs", _MRI_AUX, ("sigma_d", "mu"), ops.csmri_hqs_train, ops.csmri_hqs_backward, 3)
+csmri_pg_train, csmri_pg_backward = _solver_train_ops(
+    "csmri_pg", _MRI_AUX, ("sigma_d", "tau"), ops.csmri_pg_train, ops.csmri_pg_backward, 2)
+csmri_apg_train, csmri_apg_backward = _solver_train_ops(
+    "csmri_apg", _MRI_AUX, ("sigma_d", "tau", "beta"), ops.csmri_apg_train, ops.csmri_apg_backward, 4)
+csmri_redadmm_train, csmri_redadmm_backward = _solver_train_ops(
+    "csmri_redadmm", _MRI_AUX, ("sigma_d", "mu", "lamda"), ops.csmri_redadmm_train, ops.csmri_redadmm_backward, 7)
+pr_iadmm_train, pr_iadmm_backward = _solver_train_ops(
+    "pr_iadmm", _MRI_AUX, ("sigma_d", "mu", "tau"), ops.pr_iadmm_train, ops.pr_iadmm_backward,
+    lambda aux: 2 * aux[1].shape[1] + 5)        # mask [B,S,H,W,2]: S k-space images per iteration
 spi_admm_train, spi_admm_backward = _solver_train_ops(
     "spi_admm", [("x0", "Tensor"), ("Kmap", "Tensor")], ("sigma_d", "mu"), ops.spi_admm_train, ops.spi_admm_backward, 2)
 ct_iadmm_train, ct_iadmm_backward = _solver_train_ops(
@@ -727,6 +357,68 @@ ct_iadmm_train, ct_iadmm_backward = _solver_train_ops(
 ct_pg_train, ct_pg_backward = _solver_train_ops(
     "ct_pg", [("y0", "Tensor"), ("n_view", "int"), ("opnorm", "float")], ("sigma_d", "tau"), ops.ct_pg_train, ops.ct_pg_backward, 2,
     bwd_takes_aux=False)
+
+
+
+def _same(variables, *a):
+    return torch.empty_like(variables, memory_format=torch.contiguous_format)
+
+
+@_lib_def("pnpx::csmri_admm", mutates_args=(), device_types="cuda")
+def csmri_admm(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int, ctx: int) -> Tensor:
+    """ADMMSolver_CSMRI.forward (tasks/csmri/solver.py:29-57), all inner iterations in one native call."""
+    return ops.csmri_admm(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, _it(iter_num))
+
+
+csmri_admm.register_fake(_same)
+
+
+@_lib_def("pnpx::csmri_hqs", mutates_args=(), device_types="cuda")
+def csmri_hqs(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, iter_num: int, ctx: int) -> Tensor:
+    """HQSSolver_CSMRI.forward (tasks/csmri/solver.py:64-89)."""
+    return ops.csmri_hqs(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, _it(iter_num))
+
+
+csmri_hqs.register_fake(_same)
+
+
+@_lib_def("pnpx::csmri_pg", mutates_args=(), device_types="cuda")
+def csmri_pg(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, tau: Tensor, iter_num: int, ctx: int) -> Tensor:
+    """PGSolver_CSMRI.forward (tasks/csmri/solver.py:96-120)."""
+    return ops.csmri_pg(_ctx(ctx, variables), variables, y0, mask, sigma_d, tau, _it(iter_num))
+
+
+csmri_pg.register_fake(_same)
+
+
+@_lib_def("pnpx::csmri_apg", mutates_args=(), device_types="cuda")
+def csmri_apg(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, tau: Tensor, beta: Tensor, iter_num: int,
+              ctx: int) -> Tensor:
+    """APGSolver_CSMRI.forward (tasks/csmri/solver.py:127-165)."""
+    return ops.csmri_apg(_ctx(ctx, variables), variables, y0, mask, sigma_d, tau, beta, _it(iter_num))
+
+
+csmri_apg.register_fake(_same)
+
+
+@_lib_def("pnpx::csmri_redadmm", mutates_args=(), device_types="cuda")
+def csmri_redadmm(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, lamda: Tensor, iter_num: int,
+                  ctx: int) -> Tensor:
+    """REDADMMSolver_CSMRI.forward (tasks/csmri/solver.py:172-204)."""
+    return ops.csmri_redadmm(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, lamda, _it(iter_num))
+
+
+csmri_redadmm.register_fake(_same)
+
+
+@_lib_def("pnpx::pr_iadmm", mutates_args=(), device_types="cuda")
+def pr_iadmm(variables: Tensor, y0: Tensor, mask: Tensor, sigma_d: Tensor, mu: Tensor, tau: Tensor, iter_num: int,
+             ctx: int) -> Tensor:
+    """IADMMSolver_PR.forward (tasks/pr/solver.py:37-76)."""
+    return ops.pr_iadmm(_ctx(ctx, variables), variables, y0, mask, sigma_d, mu, tau, _it(iter_num))
+
+
+pr_iadmm.register_fake(_same)
 
 
 @_lib_def("pnpx::spi_admm", mutates_args=(), device_types="cuda")
