@@ -930,8 +930,8 @@ int pnpx_radon_forward(pnpx_ctx* ctx, const float* img, float* sino, int B, int 
   const float2* cs;
   int det;
   PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &cs, &det));
-  float* imgT = cv.take<float>(radon_pad_floats(B, R));
-  launch_radon_forward(img, (size_t)R * R, nullptr, sino, cs, imgT, R, n_view, det, B, s);
+  float* pad = cv.take<float>(radon_pad_floats(B, R));
+  launch_radon_forward(img, (size_t)R * R, nullptr, sino, cs, pad, R, n_view, det, B, s);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
