@@ -44,3 +44,25 @@ def test_step_exchange_rccl_side_stream_single_rank():
         assert D.max_over_ranks(1.25, dev) == 1.25 and D.all_true(True, dev)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_share_the_gpu(scaling):
+    """`python bench.py --gpus 2` end to end with the REAL native solver on a one-GPU box: bench.py starts its two ranks itself,
+    both use device 0 over gloo (PNPX_BENCH_SHARE_GPU; RCCL refuses two ranks on one device), shard the batch, run the episode
+    with one exchange per env step and rank 0 prints the one JSON line.  Everything but the RCCL transport of the N > 1 path."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PNPX_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "6",
+           "--size", "64", "--scaling", scaling, "--no-cpu-baseline", "--no-batch-table", "--no-fp32-mode", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    assert d["collectives_per_env_step"] == 1.0
+    assert d["config"]["global_batch"] == (6 if scaling == "strong" else 12)
+    assert "NOT_A_MEASUREMENT" in d
