@@ -367,9 +367,10 @@ inline dim3 g1d(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 // Half-split forward pass.  Levels 0 and 1 (the memory-bound, shallow-K layers) can be processed in sub-batches so
 // that a ConvBlock's temporaries are re-read soon after they were written (PNPX_SUBBATCH images at level 0, twice
-// that at level 1; 0 = whole batch).  Measured (tools/time_denoiser.py, B=48, 256^2): 6.58 ms whole batch, 6.38 ms
-// at 24, worse below 12 (launch count, thinner grids) -- the Infinity Cache does not turn these layers around, the
-// gain is small; 24 is the default.  Deeper levels always run the whole batch.
+// that at level 1; 0 = whole batch).  Measured (B=48, 256^2): r1 6.58 ms whole batch, 6.38 ms at 24; with the r3 kernels
+// (tools/ab_wall.py "subbatch=..."): 5.72 ms at 24, 5.68 whole batch, 5.83 / 5.86 / 6.05 at 16 / 12 / 8 (launch count, thinner
+// grids), and no difference beyond the run-to-run spread in the hot bench -- the Infinity Cache does not turn these layers
+// around.  24 stays the default.  Deeper levels always run the whole batch.
 static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, const float* x, const float* sigma,
                            int sigma_stride, float* out, float* out_pre, int B, int H, int W, hipStream_t s,
                            Recorder& rec, bool keep_all, int b_base = 0) {
