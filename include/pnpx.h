@@ -330,7 +330,7 @@ int pnpx_ct_iadmm(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const fl
                   float opnorm, const float* sigma_d, const float* mu, const float* tau, int param_stride,
                   int B, int R, int T, void* stream);
 /* Training path of IADMMSolver_CT.forward: `saved` = 3*T*B*R*R floats; grads wrt (cat(x, z, u), sigma_d, mu, tau);
- * work = 6*B*R*R floats. */
+ * work = 6*B*R*R + 2*n_view floats. */
 int pnpx_ct_iadmm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view,
                         float opnorm, const float* sigma_d, const float* mu, const float* tau, int param_stride, int B,
                         int R, int T, float* saved, unsigned long long* ticket, void* stream);
@@ -342,7 +342,8 @@ int pnpx_ct_iadmm_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float*
 int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view,
                float opnorm, const float* sigma_d, const float* tau, int param_stride, int B, int R, int T,
                void* stream);
-/* Training path of PGSolver_CT.forward: `saved` = 2*T*B*R*R floats; grads wrt (x, sigma_d, tau); work = 3*B*R*R floats. */
+/* Training path of PGSolver_CT.forward: `saved` = 2*T*B*R*R floats; grads wrt (x, sigma_d, tau); work = 3*B*R*R + 2*n_view
+ * floats. */
 int pnpx_ct_pg_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
                      const float* sigma_d, const float* tau, int param_stride, int B, int R, int T, float* saved,
                      unsigned long long* ticket, void* stream);

@@ -663,6 +663,57 @@ def test_ct_fused_vjp_vs_composed_autograd(den):
                        lambda v, s_, t_: pg._forward_autograd(v, y0, s_, t_, T), T, ("variables", "sigma_d", "tau"))
 
 
+def test_fused_vjps_with_and_without_the_activation_ring(unet_params):
+    """Every fused training path gives the same gradients whether the denoiser VJPs find their activations in the training ring
+    or re-compute them (to the level at which the two forward variants differ: the ring-less forward fuses the out-conv) -- the
+    re-computing VJP uses (and may re-allocate) the context's scratch buffer, which the solver loops share with it: a FRESH
+    context per solver and small shapes, so that the scratch has to grow inside the backward."""
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.tasks import csmri, pr, spi, ct
+
+    def grads(sol, v0, aux, acts, T):
+        leaves = [v0.clone().requires_grad_(True)] + [g(p, True) for p in acts]
+        out = sol((leaves[0], aux), tuple(leaves[1:]), iter_num=T)
+        wts = torch.randn(out.shape, device=out.device, generator=torch.Generator(out.device).manual_seed(21))
+        (out * wts).sum().backward()
+        return [out.detach()] + [l.grad for l in leaves]
+
+    def check(make_sol, make_case, T=2):
+        res = []
+        for cache_gb in (-1, 0):
+            d_ = UNetDenoiser2D(state_dict=unet_params)           # fresh context: its scratch starts empty
+            d_.context(dev()).set_option("train_cache_gb", cache_gb)
+            sol = make_sol(d_)
+            v0, aux, acts = make_case(sol)
+            res.append(grads(sol, v0, aux, acts, T))
+        for k, (a_, b_) in enumerate(zip(*res)):
+            e = rel(a_, b_) if float(b_.abs().max()) > 0 else float(a_.abs().max())
+            assert e < (1e-5 if k == 0 else 2e-2), (type(sol).__name__, k, e)
+
+    B, H = 1, 16
+    dm = synth.make_csmri_batch(B, H, H, seed=31)
+    am = csmri_actions(B, 3, 32, ("sigma_d", "mu", "tau", "beta", "lamda"))
+    mri_aux = (g(dm["y0"]), g(dm["mask"]))
+    for cls, keys in ((csmri.ADMMSolver_CSMRI, ("sigma_d", "mu")), (csmri.HQSSolver_CSMRI, ("sigma_d", "mu")),
+                      (csmri.PGSolver_CSMRI, ("sigma_d", "tau")), (csmri.APGSolver_CSMRI, ("sigma_d", "tau", "beta")),
+                      (csmri.REDADMMSolver_CSMRI, ("sigma_d", "mu", "lamda"))):
+        check(cls, lambda sol: (sol.reset({"x0": g(dm["x0"])}), mri_aux, [am[k] for k in keys]))
+    dp = synth.make_pr_batch(B, H, H, S=1, alpha=9.0, seed=33)     # S = 1: the k-space scratch is SMALLER than the VJP's
+    ap = csmri_actions(B, 3, 34, ("sigma_d", "mu", "tau"))
+    ap["tau"] = (ap["tau"] * 0.5).astype(np.float32)
+    check(pr.IADMMSolver_PR, lambda sol: (sol.reset({"x0": g(dp["x0"])}), (g(dp["y0"]), g(dp["mask"])),
+                                          [ap["sigma_d"], ap["mu"], ap["tau"]]))
+    ds = synth.make_spi_batch(B, H, H, K=6, seed=35)
+    rs = np.random.RandomState(36)
+    spi_acts = [rs.uniform(15 / 255.0, 70 / 255.0, (B, 3)).astype(np.float32), rs.uniform(50, 120, (B, 3)).astype(np.float32)]
+    check(spi.ADMMSolver_SPI, lambda sol: (sol.reset({"x0": g(ds["x0"])}), (g(ds["x0"]), g(ds["K"])), spi_acts),
+          T=1)                                                          # (later iterations: bisection flips on 1e-7 differences)
+    y0, x0, view = _ct_case(B, 16, 12, 37)
+    ac = csmri_actions(B, 3, 38, ("sigma_d", "mu", "tau"))
+    check(ct.IADMMSolver_CT, lambda sol: (sol.reset({"x0": x0}), (y0, view), [ac["sigma_d"], ac["mu"], ac["tau"]]), T=3)
+    check(ct.PGSolver_CT, lambda sol: (sol.reset({"x0": x0}), (y0, view), [ac["sigma_d"], ac["tau"]]), T=3)
+
+
 def test_ct_solver_gradients(den, oden32, oden64, monkeypatch):
     """The Radon pair is unmatched and each operator is used as the other's VJP (torch_radon's convention); the
     oracle is given the same convention through autograd.Function wrappers for this test."""

@@ -750,14 +750,8 @@ int pnpx_pr_iadmm_backward(pnpx_ctx* ctx, const float* y0, const float* mask, co
     const size_t is = 3 * (size_t)HW, n = (size_t)HW * B;
     PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float2) * is * B, hipMemcpyDeviceToDevice, s));
     if (T == 0) return PNPX_OK;
-    void* p;
-    PNPX_TRY(ctx_scratch(ctx, n * S * sizeof(float2) + 4096, &p));
-    Carver cv{static_cast<char*>(p)};
-    float2* k = cv.take<float2>(n * S);
     FftPlan2D P;
     PNPX_TRY(make_fft_plan(ctx, B * S, H, W, false, &P));
-    StoreC kst{k, H, W};
-    LoadC kld{k, H, W};
     float2* g = reinterpret_cast<float2*>(grad_vars_in);
     const float2* mk = reinterpret_cast<const float2*>(mask);
     float *gxr = work, *gd = work + n, *c_tau = work + 2 * n, *c_mu = work + 3 * n;
@@ -766,6 +760,13 @@ int pnpx_pr_iadmm_backward(pnpx_ctx* ctx, const float* y0, const float* mask, co
     const float2* sv_G = reinterpret_cast<const float2*>(saved + (size_t)T * n * (1 + 2 * S));
     const float2* sv_q = reinterpret_cast<const float2*>(saved + (size_t)T * n * (3 + 2 * S));
     for (int i = T - 1; i >= 0; --i) {
+      // the context's scratch is shared with the denoiser's VJP below, which may also GROW (= re-allocate) it: the k-space
+      // buffer is carved anew every iteration and nothing in it has to survive that call
+      void* p;
+      PNPX_TRY(ctx_scratch(ctx, n * S * sizeof(float2) + 4096, &p));
+      float2* k = static_cast<float2*>(p);
+      StoreC kst{k, H, W};
+      LoadC kld{k, H, W};
       PNPX_TRY((launch_rows<false>(P, LoadCdpDiff{g + HW, g + 2 * HW, is, mk, S, W, HW}, kst, s)));
       PNPX_TRY((launch_cols<false, true>(P, kld, MidPrResidualAdjoint{y0, sv_w + (size_t)i * n * S, W, HW}, kst, s)));
       PNPX_TRY((launch_rows<true>(P, kld, kst, s)));
@@ -958,15 +959,28 @@ struct CtScratch {
   float *sino, *pad, *img[4];
   int det;
 };
-static int ct_scratch(pnpx_ctx* ctx, int B, int R, int n_view, int extra, hipStream_t s, CtScratch* C) {
+// `cs_home`: where the (cos, sin) table lives.  NULL = in the scratch itself (forward loops: nothing else touches the scratch
+// while they run); the backward loops pass a place in their caller-provided work buffer, because the denoiser's VJP uses --
+// and may re-allocate -- the same scratch between two uses of the table, and re-carve the rest every iteration (upload = false).
+static int ct_scratch(pnpx_ctx* ctx, int B, int R, int n_view, int extra, hipStream_t s, CtScratch* C,
+                      float2* cs_home = nullptr, bool upload = true) {
   const size_t n = (size_t)R * R * B;
   const int det = pnpx_radon_det_count(R);
   void* p;
   PNPX_TRY(ctx_scratch(ctx, (extra * n + radon_pad_floats(B, R) + (size_t)B * n_view * det) * sizeof(float) +
                                 sizeof(float2) * n_view + 16384, &p));
   Carver cv{static_cast<char*>(p)};
-  int det2;
-  PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &C->cs, &det2));
+  float2* table = cv.take<float2>(n_view);
+  if (cs_home) table = cs_home;
+  if (upload) {
+    std::vector<float2> cs;
+    int det2;
+    PNPX_TRY(radon_table(R, n_view, &cs, &det2));
+    // small synchronous upload (host table is a local): the vector may die after the synchronisation
+    PNPX_HIP(hipMemcpyAsync(table, cs.data(), sizeof(float2) * n_view, hipMemcpyHostToDevice, s));
+    PNPX_HIP(hipStreamSynchronize(s));
+  }
+  C->cs = table;
   for (int k = 0; k < extra; ++k) C->img[k] = cv.take<float>(n);
   C->sino = cv.take<float>((size_t)B * n_view * det);
   C->pad = cv.take<float>(radon_pad_floats(B, R));
@@ -1054,7 +1068,7 @@ int pnpx_ct_iadmm_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, co
 }
 
 // VJP of the T-iteration CT iADMM map wrt (cat(x, z, u), sigma_d, mu, tau); the data step's adjoint is A^T A / opnorm^2 with the
-// projector pair standing in for each other's transpose (as in the composed path and in torch_radon).  work = 6*B*R*R floats.
+// projector pair standing in for each other's transpose (as in the composed path and in torch_radon).  work = 6*B*R*R + 2*n_view floats.
 int pnpx_ct_iadmm_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float* sigma_d, const float* mu, const float* tau,
                            int param_stride, const float* saved, const float* grad_vars_out, float* grad_vars_in,
                            float* grad_sigma_d, float* grad_mu, float* grad_tau, float* work, int B, int R, int T,
@@ -1070,10 +1084,12 @@ int pnpx_ct_iadmm_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float*
     PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float) * is * B, hipMemcpyDeviceToDevice, s));
     if (T == 0) return PNPX_OK;
     CtScratch C;
-    PNPX_TRY(ct_scratch(ctx, B, R, n_view, 0, s, &C));
+    float2* cs_home = reinterpret_cast<float2*>(work + 6 * n);       // the table outlives the VJP calls in the work buffer
+    PNPX_TRY(ct_scratch(ctx, B, R, n_view, 0, s, &C, cs_home, true));
     const float op2 = (float)((double)opnorm * (double)opnorm);
     float *e = work, *J = work + n, *gxr = work + 2 * n, *gd = work + 3 * n, *c_tau = work + 4 * n, *c_mu = work + 5 * n;
     for (int i = T - 1; i >= 0; --i) {
+      PNPX_TRY(ct_scratch(ctx, B, R, n_view, 0, s, &C, cs_home, false));   // re-carve: the VJP below shares (and may grow) the scratch
       hipLaunchKernelGGL(ct_cotangent_kernel, g1(n), dim3(256), 0, s, grad_vars_in, is, e, HW, B);
       PNPX_LAUNCH_CHECK();
       PNPX_TRY(ct_normal_op(C, e, (size_t)HW, nullptr, J, op2, R, n_view, B, s));
@@ -1148,7 +1164,7 @@ int pnpx_ct_pg_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const
 }
 
 // VJP of the T-iteration CT PG map x' = D(x - tau g(x)) wrt (x, sigma_d, tau): gd = D^T gx';  d/d tau = -<gd, g_i>;
-// gx = gd - tau A^T A gd / opnorm^2.  work = 3*B*R*R floats.
+// gx = gd - tau A^T A gd / opnorm^2.  work = 3*B*R*R + 2*n_view floats.
 int pnpx_ct_pg_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float* sigma_d, const float* tau, int param_stride,
                         const float* saved, const float* grad_vars_out, float* grad_vars_in, float* grad_sigma_d,
                         float* grad_tau, float* work, int B, int R, int T, unsigned long long ticket, void* stream) {
@@ -1163,12 +1179,14 @@ int pnpx_ct_pg_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float* si
     PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
     if (T == 0) return PNPX_OK;
     CtScratch C;
-    PNPX_TRY(ct_scratch(ctx, B, R, n_view, 0, s, &C));
+    float2* cs_home = reinterpret_cast<float2*>(work + 3 * n);
+    PNPX_TRY(ct_scratch(ctx, B, R, n_view, 0, s, &C, cs_home, true));
     const float op2 = (float)((double)opnorm * (double)opnorm);
     float *gd = work, *J = work + n, *c_tau = work + 2 * n;
     for (int i = T - 1; i >= 0; --i) {
       PNPX_TRY(unet_denoise_backward_ticket(ctx, saved + (size_t)i * n, sigma_d + i, param_stride, grad_vars_in, gd,
                                             grad_sigma_d + (size_t)i * B, B, R, R, s, ticket ? ticket + i : 0));
+      PNPX_TRY(ct_scratch(ctx, B, R, n_view, 0, s, &C, cs_home, false));   // re-carve after the VJP (shared, growable scratch)
       PNPX_TRY(ct_normal_op(C, gd, (size_t)HW, nullptr, J, op2, R, n_view, B, s));
       hipLaunchKernelGGL(ct_pg_adjoint_kernel, g1(n), dim3(256), 0, s, gd, J, saved + ((size_t)T + i) * n, tau + i,
                          param_stride, HW, B, grad_vars_in, c_tau);

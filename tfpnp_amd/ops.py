@@ -786,7 +786,7 @@ def ct_iadmm_backward(ctx, n_view, opnorm, sigma_d, mu, tau, saved, grad_out, it
     gin = torch.empty_like(g)
     gs = _hyper_grads(T, B, 3, g.device)
     if B and T:
-        work = torch.empty(6 * B * R * R, dtype=torch.float32, device=g.device)
+        work = torch.empty(6 * B * R * R + 2 * int(n_view), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             check(_lib.lib().pnpx_ct_iadmm_backward(ctx.handle, int(n_view), float(opnorm), *[_p(p) for p in ps],
                                                     ps[0].shape[1], _p(saved), _p(g), _p(gin), *[_p(x) for x in gs], _p(work),
@@ -825,7 +825,7 @@ def ct_pg_backward(ctx, n_view, opnorm, sigma_d, tau, saved, grad_out, iter_num=
     gin = torch.empty_like(g)
     gs = _hyper_grads(T, B, 2, g.device)
     if B and T:
-        work = torch.empty(3 * B * R * R, dtype=torch.float32, device=g.device)
+        work = torch.empty(3 * B * R * R + 2 * int(n_view), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             check(_lib.lib().pnpx_ct_pg_backward(ctx.handle, int(n_view), float(opnorm), *[_p(p) for p in ps], ps[0].shape[1],
                                                  _p(saved), _p(g), _p(gin), *[_p(x) for x in gs], _p(work), B, R, T,
