@@ -436,6 +436,42 @@ def test_csmri_admm_train_degenerate_calls(den):
     assert ve.grad.shape == ve.shape
 
 
+def test_every_fused_solver_degenerate_calls(den):
+    """iter_num = 0 and an empty batch through every fused training path (CS-MRI family, PR, SPI, CT): identity forward, the
+    gradient passes straight through, hyper-parameter gradients are zeros of the right shape."""
+    from tfpnp_amd.tasks import csmri, pr, spi, ct
+    B, H = 2, 32
+    dm = synth.make_csmri_batch(B, H, H, seed=201)
+    a = csmri_actions(B, 3, 202, ("sigma_d", "mu", "tau", "beta", "lamda"))
+    dp = synth.make_pr_batch(B, H, H, S=2, alpha=9.0, seed=203)
+    ds = synth.make_spi_batch(B, H, H, K=6, seed=204)
+    y0c, x0c, view = _ct_case(B, H, 12, 205)
+    cases = [(cls(den), lambda sol: sol.reset({"x0": g(dm["x0"])}), (g(dm["y0"]), g(dm["mask"])), keys)
+             for cls, keys in ((csmri.ADMMSolver_CSMRI, ("sigma_d", "mu")), (csmri.HQSSolver_CSMRI, ("sigma_d", "mu")),
+                               (csmri.PGSolver_CSMRI, ("sigma_d", "tau")), (csmri.APGSolver_CSMRI, ("sigma_d", "tau", "beta")),
+                               (csmri.REDADMMSolver_CSMRI, ("sigma_d", "mu", "lamda")))]
+    cases += [(pr.IADMMSolver_PR(den), lambda sol: sol.reset({"x0": g(dp["x0"])}), (g(dp["y0"]), g(dp["mask"])),
+               ("sigma_d", "mu", "tau")),
+              (spi.ADMMSolver_SPI(den), lambda sol: sol.reset({"x0": g(ds["x0"])}), (g(ds["x0"]), g(ds["K"])), ("sigma_d", "mu")),
+              (ct.IADMMSolver_CT(den), lambda sol: sol.reset({"x0": x0c}), (y0c, view), ("sigma_d", "mu", "tau")),
+              (ct.PGSolver_CT(den), lambda sol: sol.reset({"x0": x0c}), (y0c, view), ("sigma_d", "tau"))]
+    for sol, reset, aux, keys in cases:
+        name = type(sol).__name__
+        v = reset(sol).requires_grad_(True)
+        hp = [g(a[k], True) for k in keys]
+        out = sol((v, aux), tuple(hp), iter_num=0)
+        assert torch.equal(out, v), name
+        wts = torch.randn_like(out)
+        (out * wts).sum().backward()
+        assert torch.equal(v.grad, wts), name
+        assert all(h.grad is not None and h.grad.shape == h.shape and float(h.grad.abs().max()) == 0.0 for h in hp), name
+        ve = v.detach()[:0].requires_grad_(True)
+        oe = sol((ve, tuple(t_[:0] for t_ in aux)), tuple(h.detach()[:0].requires_grad_(True) for h in hp))
+        assert oe.shape == ve.shape, name
+        oe.sum().backward()
+        assert ve.grad.shape == ve.shape, name
+
+
 def test_csmri_admm_activation_cache(den):
     """The training path parks the denoiser activations of training forwards in a ring (tickets):
     (a) gradients with the cache == gradients by re-computation (bit for bit for the same forward: same kernels);
