@@ -142,3 +142,54 @@ def test_other_task_envs_vs_reference_golden(unet_params, task):
         assert rel(env.state["output"], gold[f"{task}_output{s}"]) < tol_state
         assert np.array_equal(env.idx_left.cpu().numpy(), gold[f"{task}_idx_left{s}"])
         assert not all_done
+
+
+@pytest.mark.parametrize("task", ["pr", "spi", "ct"])
+def test_other_task_env_forward_differentiates_through_the_fused_solver(unet_params, task, monkeypatch):
+    """PnPEnv.forward (tfpnp/env/base.py:193-206) of the PR / SPI / CT environments under autograd: the delta-PSNR reward
+    differentiated wrt the actions runs through the solver's fused native training path; its action gradients equal those of
+    the same env with the solver's composed loop (`_forward_autograd`) put in place of `forward`."""
+    from tests.golden_inputs import env_case
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.tasks import pr, spi, ct
+    den = UNetDenoiser2D(state_dict=unet_params)
+    data, acts = env_case(task)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    make = {"pr": lambda: pr.PREnv(None, pr.IADMMSolver_PR(den), max_episode_step=3),
+            "spi": lambda: spi.SPIEnv(None, spi.ADMMSolver_SPI(den), max_episode_step=3),
+            "ct": lambda: ct.CTEnv(None, ct.IADMMSolver_CT(den), max_episode_step=3)}[task]
+    if task == "ct":                               # the golden CT case is the reference's geometry (47 bins) and covers reset only:
+        from tests.golden_inputs import csmri_actions   # measure with this package's own projector instead
+        from tfpnp_amd import synth
+        from tfpnp_amd.data.synthesis import ct_measure
+        gt = t(synth.phantom_batch(3, 32, 32, 512))
+        data = {k: v.cpu().numpy() for k, v in ct_measure(gt, 20).items()}
+        acts = [dict(csmri_actions(3, 3, 511, ("sigma_d", "mu", "tau")))]
+    keys = [k for k in acts[0] if k != "idx_stop"]
+
+    def run(composed):
+        env = make()
+        sol = env.solver
+        if composed:
+            if task == "ct":
+                monkeypatch.setattr(sol, "forward", lambda inputs, parameters, iter_num=None:
+                                    sol._forward_autograd(inputs[0], inputs[1][0], *parameters, iter_num))
+            else:
+                monkeypatch.setattr(sol, "forward", lambda inputs, parameters, iter_num=None:
+                                    sol._forward_autograd(inputs[0], *inputs[1], *parameters, iter_num))
+        ob = env.reset({k: t(v) for k, v in data.items()})
+        action = {k: t(acts[0][k]).clone().requires_grad_(True) for k in keys}
+        _, reward = env.forward(ob, action)
+        assert reward.shape[1] == 1 and torch.isfinite(reward).all()
+        reward.sum().backward()
+        return reward.detach(), [action[k].grad for k in keys]
+
+    r_f, g_f = run(False)
+    r_c, g_c = run(True)
+    tol = 5e-2 if task == "spi" else 2e-2          # SPI: bisection flips between two forward variants (test_spi_golden)
+    assert rel(r_f, r_c) < tol
+    for k, a_, b_ in zip(keys, g_f, g_c):
+        assert a_ is not None and torch.isfinite(a_).all(), k
+        if float(b_.abs().max()) > 0:
+            assert rel(a_, b_) < tol, (task, k, rel(a_, b_))
