@@ -422,3 +422,18 @@ def test_csmri_other_solvers_ragged_vs_oracle(den, oden, name, keys):
     st = sol((v0, (g(d["y0"]), g(d["mask"]))), tuple(g(a[k]) for k in keys), iter_num=T)
     ref = getattr(O, "csmri_" + name)(oden, t(v0.cpu().numpy()), t(d["y0"]), t(d["mask"]), *[t(a[k][:, :T]) for k in keys])
     assert rel(st, ref) < 1e-4
+
+
+def test_radon_forward_shape_sweep_vs_oracle():
+    """The ray-driven projector on zero-bordered copies against the oracle over odd / tiny / large resolutions and view counts,
+    with LOUD image borders (an off-by-one in the border handling or the loose sample interval would show at once)."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.utils import transforms as T
+    rs = np.random.RandomState(0)
+    for (R, V, B) in [(16, 1, 1), (17, 3, 2), (31, 7, 1), (33, 30, 2), (50, 11, 3), (97, 13, 1), (128, 60, 1), (200, 9, 1), (300, 5, 1)]:
+        img = rs.rand(B, 1, R, R).astype(np.float32)
+        img[:, :, :2, :], img[:, :, -2:, :], img[:, :, :, :2], img[:, :, :, -2:] = 5.0, -3.0, 7.0, -2.0
+        angles, det = O.radon_geometry(R, V)
+        ref = O.radon_forward(torch.from_numpy(img), angles, det)
+        out = T.Radon_norm(R, V, device=dev()).forward(torch.from_numpy(img).to(dev())).cpu()
+        assert float((out - ref).abs().max() / ref.abs().max()) < 2e-6, (R, V, B)
