@@ -28,6 +28,7 @@ inline HsFastDiv hs_fastdiv(unsigned d) {
 }
 
 struct ConvHsArgs {
+  int plain_walk = 0;   // set by the launcher: one tile per workgroup, tile j = blockIdx.x (launches that fit one round)
   const char* in0;   // HS8 tensor, G0 groups of 8 channels
   const char* in1;   // second source (channel concat), G1 groups
   const char* wpk;

@@ -175,7 +175,7 @@ __global__ __launch_bounds__((NW + HS_UPS_WAVES * UPS) * 64,
   // weight byte through one XCD (measured at B=1, 8x8 level: 386 us with the 8 cout tiles on one XCD, 53 us spread
   // over eight), so below 32 regions the work items are simply dealt out to consecutive workgroups (= XCDs).
   const int nregions = a.tilesX * a.tilesY * a.B;
-  const int nx = (gridDim.x % 8 == 0 && nregions >= 32) ? 8 : 1;
+  const int nx = (!a.plain_walk && gridDim.x % 8 == 0 && nregions >= 32) ? 8 : 1;
   const int xcd = blockIdx.x % nx, nslot = gridDim.x / nx;
 
   // the layer's bias vector, pre-scaled by HS_ASCALE, stays in LDS for the life of the workgroup (a global load in
@@ -931,12 +931,19 @@ static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
     }
   }
 #endif
-  if (grid > ntiles) grid = ntiles;
-  if (grid >= 8) grid -= grid % 8;          // whole XCD groups (the kernel falls back to a plain walk otherwise)
-  // the XCD-grouped walk (>= 32 pixel regions) wants nct | grid / 8 so that a workgroup keeps its cout tile; the plain walk of
-  // small launches has no such need, and rounding there would leave CUs idle (192 tiles on 128 workgroups: 2 rounds instead of 1)
-  const bool grouped = (long long)a.tilesX * a.tilesY * a.B >= 32;
-  if (grouped && a.nct > 1 && (grid / 8) % a.nct != 0 && grid >= 8 * a.nct) grid -= grid % (8 * a.nct);
+  // A launch whose tiles fit one round gets exactly one workgroup per tile and the plain walk (tile j = blockIdx.x: consecutive
+  // workgroups = consecutive XCDs take consecutive cout tiles of a region, so an XCD's L2 still sees only nct / 8-ths of the weights).
+  // The XCD-grouped walk wants 8 | grid and nct | grid / 8; rounding a small grid down to that made two rounds out of one
+  // (192 tiles on 128 workgroups at B = 6, 144 on 128 at B = 9: 85 instead of 44 us per launch at the 32 x 32 level), and an
+  // unrounded grouped walk leaves a ragged second round.  Larger launches run on all 256 workgroups, where both conditions hold.
+  if (grid >= ntiles) {
+    grid = ntiles;
+    a.plain_walk = 1;
+  } else {
+    if (grid >= 8) grid -= grid % 8;          // whole XCD groups (the kernel falls back to a plain walk otherwise)
+    const bool grouped = (long long)a.tilesX * a.tilesY * a.B >= 32;
+    if (grouped && a.nct > 1 && (grid / 8) % a.nct != 0 && grid >= 8 * a.nct) grid -= grid % (8 * a.nct);
+  }
 #ifdef PNPX_TUNING   // PNPX_HS_WGT=<file>: per-workgroup start / end stamps of every launch (tools/wg_spread.py)
   static unsigned long long* wbuf = nullptr;
   const char* wfile = getenv("PNPX_HS_WGT");
