@@ -544,10 +544,13 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
 static int launch_chains(const pnpx_ctx* ctx, int B, int H, int W) {
   int n = ctx->opt_chains;
   if (n == 0) {
-    // automatic: two chains where it was measured to pay (tools/ab_wall.py, 256^2: B = 6 1.155 -> 1.069 ms, B = 24
-    // 3.17 -> 3.07 ms per forward; B = 4 / 12 / 48: no gain or a loss) -- the per-GPU shards of an 8- and 2-way split
+    // automatic: two chains where they were measured to pay (tools/chains_table.py, every batch size 1..48 at 256^2,
+    // profiles/r3_chains_table.txt): a second chain fills the drain of launches whose last round is partly empty -- up to -12 %
+    // (B = 17, 33), -7 % at B = 6 / 9 / 10, -2 % at B = 24; it costs 2..10 % where one chain already fills its rounds (B <= 4,
+    // B = 7, 8, 15, 16) and changes nothing from B = 47 up (power-limited).  q = batch in 256 x 256 images.
     const long long q = (long long)B * H * W / (256 * 256);
-    n = ((q >= 5 && q <= 8) || (q >= 20 && q <= 28)) ? 2 : 1;
+    const bool full_rounds = q <= 16 && (q % 8 == 7 || q % 8 == 0);
+    n = (q >= 5 && q <= 46 && !full_rounds) ? 2 : 1;
   }
   if (n > 8) n = 8;
   return n > B ? B : (n < 1 ? 1 : n);

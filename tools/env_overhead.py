@@ -9,7 +9,7 @@ from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI, CSMRIEnv
 
 dev = torch.device("cuda:0")
 t = lambda a: torch.from_numpy(a)
-B, H = 48, 256
+B, H = (int(sys.argv[1]) if len(sys.argv) > 1 else 48), 256
 den = UNetDenoiser2D(state_dict=synth.make_unet_params(0))
 solver = ADMMSolver_CSMRI(den)
 d = synth.make_csmri_batch(B, H, H, ratio=4, sigma_n=15.0, seed=1234)
