@@ -99,6 +99,23 @@ def test_drunet_full_config5_iteration_runs_and_matches_oracle_slice(drunet):
     assert rel(v[:2, :1], want[:, :1]) < 1e-4
 
 
+def test_drunet_launch_chains_are_bit_identical(drunet):
+    """The DRUNet forward sliced into independent launch chains (option `chains`; automatic for the batch sizes between round
+    boundaries, as for the UNet): per-image results do not depend on the slicing."""
+    ctx = drunet.context(dev())
+    try:
+        for (B, H, W) in [(5, 64, 64), (9, 32, 48), (3, 128, 64), (6, 256, 256)]:
+            x, s = denoiser_inputs(B, H, W, 77)
+            x, s = t(x).to(dev()), t(s).to(dev())
+            ctx.set_option("chains", 1)
+            ref = drunet(x, s).clone()
+            for c in (2, 3, 0):
+                ctx.set_option("chains", c)
+                assert torch.equal(drunet(x, s), ref), (B, H, W, c)
+    finally:
+        ctx.set_option("chains", 0)
+
+
 def test_drunet_contract_errors(drunet):
     from tfpnp_amd._lib import PnpxError
     from tfpnp_amd.pnp import DRUNetDenoiser2D, create_denoiser

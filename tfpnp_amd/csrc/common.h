@@ -111,6 +111,8 @@ struct PolicyNet {
   int capB = 0, capH = 0, capW = 0;
 };
 
+// number of independent launch chains for a B-image denoiser forward (unet.hip; option "chains", 0 = automatic)
+int launch_chains(const pnpx_ctx* ctx, int B, int H, int W);
 // DRUNet denoiser (drunet.hip): packed weights per MFMA launch in state_dict order + its own activation arena
 struct DruNet {
   bool loaded = false;

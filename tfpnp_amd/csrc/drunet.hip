@@ -273,9 +273,29 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
     N.capW = W;
   }
   const DruPlan Pl = dru_plan(N.capB, H, W);
-  char* A = static_cast<char*>(N.arena.p);
+  char* const A0 = static_cast<char*>(N.arena.p);
   unsigned* const range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
   const std::vector<LayerDesc> L = dru_layers(N.nb);
+
+  // The forward over images b0 .. b0 + B - 1 of the arena on stream s (x / sigma / out already point at the first of them): every
+  // tensor is [image][group][h + 2][w + 2] records, so a slice of the batch is a contiguous piece of each -- independent launch
+  // chains over slices run side by side on side streams exactly as for the UNet (unet.hip: launch_chains; bit-identical per image).
+  auto run = [&](int b0, int B, const float* x, const float* sigma, float* out, float* out_pre, hipStream_t s) -> int {
+  struct Shifted {   // arena offsets of this slice
+    size_t S[4], P[4], Q[4], M[4], U[4], DT[4], zimg;
+  } Sl{};
+  for (int l = 0; l < 4; ++l) {
+    const size_t per = rec_bytes(DRU_NC[l], H >> l, W >> l) * (size_t)b0;
+    Sl.S[l] = Pl.S[l] + per;
+    Sl.P[l] = Pl.P[l] + per;
+    Sl.Q[l] = Pl.Q[l] + per;
+    Sl.M[l] = Pl.M[l] + per;
+    Sl.U[l] = Pl.U[l] + per;
+    Sl.DT[l] = Pl.DT[l] + rec_bytes(2 * DRU_NC[l], H >> l, W >> l) * (size_t)b0;
+  }
+  Sl.zimg = Pl.zimg + sizeof(float) * (size_t)H * W * b0;
+  char* const A = A0;
+  const Shifted& Pl = Sl;      // the body below addresses the slice through the same names
   size_t li = 0;
 
   // one MFMA convolution launch: layer li, `in` (cin channels) -> `outp`
@@ -363,6 +383,31 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
     set_error("DRUNet: internal layer walk mismatch (%zu of %zu)", li, L.size());
     return PNPX_ERR_ARG;
   }
+  return PNPX_OK;
+  };
+
+  const int chains = launch_chains(ctx, B, H, W);
+  if (chains <= 1) return run(0, B, x, sigma, out, out_pre, s);
+  while ((int)ctx->side_streams.size() < chains - 1) {
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    PNPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ctx->side_streams.push_back(st);
+    PNPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ctx->side_joins.push_back(ev);
+  }
+  if (!ctx->side_fork) PNPX_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+  const size_t px = (size_t)H * W;
+  PNPX_HIP(hipEventRecord(ctx->side_fork, s));
+  for (int c = chains - 1; c >= 0; --c) {       // the caller's stream takes slice 0 last: its host-side issue overlaps
+    const int lo = (int)((long long)B * c / chains), hi = (int)((long long)B * (c + 1) / chains);
+    hipStream_t st = c ? ctx->side_streams[c - 1] : s;
+    if (c) PNPX_HIP(hipStreamWaitEvent(st, ctx->side_fork, 0));
+    PNPX_TRY(run(lo, hi - lo, x + lo * px, sigma + (size_t)lo * sigma_stride, out + lo * px, out_pre ? out_pre + lo * px : nullptr,
+                 st));
+    if (c) PNPX_HIP(hipEventRecord(ctx->side_joins[c - 1], st));
+  }
+  for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, ctx->side_joins[c - 1], 0));
   return PNPX_OK;
 }
 

@@ -541,7 +541,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
 }
 
 // Number of independent launch chains for a B-image forward: option "chains" (0 = automatic, n = exactly n when B >= n).
-static int launch_chains(const pnpx_ctx* ctx, int B, int H, int W) {
+int launch_chains(const pnpx_ctx* ctx, int B, int H, int W) {
   int n = ctx->opt_chains;
   if (n == 0) {
     // automatic: two chains where they were measured to pay (tools/chains_table.py, every batch size 1..48 at 256^2,
