@@ -84,6 +84,27 @@ def test_policy_actor_full_size_vs_oracle_and_determinism():
     assert torch.equal(p2, probs) and torch.equal(d2, det)
 
 
+def test_policy_launch_chains_are_bit_identical():
+    """The actor forward sliced into independent launch chains (option `chains`; automatic between the round boundaries of its
+    deep stages): per-observation outputs do not depend on the slicing, nor on the batch they arrive in."""
+    from tfpnp_amd import ops
+    actor, _ = make_actor("admm", 9, 10, False)
+    ctx = actor.context(dev())
+    try:
+        for (B, H, W) in [(9, 64, 64), (17, 64, 96), (5, 128, 128), (33, 32, 32)]:
+            ob = g(policy_obs(B, 9, H, W, 85))
+            ctx.set_option("chains", 1)
+            ref = [t_.clone() for t_ in ops.policy_forward(ctx, ob)]
+            for c in (2, 3, 0):
+                ctx.set_option("chains", c)
+                out = ops.policy_forward(ctx, ob)
+                assert all(torch.equal(a, b) for a, b in zip(out, ref)), (B, H, W, c)
+            one = ops.policy_forward(ctx, ob[B // 2:B // 2 + 1])
+            assert all(torch.equal(a, b[B // 2:B // 2 + 1]) for a, b in zip(one, ref))
+    finally:
+        ctx.set_option("chains", 0)
+
+
 def test_policy_rejects_bad_input():
     from tfpnp_amd import ops, policy
     from tfpnp_amd._lib import PnpxError

@@ -582,8 +582,30 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
     N.capH = H;
     N.capW = W;
   }
-  const PolicyPlan P = make_policy_plan(N.capB, N.cin_pad, H, W);
+  const PolicyPlan P0 = make_policy_plan(N.capB, N.cin_pad, H, W);
   float* A = static_cast<float*>(N.arena.p);
+  const bool all_hs = ctx->opt_policy_s2_hs && (N.stem_hs.cin_pad % 16 == 0);   // every activation is an HS8 tensor (the default)
+
+  // The forward over observations b0 .. b0 + B - 1 (ob / probs / det already point at the first of them) on stream s.  With every
+  // activation an HS8 tensor [image][group][h + 2][w + 2], a slice of the batch is a contiguous piece of each: slices run as
+  // independent launch chains on side streams like the denoisers' (unet.hip: launch_chains; bit-identical per image) -- the deep
+  // 8 x 8 / 16 x 16 stages otherwise step up at every round boundary (B = 33: 1.34 ms against 1.02 at B = 32).
+  auto run = [&](int b0, int B, const float* ob, float* probs, float* det, hipStream_t s) -> int {
+  PolicyPlan P = P0;
+  if (b0) {
+    auto shift = [&](PolAct& d) { d.off += (size_t)b0 * d.C * (d.H + 2) * (d.W + 2); };   // HS8 tensors only (all_hs)
+    shift(P.stem_hs);
+    shift(P.ob_hs);
+    shift(P.stem_o);
+    for (int n = 0; n < 4; ++n) {
+      shift(P.t1[n]);
+      shift(P.sc[n]);
+      shift(P.o0[n]);
+      shift(P.t2[n]);
+      shift(P.o1[n]);
+      if (n < 3) shift(P.o1s[n]);
+    }
+  }
   auto ptr = [&](const PolAct& d) { return A + d.off; };
 
   auto hsc0 = [&](const PolAct& d) { return reinterpret_cast<char*>(A + d.off); };
@@ -695,6 +717,41 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
   hipLaunchKernelGGL(pool_heads_kernel, dim3(B), dim3(256), 0, s, reinterpret_cast<const HsRec*>(hsc(P.o1[3])), H / 32, W / 32, N.fc_sm_w, N.fc_sm_b,
                      N.fc_det_w, N.fc_det_b, N.fc_det2_w, N.fc_det2_b, N.n_det, N.spi_head, probs, det);
   PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+  };
+
+  // option "chains": n = exactly n chains (when B >= n); 0 = automatic, from the table of every batch size 1..48 at 256 x 256 with
+  // one and two chains: two chains pay between the round boundaries of the 8 x 8 / 16 x 16 stages -- B = 9..15
+  // (-3..-6 %), 17..24 (-2..-7 %), 33..48 (-8..-15 %) -- and cost up to 12 % elsewhere (B = 32).  q = batch in 256 x 256 images.
+  int chains = 1;
+  if (all_hs) {
+    if (ctx->opt_chains != 0) {
+      chains = launch_chains(ctx, B, H, W);
+    } else {
+      const long long q = (long long)B * H * W / (256 * 256);
+      chains = ((q >= 9 && q <= 15) || (q >= 17 && q <= 24) || q >= 33) ? 2 : 1;
+    }
+    if (chains > B) chains = B;
+  }
+  if (chains <= 1) return run(0, B, ob, probs, det, s);
+  while ((int)ctx->side_streams.size() < chains - 1) {
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    PNPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ctx->side_streams.push_back(st);
+    PNPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    ctx->side_joins.push_back(ev);
+  }
+  if (!ctx->side_fork) PNPX_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+  PNPX_HIP(hipEventRecord(ctx->side_fork, s));
+  for (int c = chains - 1; c >= 0; --c) {       // the caller's stream takes slice 0 last: its host-side issue overlaps
+    const int lo = (int)((long long)B * c / chains), hi = (int)((long long)B * (c + 1) / chains);
+    hipStream_t st = c ? ctx->side_streams[c - 1] : s;
+    if (c) PNPX_HIP(hipStreamWaitEvent(st, ctx->side_fork, 0));
+    PNPX_TRY(run(lo, hi - lo, ob + (size_t)lo * N.num_inputs * H * W, probs + (size_t)lo * 2, det + (size_t)lo * N.n_det, st));
+    if (c) PNPX_HIP(hipEventRecord(ctx->side_joins[c - 1], st));
+  }
+  for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, ctx->side_joins[c - 1], 0));
   return PNPX_OK;
 }
 
