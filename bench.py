@@ -176,7 +176,9 @@ def main():
         out["NOT_A_MEASUREMENT"] = f"PNPX_BENCH_SHARE_GPU: {world} ranks time-share device 0 over gloo (plumbing test)"
 
     if rank == 0 and not args.no_roofline:
-        out["roofline"] = roofline(den, dev, B, H, W)
+        # on the images and noise levels the episode ended with (real operand statistics: the package is power-capped
+        # and MFMA power follows operand bit activity)
+        out["roofline"] = roofline(den, dev, env.state["output"].detach().clone(), actions[-1]["sigma_d"][:, -1].contiguous())
         out["roofline"]["power"] = power
         if power and power.get("gfx_clk_mhz_avg"):
             # the same dense-f16 peak at the clock the power cap actually allowed during the timed region
@@ -328,22 +330,40 @@ class PowerSampler:
                 "samples": n, "source": "amdsmi current_socket_power / GFX clk, 50 ms period over the timed region"}
 
 
-def roofline(den, dev, B, H, W, reps=3):
-    """fp32-MFMA roofline of the dominant kernel family (the 27 conv3x3 launches of one denoiser forward):
-    algorithmic FLOPs (2*9*Cin*Cout*H*W*B per launch) / HIP-event duration of exactly those launches."""
-    x = torch.rand(B, 1, H, W, device=dev)
-    sigma = torch.full((B,), 25 / 255.0, device=dev)
+def forward_split(den, dev, x, sigma, n_fwd=12, reps=3):
+    """Steady-state time of ONE denoiser forward and its split by kernel.
+    whole_ms : one HIP-event pair around n_fwd back-to-back production forwards (the launch chains the solver runs,
+               hot clocks), divided by n_fwd -- the number every per-kernel figure is scaled to.
+    shares   : per-kernel fractions from ops.unet_profile, which brackets EVERY launch with its own event pair (that
+               serialises the launch chains and adds a gap per launch, so its absolute sum is a few per cent longer
+               than a real forward; only the ratios are used)."""
     ctx = den.context(dev)
-    tot_ms = conv_ms = 0.0
-    conv_fl = 0.0
-    per = {}
+    den(x, sigma)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n_fwd):
+        den(x, sigma)
+    e1.record()
+    torch.cuda.synchronize()
+    whole_ms = e0.elapsed_time(e1) / n_fwd
+    per, fl = {}, 0.0
     for _ in range(reps):
-        for name, ms, fl in ops.unet_profile(ctx, x, sigma):
-            tot_ms += ms
+        for name, ms, f in ops.unet_profile(ctx, x, sigma):
             per[name] = per.get(name, 0.0) + ms
             if name == "conv3x3":
-                conv_ms += ms
-                conv_fl += fl
+                fl += f
+    tot = sum(per.values())
+    return whole_ms, {k: v / tot for k, v in per.items()}, fl / reps, tot / reps
+
+
+def roofline(den, dev, x, sigma):
+    """MFMA roofline of the dominant kernel family (the 27 conv3x3 layers of one denoiser forward): algorithmic FLOPs
+    (2*9*Cin*Cout*H*W*B per launch) / time of exactly those launches inside a steady-state production forward
+    (forward_split: bracketed whole forwards x the per-kernel share)."""
+    B, _, H, W = x.shape
+    whole_ms, shares, conv_fl, profiled_ms = forward_split(den, dev, x, sigma)
+    conv_ms = whole_ms * shares.get("conv3x3", 0.0)
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12
     return {
         "bound": "mfma",
@@ -354,16 +374,22 @@ def roofline(den, dev, B, H, W, reps=3):
         "unit": "TFLOP/s",
         "frac": achieved / PEAK_HS_TFLOPS,
         "peak_note": "dense f16 MFMA peak 2500 TF/s / 3 MFMAs per product; the exact-fp32 MFMA peak is 157.3 TF/s",
+        "executed_mfma_flops_per_forward": 3 * conv_fl,
+        "executed_mfma_note": "every algorithmic product is 3 f16 MFMA products (hi*hi, hi*lo, lo*hi); no Winograd / FFT "
+                              "reduction (profiles/r4_winograd_probe.md), so executed = 3 x algorithmic",
         "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
         # what the same MFMA stream sustains on this GPU (profiles/r1_mfma_microbench.md, tools/micro/mfma_rate.hip):
         # register-only loop on toggling operands 1740 TF/s f16 (power-limited), with conv_hs's fragment reads 1491
         "frac_of_sustained_mfma_loop": achieved / (1740.0 / 3.0),
         "frac_of_sustained_mfma_loop_with_operand_reads": achieved / (1491.0 / 3.0),
         "traffic": pmc_traffic(B, H, W),
-        "flops_per_forward": conv_fl / reps,
-        "conv_ms_per_forward": conv_ms / reps,
-        "denoiser_ms_per_forward": tot_ms / reps,
-        "ms_by_kernel": {k: v / reps for k, v in per.items()},
+        "flops_per_forward": conv_fl,
+        "conv_ms_per_forward": conv_ms,
+        "denoiser_ms_per_forward": whole_ms,
+        "timing": "one HIP-event pair around 12 back-to-back production forwards on the episode's final images; per-kernel "
+                  "split = shares of a per-launch-event pass scaled to it (that pass alone sums to "
+                  f"{profiled_ms:.3f} ms: launch chains serialised)",
+        "ms_by_kernel": {k: whole_ms * v for k, v in shares.items()},
     }
 
 
@@ -412,23 +438,18 @@ def fp32_mode(params, data, actions, dev, B, H, W, steps, warmup):
         episode()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    ctx = den.context(dev)
-    x = torch.rand(B, 1, H, W, device=dev)
-    sigma = torch.full((B,), 25 / 255.0, device=dev)
-    conv_ms = conv_fl = 0.0
-    reps = 3
-    for _ in range(reps):
-        for name, ms, fl in ops.unet_profile(ctx, x, sigma):
-            if name == "conv3x3":
-                conv_ms += ms
-                conv_fl += fl
+    x = env.state["output"].detach().clone()
+    sigma = actions[-1]["sigma_d"][:, -1].contiguous()
+    whole_ms, shares, conv_fl, _ = forward_split(den, dev, x, sigma, n_fwd=6)
+    conv_ms = whole_ms * shares.get("conv3x3", 0.0)
     tf = conv_fl / (conv_ms * 1e-3) / 1e12
     return {"value": N_POLICY_STEPS * ACTION_PACK / dt, "unit": "iters/s", "steps": steps, "warmup": max(1, warmup),
             "ms_per_step": 1e3 * dt, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 FMA chain)",
             "iters_per_s": N_POLICY_STEPS * ACTION_PACK / dt,
             "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (27 launches per denoiser forward)",
                          "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / PEAK_FP32_MFMA_TFLOPS, "conv_ms_per_forward": conv_ms / reps, "traffic": None}}
+                         "frac": tf / PEAK_FP32_MFMA_TFLOPS, "conv_ms_per_forward": conv_ms,
+                         "denoiser_ms_per_forward": whole_ms, "traffic": None}}
 
 
 def pmc_traffic(B, H, W):

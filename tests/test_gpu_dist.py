@@ -56,7 +56,7 @@ def test_bench_two_ranks_share_the_gpu(scaling):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PNPX_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "6",
-           "--size", "64", "--scaling", scaling, "--no-cpu-baseline", "--no-batch-table", "--no-fp32-mode", "--no-roofline"]
+           "--size", "64", "--scaling", scaling, "--no-cpu-baseline", "--no-batch-table", "--no-fp32-mode"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -66,3 +66,8 @@ def test_bench_two_ranks_share_the_gpu(scaling):
     assert d["collectives_per_env_step"] == 1.0
     assert d["config"]["global_batch"] == (6 if scaling == "strong" else 12)
     assert "NOT_A_MEASUREMENT" in d
+    # the roofline object is self-consistent with the step clock: 30 denoiser forwards fit inside one step
+    rf = d["roofline"]
+    assert 0 < rf["conv_ms_per_forward"] <= rf["denoiser_ms_per_forward"]
+    assert rf["denoiser_ms_per_forward"] * d["config"]["iters_per_step"] <= d["ms_per_step"]
+    assert abs(sum(rf["ms_by_kernel"].values()) - rf["denoiser_ms_per_forward"]) < 1e-6 * rf["denoiser_ms_per_forward"] + 1e-9
