@@ -152,6 +152,49 @@ def gradient_goldens(den):
     save("solver_grads", in_sha=sha(d["y0"], d["mask"], d["x0"], a["sigma_d"], a["mu"], wts, d2["y0"], raw0), **res)
 
 
+def kinkfree_gradient_goldens(den):
+    """(13) the reference's OWN autograd on the kink-free cases of tests/golden_inputs.py (KINKFREE_TRY): HQS / PG / APG /
+    RED-ADMM for CS-MRI (tasks/csmri/solver.py:64-204), iADMM for phase retrieval (tasks/pr/solver.py:37-76), ADMM for
+    single-photon imaging (tasks/spi/solver.py:17-52) and the DRUNet denoiser assembled from basicblock.py -- d sum(out * wts)
+    / d (variables, hyper-parameters).  Every non-smooth decision of these trajectories is >= KINK_MARGIN from its kink
+    (re-checked by tests/test_oracle_golden.py), so the native VJPs must reproduce the numbers to rounding."""
+    from tests.golden_inputs import KINKFREE_KEYS, kinkfree_case
+    cs = ref_shim.load_task_module("csmri", "solver")
+    pr = ref_shim.load_task_module("pr", "solver")
+    spi = ref_shim.load_task_module("spi", "solver")
+    res, hashes = {}, []
+
+    def run(name, fn):
+        c = kinkfree_case(name)
+        leaves = [t(c["v0"]).requires_grad_(True)] + [t(p).requires_grad_(True) for p in c["acts"]]
+        out = fn(c, *leaves)
+        (out * t(c["wts"])).sum().backward()
+        res[f"{name}_out"] = out.detach()
+        for key, leaf in zip(("variables",) + KINKFREE_KEYS[name], leaves):
+            res[f"{name}_grad_{key}"] = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
+        hashes.extend([c["v0"], c["wts"]] + list(c["acts"]))
+
+    for name, cls in (("hqs", cs.HQSSolver_CSMRI), ("pg", cs.PGSolver_CSMRI), ("apg", cs.APGSolver_CSMRI),
+                      ("redadmm", cs.REDADMMSolver_CSMRI)):
+        run(name, lambda c, v, *p, cls=cls: cls(den)((v, (t(c["y0"]), t(c["mask"]))), tuple(p)))
+    run("pr", lambda c, v, *p: pr.IADMMSolver_PR(den)((v, (t(c["y0"]), t(c["mask"]))), tuple(p)))
+    run("spi", lambda c, v, *p: spi.ADMMSolver_SPI(den)((v, (t(c["x0"]), t(c["K"]))), tuple(p)))
+    net = ref_shim.make_drunet(synth.make_drunet_params(WEIGHT_SEED))
+
+    def dru(c, x, sigma):                 # tfpnp/pnp/denoiser/base.py:23-32 with the network swapped (as drunet_goldens)
+        N, C, H, W = x.shape
+        return torch.clamp(net(torch.cat([x, torch.ones(N, 1, H, W) * sigma.view(N, 1, 1, 1)], dim=1)), 0, 1)
+    run("drunet", dru)
+    # one arbitrary DRUNet case (B=2, 32x32: ReLU decisions may flip between fp32 evaluations; loose bound in the tests)
+    x, sigma = denoiser_inputs(2, 32, 32, 1161)
+    w = np.random.RandomState(1162).standard_normal(x.shape).astype(np.float32)
+    lx, ls = t(x).requires_grad_(True), t(sigma).requires_grad_(True)
+    o = dru(None, lx, ls)
+    (o * t(w)).sum().backward()
+    res.update(drunet32_out=o.detach(), drunet32_grad_variables=lx.grad, drunet32_grad_sigma=ls.grad)
+    save("solver_grads_kinkfree", in_sha=sha(*hashes, x, sigma, w), **res)
+
+
 def drunet_goldens():
     """(11) DRUNet: the model assembled from the reference's own basicblock.py parts (ref_shim.make_drunet) on seeded inputs:
     pre-clamp network output and the clamped denoiser output, plus one SPI ADMM call that uses it as the prox."""
@@ -257,6 +300,10 @@ def main():
     if "--only-drunet" in sys.argv:
         print("[11] DRUNet")
         drunet_goldens()
+        return
+    if "--only-kinkfree" in sys.argv:
+        print("[13] kink-free gradient cases")
+        kinkfree_gradient_goldens(ref_shim.make_denoiser(synth.make_unet_params(WEIGHT_SEED), tempfile.mkdtemp()))
         return
     if "--only-grads" in sys.argv or "--only-envs" in sys.argv:
         den = ref_shim.make_denoiser(synth.make_unet_params(WEIGHT_SEED), tempfile.mkdtemp())
@@ -450,6 +497,12 @@ def main():
     gradient_goldens(den)
     print("[10] PR / SPI / CT environments")
     env_goldens(den)
+    print("[11] DRUNet")
+    drunet_goldens()
+    print("[12] measurement synthesis")
+    synthesis_goldens()
+    print("[13] kink-free gradient cases")
+    kinkfree_gradient_goldens(den)
     print("done")
 
 

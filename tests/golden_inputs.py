@@ -1,6 +1,7 @@
 """Seeded input generators shared by oracle/make_goldens.py (which runs the real reference on them)
 and by the tests (which rebuild the same inputs and compare against tests/golden/*.npz)."""
 import hashlib
+import os
 
 import numpy as np
 import torch
@@ -143,6 +144,10 @@ class _KinkProbe:
         self.margin = min(self.margin, float(x.abs().min() / x.abs().mean()))
         return self.F.leaky_relu(x, slope)
 
+    def relu(self, x):
+        self.margin = min(self.margin, float(x.abs().min() / x.abs().mean()))
+        return self.F.relu(x)
+
     def max_pool2d(self, x, k):
         B, C, H, W = x.shape
         win = x[:, :, :H // 2 * 2, :W // 2 * 2].reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5)
@@ -153,27 +158,134 @@ class _KinkProbe:
 
 
 def solver_kink_margin(run):
-    """Smallest distance of any LeakyReLU / max-pool / clamp decision from its kink over a whole fp64 oracle solver run
-    (every denoiser call of every inner iteration)."""
+    """Smallest distance of any LeakyReLU / ReLU / max-pool / clamp / bisection decision from its kink over a whole fp64
+    oracle run (every denoiser call of every inner iteration; UNet or DRUNet prox; the SPI Poisson prox's 10 sign tests)."""
     from oracle import pnp_oracle as O
-    probe, keep_f, keep_d = _KinkProbe(), O.F, O.denoise
-    clamp_margin = [float("inf")]
+    probe = _KinkProbe()
+    keep = (O.F, O.denoise, O.drunet_denoise, O.spi_inverse)
+    other = [float("inf")]
 
-    def denoise_probe(x, sigma, params):
-        N, _, H, W = x.shape
-        pre = O.unet_forward(torch.cat([x, torch.ones(N, 1, H, W, dtype=x.dtype) * sigma.view(N, 1, 1, 1)], 1), params)
-        clamp_margin[0] = min(clamp_margin[0], float(pre.abs().min()), float((pre - 1).abs().min()))
+    def note(v):
+        other[0] = min(other[0], float(v))
+
+    def clamp01(pre):
+        note(pre.abs().min())
+        note((pre - 1).abs().min())
         return torch.clamp(pre, 0, 1)
 
-    O.F, O.denoise = probe, denoise_probe
+    def noise_cat(x, sigma):
+        N, _, H, W = x.shape
+        return torch.cat([x, torch.ones(N, 1, H, W, dtype=x.dtype) * sigma.view(N, 1, 1, 1)], 1)
+
+    def spi_inverse_probe(ztilde, K1, K, mu):          # oracle/pnp_oracle.py::spi_inverse with the decisions recorded
+        K0 = K ** 2 - K1
+        live = (K1 != 0).expand_as(ztilde)
+        bmin = 1e-5 * torch.ones_like(ztilde)
+        bmax = 1.1 * torch.ones_like(ztilde)
+        bave = (bmin + bmax) / 2.0
+        for _ in range(10):
+            tmp = K1 / (torch.exp(bave) - 1) - mu * bave - K0 + mu * ztilde
+            if bool(live.any()):
+                note((tmp.abs() / mu)[live].min())      # in units of z
+        z_lin = ztilde - (K0 / mu)
+        if bool((~live).any()):
+            note(z_lin[~live].abs().min())
+            note((z_lin[~live] - 1).abs().min())
+        return keep[3](ztilde, K1, K, mu)
+
+    O.F = probe
+    O.denoise = lambda x, sigma, params: clamp01(O.unet_forward(noise_cat(x, sigma), params))
+    O.drunet_denoise = lambda x, sigma, params: clamp01(O.drunet_forward(noise_cat(x, sigma), params))
+    O.spi_inverse = spi_inverse_probe
     try:
         with torch.no_grad():
             run()
     finally:
-        O.F, O.denoise = keep_f, keep_d
-    return min(probe.margin, clamp_margin[0])
+        O.F, O.denoise, O.drunet_denoise, O.spi_inverse = keep
+    return min(probe.margin, other[0])
 
 
+# ---- kink-free gradient cases (tests/golden/solver_grads_kinkfree.npz) -------------------------------------------------
+# One small case per differentiable solver / denoiser whose whole fp64 trajectory keeps every non-smooth decision at least
+# KINK_MARGIN away from its kink, so that independent fp32-class evaluations (the reference's autograd on the CPU, the native
+# VJPs) share every decision and agree to rounding.  KINKFREE_TRY[name] = the first try index that qualifies, found by
+# `python tests/golden_inputs.py` (search) and re-verified by tests/test_oracle_golden.py.
+KINK_MARGIN = 1e-5
+KINKFREE_KEYS = {"hqs": ("sigma_d", "mu"), "pg": ("sigma_d", "tau"), "apg": ("sigma_d", "tau", "beta"),
+                 "redadmm": ("sigma_d", "mu", "lamda"), "pr": ("sigma_d", "mu", "tau"), "spi": ("sigma_d", "mu"),
+                 "drunet": ("sigma",)}
+KINKFREE_TRY = {"hqs": 0, "pg": 2, "apg": 1, "redadmm": 0, "pr": 1, "spi": 5, "drunet": 4}
+
+
+def kinkfree_case(name, k=None):
+    """Inputs of the kink-free gradient case `name` (try index k, default the frozen one): dict with the data tensors, `v0`
+    (initial variables; the image for "drunet"), `acts` (list, KINKFREE_KEYS order) and `wts` (output weights of the loss)."""
+    from oracle import pnp_oracle as O
+    k = KINKFREE_TRY[name] if k is None else k
+    keys = KINKFREE_KEYS[name]
+    if name in ("hqs", "pg", "apg", "redadmm"):
+        d = synth.make_csmri_batch(1, 16, 16, seed=1071 + 100 * k)
+        a = csmri_actions(1, 2, 1072 + 100 * k, keys)
+        if "beta" in a:
+            a["beta"] = (0.3 * a["beta"]).astype(np.float32)
+        x0 = d["x0"]
+        nvar = {"hqs": 2, "pg": 1, "apg": 2, "redadmm": 3}[name]
+        v0 = np.concatenate([x0] * nvar, 1)             # reset: x (and z / s) = x0.clone() ...
+        if name == "redadmm":
+            v0[:, 2] = 0                                #       ... u = 0 (tfpnp/pnp/solver/base.py:118-209)
+        c = {"y0": d["y0"], "mask": d["mask"]}
+    elif name == "pr":
+        d = synth.make_pr_batch(1, 16, 16, S=4, alpha=9.0, seed=1075 + 100 * k)
+        a = csmri_actions(1, 2, 1076 + 100 * k, keys)
+        a["tau"] = (0.5 * a["tau"]).astype(np.float32)
+        # the solver's own start (x = z = ones) is a constant image, whose denoised value sits ON the clamp's kink at 1: start
+        # from a mid-grey estimate instead (the gradient identity under test does not care where the iteration starts)
+        rs = np.random.RandomState(1077 + 100 * k)
+        z = 0.2 + 0.6 * d["gt"] + 0.02 * rs.standard_normal(d["gt"].shape).astype(np.float32)
+        zc = np.stack([z, 0.02 * rs.standard_normal(z.shape).astype(np.float32)], -1)
+        v0 = np.concatenate([zc, zc, 0.02 * rs.standard_normal(zc.shape).astype(np.float32)], 1)
+        c = {"y0": d["y0"], "mask": d["mask"]}
+    elif name == "spi":
+        d = synth.make_spi_batch(1, 16, 16, K=6, seed=1078 + 100 * k)
+        rs = np.random.RandomState(1079 + 100 * k)
+        a = {"sigma_d": rs.uniform(15 / 255.0, 70 / 255.0, (1, 1)).astype(np.float32),
+             "mu": rs.uniform(50, 120, (1, 1)).astype(np.float32)}
+        v0 = np.concatenate([d["x0"], d["x0"], 0.02 * rs.standard_normal(d["x0"].shape).astype(np.float32)], 1)
+        c = {"x0": d["x0"], "K": d["K"]}
+    elif name == "drunet":
+        x, sigma = denoiser_inputs(1, 16, 16, 1061 + 100 * k)
+        a = {"sigma": sigma}
+        v0 = x
+        c = {}
+    else:
+        raise KeyError(name)
+    c.update(v0=np.ascontiguousarray(v0, np.float32), acts=[a[key] for key in keys],
+             wts=np.random.RandomState(1073).standard_normal(v0.shape).astype(np.float32))
+    return c
+
+
+def kinkfree_oracle_run(name, c, dtype, den):
+    """The oracle evaluation of case `c` as a function of (v0, *acts) -> output, in `dtype` (den: oracle denoiser of that dtype)."""
+    from oracle import pnp_oracle as O
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    if name in ("hqs", "pg", "apg", "redadmm"):
+        y0, m = tt(c["y0"]).to(dtype), tt(c["mask"])
+        return lambda v, *p: getattr(O, "csmri_" + name)(den, v, y0, m, *p)
+    if name == "pr":
+        y0, m = tt(c["y0"]).to(dtype), tt(c["mask"]).to(dtype)
+        return lambda v, *p: O.pr_iadmm(den, v, y0, m, *p)
+    if name == "spi":
+        x0, K = tt(c["x0"]).to(dtype), tt(c["K"]).to(dtype)
+        return lambda v, *p: O.spi_admm(den, v, x0, K, *p)
+    if name == "drunet":
+        return lambda v, sigma: den(v, sigma)
+    raise KeyError(name)
+
+
+def kinkfree_margin(name, c, den64):
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()
+    fn = kinkfree_oracle_run(name, c, torch.float64, den64)
+    return solver_kink_margin(lambda: fn(tt(c["v0"]), *[tt(p) for p in c["acts"]]))
 
 
 def env_case(task):
@@ -234,3 +346,22 @@ def noise_model_inputs():
     return (rs.standard_normal((3, 1, 16, 24, 2)).astype(np.float32),       # k-space-like (GaussianModelC / D)
             rs.uniform(0, 2, (3, 4, 16, 24)).astype(np.float32),            # magnitudes (PoissonModel)
             rs.uniform(0, 40, (3, 1, 30, 45)).astype(np.float32))           # sinogram-like (GaussianModelP)
+
+
+if __name__ == "__main__":      # search: first qualifying try per case (paste into KINKFREE_TRY)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pnp_oracle as O
+    unet64 = O.Denoiser(synth.make_unet_params(WEIGHT_SEED), torch.float64)
+    dru64 = O.DRUNetDenoiser(synth.make_drunet_params(WEIGHT_SEED), torch.float64)
+    found = {}
+    for name in (sys.argv[1:] or KINKFREE_KEYS):
+        for k in range(200):
+            m = kinkfree_margin(name, kinkfree_case(name, k), dru64 if name == "drunet" else unet64)
+            if m > KINK_MARGIN:
+                found[name] = k
+                print(f"{name}: try {k} margin {m:.2e}", flush=True)
+                break
+        else:
+            print(f"{name}: none found")
+    print("KINKFREE_TRY =", found)

@@ -251,8 +251,10 @@ def test_env_step_redoes_a_tripped_step_in_exact_fp32(unet_params):
     g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
     data = {k: g(v) for k, v in d.items()}
     acts = [{k: g(v) for k, v in a.items()} for a in synth.make_actions(3)[:2]]
-    for a in acts:
-        a["idx_stop"] = torch.zeros(3, dtype=torch.int64, device=dev())
+    # item 1 stops IN the tripped step (the repeated step must still report the rows that were live during it)
+    acts[0]["idx_stop"] = torch.tensor([0, 1, 0], dtype=torch.int64, device=dev())
+    acts[1] = {k: (v[:2] if k != "idx_stop" else v) for k, v in acts[1].items()}
+    acts[1]["idx_stop"] = torch.zeros(2, dtype=torch.int64, device=dev())
     got = {}
     for mode in (0, 1):
         den = UNetDenoiser2D(state_dict=hot, conv_mode=mode)
@@ -261,8 +263,10 @@ def test_env_step_redoes_a_tripped_step_in_exact_fp32(unet_params):
         rows = []
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
-            for a in acts:
-                ob, _, reward, _, _ = env.step(a)
+            for i, a in enumerate(acts):
+                ob, ob_masked, reward, _, info = env.step(a)
+                assert ob.variables.shape[0] == reward.shape[0] == info["done"].shape[0] == (3, 2)[i]
+                assert ob_masked.variables.shape[0] == 2
                 rows.append((ob.variables.clone(), reward.clone()))
         got[mode] = (rows, env.range_redone_steps, [str(x.message) for x in w], den.context(dev()).get_option("conv_mode"))
     assert got[0][1] == 0 and got[1][1] == 1                 # the first hot step tripped, was redone; the second ran exact

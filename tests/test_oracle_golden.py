@@ -311,3 +311,28 @@ def test_drunet_spi_admm():
         for i in range(sg.shape[1]):
             v = O.spi_admm(den, v, x0, t(d["K"]), t(sg[:, i:i + 1]), t(m[:, i:i + 1]))
             assert rel(v, g[f"admm_step{i + 1}"]) < 5e-6
+
+
+@pytest.mark.parametrize("name", ["hqs", "pg", "apg", "redadmm", "pr", "spi", "drunet"])
+def test_kinkfree_gradient_cases(unet_params, name):
+    """tests/golden/solver_grads_kinkfree.npz (the REAL reference's autograd; oracle/make_goldens.py::kinkfree_gradient_goldens):
+    (i) the frozen case really keeps every non-smooth decision >= KINK_MARGIN from its kink over the fp64 oracle trajectory,
+    (ii) the fp32 oracle's autograd reproduces the reference's gradients -- which pins the oracle as a gradient checker too."""
+    from tests.golden_inputs import KINK_MARGIN, KINKFREE_KEYS, kinkfree_case, kinkfree_margin, kinkfree_oracle_run
+    g = golden("solver_grads_kinkfree")
+    c = kinkfree_case(name)
+    dru = name == "drunet"
+    params = synth.make_drunet_params(0) if dru else unet_params
+    mk = O.DRUNetDenoiser if dru else O.Denoiser
+    assert kinkfree_margin(name, c, mk(params, torch.float64)) > KINK_MARGIN
+    leaves = [t(c["v0"]).requires_grad_(True)] + [t(p).requires_grad_(True) for p in c["acts"]]
+    out = kinkfree_oracle_run(name, c, torch.float32, mk(params))(*leaves)
+    (out * t(c["wts"])).sum().backward()
+    assert rel(out, g[f"{name}_out"]) < TOL
+    for key, leaf in zip(("variables",) + KINKFREE_KEYS[name], leaves):
+        want = g[f"{name}_grad_{key}"]
+        got = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
+        if float(np.abs(want).max()) == 0.0:
+            assert float(got.abs().max()) == 0.0, key
+        else:
+            assert rel(got, want) < 1e-4, (key, rel(got, want))

@@ -53,8 +53,22 @@ static void unet_layers(LayerSpec out[27]) {
     for (int j = 0; j < 3; ++j) out[3 * b + j] = LayerSpec{j == 0 ? blocks[b][0] : blocks[b][1], blocks[b][1]};
 }
 
+// DRUNet contexts never switch kernel family: the bias-free ReLU network is positively homogeneous, so a tripped guard is
+// answered by running on inputs scaled down by another factor 16 (DruNet::shift, drunet.hip) -- exact up to f16 subnormals.
+static void drunet_rescale(pnpx_ctx* ctx) {
+  if (ctx->drunet.shift < 16) ctx->drunet.shift += 4;
+  *ctx->range_flag_host = 0;
+}
+
 void range_guard_enter(pnpx_ctx* ctx) {
   if (!ctx->opt_range_guard || !ctx->range_flag_host) return;
+  if (ctx->drunet.loaded) {
+    if (*static_cast<volatile unsigned*>(ctx->range_flag_host) != 0) {
+      ctx->range_tripped = true;      // an EARLIER call overflowed: its output was invalid (pnpx_ctx_status reports it)
+      drunet_rescale(ctx);            // every later call runs 16x further inside the range
+    }
+    return;
+  }
   if (*static_cast<volatile unsigned*>(ctx->range_flag_host) != 0 && !ctx->range_tripped) {
     ctx->range_tripped = true;        // an EARLIER call overflowed: its output was invalid (pnpx_ctx_status reports it)
     ctx->conv_mode = CONV_F32;        // every later call is exact
@@ -64,6 +78,13 @@ void range_guard_enter(pnpx_ctx* ctx) {
 int range_guard_strict(pnpx_ctx* ctx, hipStream_t s, bool* rerun) {
   *rerun = false;
   PNPX_HIP(hipStreamSynchronize(s));
+  if (ctx->drunet.loaded) {
+    if (*static_cast<volatile unsigned*>(ctx->range_flag_host) != 0 && ctx->drunet.shift < 16) {
+      drunet_rescale(ctx);            // this call is repeated 16x further inside the range before it returns
+      *rerun = true;
+    }
+    return PNPX_OK;
+  }
   if (*static_cast<volatile unsigned*>(ctx->range_flag_host) != 0 && !ctx->range_tripped) {
     ctx->conv_mode = CONV_F32;        // this call is repeated in exact fp32 before it returns: nothing invalid escapes
     *ctx->range_flag_host = 0;
@@ -182,6 +203,10 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->conv_mode = value;
     return PNPX_OK;
   }
+  if (is("drunet_shift") && value >= 0 && value <= 16 && (value & 3) == 0) {   // DRUNet passes run on inputs scaled by 2^-value
+    ctx->drunet.shift = value;                                                 // (raised by 4 whenever the range guard trips)
+    return PNPX_OK;
+  }
   if (is("subbatch") && value >= 0) {
     ctx->opt_subbatch = value;
     return PNPX_OK;
@@ -260,6 +285,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
     return PNPX_ERR_ARG;
   }
   if (is("conv_mode")) *value = ctx->conv_mode;
+  else if (is("drunet_shift")) *value = ctx->drunet.shift;
   else if (is("subbatch")) *value = ctx->opt_subbatch;
   else if (is("fuse_pool")) *value = ctx->opt_fuse_pool;
   else if (is("fuse_outc")) *value = ctx->opt_fuse_outc;
@@ -284,6 +310,12 @@ int pnpx_ctx_status(pnpx_ctx* ctx) {
   LOCK_CTX(ctx);
   range_guard_enter(ctx);
   if (ctx->range_tripped) {
+    if (ctx->drunet.loaded)
+      set_error("half-split range guard tripped: an activation of an earlier DRUNet call left the f16 hi/lo range (|v| >= 4095 "
+                "or NaN); that call's output is invalid.  The context now runs its passes on inputs scaled by 2^-%d (the "
+                "bias-free network is positively homogeneous; the tail multiplies back); acknowledge with "
+                "pnpx_ctx_set_option(ctx, \"range_guard\", 1)", ctx->drunet.shift);
+    else
     set_error("half-split range guard tripped: an activation of an earlier call left the f16 hi/lo range (|v| >= 4095 or "
               "NaN); that call's output is invalid.  The context now runs conv_mode 0 (exact fp32 MFMA); re-arm with "
               "pnpx_ctx_set_option(ctx, \"range_guard\", 1)");
@@ -295,7 +327,7 @@ int pnpx_ctx_status(pnpx_ctx* ctx) {
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
   if (!ctx) return 0;
   size_t n = ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_grad.buf.bytes + ctx->scratch.bytes +
-             ctx->drunet.weights.bytes + ctx->drunet.arena.bytes;
+             ctx->drunet.weights.bytes + ctx->drunet.arena.bytes + ctx->drunet.arena_grad.bytes;
   for (const auto& sl : ctx->train_ring) n += sl.arena.buf.bytes + sl.pre.bytes;
   return n;
 }

@@ -121,9 +121,22 @@ struct DruNet {
   std::vector<int> taps;           // per layer: 3x3 tap mask its weights are packed with (0x010 for the 1x1 layers)
   const float* head_w = nullptr;   // [64][2][3][3] native (VALU head convolution)
   const float* zero = nullptr;     // [1024] zeros: the bias operand of the bias-free network
-  const float* e0 = nullptr;       // [32] = (1, 0, ...): channel selector of the fused tail epilogue, followed by zeros
-  DeviceBuf weights, arena;
+  const float* e0 = nullptr;       // [5][32]: row k = (2^(4k), 0, ...): channel selector of the fused tail epilogue that also undoes a
+                                   // 2^-(4k) down-scaling of the pass (shift, below); followed by zeros
+  // Range handling.  The network is bias-free with ReLU activations only, i.e. positively homogeneous: f(a * in) = a * f(in) for
+  // a > 0, and a power-of-two `a` commutes exactly with every step (the hi/lo split included, subnormals aside).  When the
+  // half-split range guard trips (an activation left |v| < 4095) the pass is repeated / later passes run on inputs scaled by
+  // 2^-shift (in the head convolution's store) with the tail multiplying back -- the DRUNet's counterpart of the UNet's
+  // exact-fp32 fallback.  0, 4, 8, 12 or 16.
+  int shift = 0;
+  // adjoint (input-gradient) layers, index-parallel to `layers` (transposed, tap-flipped; the head's adjoint is a 64 -> 32
+  // launch whose channels 0 / 1 are the image / noise-map gradients; the tail's adjoint runs on the vector ALU)
+  std::vector<ConvLayerHsDev> layers_bwd;
+  const float* tail_bwd_w = nullptr;   // [64][2][3][3]: conv_first_hs_kernel weights of the tail's adjoint (1 -> 64 channels)
+  DeviceBuf weights, arena, arena_grad;
   int capB = 0, capH = 0, capW = 0;
+  bool arena_keeps = false;            // the arena has room for every ResBlock's middle activation (backward pass)
+  int gcapB = 0, gcapH = 0, gcapW = 0;
 };
 
 }  // namespace pnpx
@@ -215,10 +228,13 @@ template <class F>
 int guarded(pnpx_ctx* ctx, hipStream_t s, F&& body) {
   range_guard_enter(ctx);
   int st = body();
-  if (st == PNPX_OK && ctx->opt_range_guard == 2 && ctx->conv_mode == CONV_HS) {
+  // strict mode: the UNet repeats the call once in exact fp32; a DRUNet context repeats it on inputs scaled down by another
+  // factor 16 per attempt (api.hip::range_guard_strict) until the guard stays quiet
+  for (int attempt = 0; attempt < 4 && st == PNPX_OK && ctx->opt_range_guard == 2 && ctx->conv_mode == CONV_HS; ++attempt) {
     bool rerun = false;
     PNPX_TRY(range_guard_strict(ctx, s, &rerun));
-    if (rerun) st = body();
+    if (!rerun) break;
+    st = body();
   }
   return st;
 }
@@ -256,7 +272,10 @@ int unet_denoise_backward_ticket(pnpx_ctx* ctx, const float* x, const float* sig
 size_t drunet_num_params(int nb);
 int drunet_load(pnpx_ctx* ctx, const float* params, size_t n, int nb);
 int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre, int B,
-                   int H, int W, hipStream_t s);
+                   int H, int W, hipStream_t s, bool keep_mids = false);
+// VJP wrt x and sigma: forward re-computed keeping every ResBlock's ReLU output, then the adjoint chain on the same kernels
+int drunet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out,
+                            float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s);
 void drunet_free(pnpx_ctx* ctx);
 
 // Policy actor (policy.hip)

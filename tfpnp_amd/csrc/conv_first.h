@@ -13,7 +13,7 @@ namespace pnpx {
 static __global__ __launch_bounds__(256) void conv_first_hs_kernel(const float* __restrict__ x, const float* __restrict__ sigma,
                                                             int sigma_stride, const float* __restrict__ w,
                                                             const float* __restrict__ bias, HsRec* __restrict__ dst, int H,
-                                                            int W, float slope) {
+                                                            int W, float slope, float oscale) {   // oscale: HS_ASCALE, or HS_ASCALE * 2^-k for a down-scaled pass (drunet.hip)
   const int g = blockIdx.y, b = blockIdx.z;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= H * W) return;
@@ -37,7 +37,7 @@ static __global__ __launch_bounds__(256) void conv_first_hs_kernel(const float* 
     for (int t = 0; t < 9; ++t) acc = fmaf(wc[t], xi[t], acc);
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc = fmaf(wc[9 + t], si[t], acc);
-    v[c] = fmaxf(acc, acc * slope) * HS_ASCALE;
+    v[c] = fmaxf(acc, acc * slope) * oscale;
   }
   dst[((size_t)(b * gridDim.y + g) * (H + 2) + (y + 1)) * (W + 2) + xx + 1] = hs_pack(v);   // gridDim.y = cout / 8
 }

@@ -310,6 +310,8 @@ static pnpx_ctx::TrainSlot* train_slot_acquire(pnpx_ctx* ctx, int B, int H, int 
 int unet_denoise_train(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, int B, int H,
                        int W, hipStream_t s, unsigned long long* ticket) {
   *ticket = 0;
+  if (ctx->drunet.loaded)     // DRUNet: no activation ring; ticket 0 = its VJP re-computes the forward (drunet_denoise_backward)
+    return unet_denoise(ctx, x, sigma, sigma_stride, out, nullptr, B, H, W, s, nullptr);
   if (pnpx_ctx::TrainSlot* sl = train_slot_acquire(ctx, B, H, W)) {
     const int st = unet_denoise(ctx, x, sigma, sigma_stride, out, static_cast<float*>(sl->pre.p), B, H, W, s, nullptr,
                                 &sl->arena, ctx->conv_mode, true);
@@ -452,7 +454,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
     } else if (li == 0 && first_fused) {
       hipLaunchKernelGGL(conv_first_hs_kernel, dim3((H * W + 255) / 256, 4, nb), dim3(256), 0, s, x + (size_t)b0 * H * W,
                          sigma + (size_t)b0 * sigma_stride, sigma_stride, ctx->conv0_w, ctx->conv[0].b, rat(ta, b0), H, W,
-                         0.2f);
+                         0.2f, HS_ASCALE);
       PNPX_LAUNCH_CHECK();
       PNPX_TRY(rec.mark("conv3x3", 2.0 * 9.0 * 2 * 32 * (double)H * W * nb));
     } else
@@ -558,9 +560,9 @@ int launch_chains(const pnpx_ctx* ctx, int B, int H, int W) {
 
 int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
                  int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena, int mode, bool keep_all) {
-  if (ctx->drunet.loaded) {   // the context's denoiser is a DRUNet (drunet.hip): inference only
+  if (ctx->drunet.loaded) {   // the context's denoiser is a DRUNet (drunet.hip)
     if (arena || keep_all || prof) {
-      set_error("the DRUNet denoiser has no training path / per-launch profile (forward only)");
+      set_error("the DRUNet denoiser keeps its activations in its own arena (drunet_denoise_backward re-computes them) and has no per-launch profile");
       return PNPX_ERR_ARG;
     }
     return drunet_denoise(ctx, x, sigma, sigma_stride, out, out_pre, B, H, W, s);

@@ -15,6 +15,7 @@
 #include "conv_hs.h"
 #include "hs_rec.h"
 #include "unet_plan.h"
+#include "grad_common.h"
 
 namespace pnpx {
 namespace {
@@ -149,7 +150,6 @@ __global__ __launch_bounds__(256) void skip_pool_merge_kernel(const float* __res
 }
 
 // gx = g_in0[:, 0] + g_res;  gsigma[b] = sum over pixels of g_in0[:, 1]   (two-stage, deterministic)
-constexpr int SIG_CHUNKS = 64;
 __global__ __launch_bounds__(256) void input_grad_kernel(const float* __restrict__ g_in0, int Cg,
                                                          const float* __restrict__ g_res, float* __restrict__ gx,
                                                          float* __restrict__ part, int H, int W) {
@@ -172,13 +172,6 @@ __global__ __launch_bounds__(256) void input_grad_kernel(const float* __restrict
   __syncthreads();
   if (threadIdx.x == 0) part[b * SIG_CHUNKS + chunk] = (w[0] + w[1]) + (w[2] + w[3]);
 }
-__global__ void sigma_grad_final_kernel(const float* __restrict__ part, float* __restrict__ gsigma, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  float s = 0.f;
-  for (int c = 0; c < SIG_CHUNKS; ++c) s += part[b * SIG_CHUNKS + c];
-  gsigma[b] = s;
-}
 
 
 // ------------------------------------------------------------------------------------ half-split (HS8) variants
@@ -186,24 +179,6 @@ __global__ void sigma_grad_final_kernel(const float* __restrict__ part, float* _
 // (conv_hs.hip, LeakyReLU' from the saved activation's sign in its epilogue).  f16 has a narrow exponent range, so the
 // whole backward pass runs on grad_out / m with m = the power of two >= max|grad_out| and the two results are
 // multiplied by m at the end (exact: power-of-two scaling commutes with every linear step).  One thread per record.
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, size_t n, unsigned* __restrict__ bits) {
-  float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(g[i]));
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(bits, __float_as_uint(m));   // non-negative floats order like their bits
-}
-__global__ void grad_scale_kernel(const unsigned* __restrict__ bits, float2* __restrict__ sc) {
-  const float m = __uint_as_float(*bits);
-  if (!(m > 0.f) || !isfinite(m)) {
-    *sc = make_float2(m > 0.f ? 1.f : 0.f, m > 0.f ? 1.f : 0.f);   // all-zero gradient -> zeros; inf/nan -> pass through
-    return;
-  }
-  int e;
-  (void)frexpf(m, &e);                    // m = f * 2^e, f in [0.5, 1)
-  *sc = make_float2(ldexpf(1.f, -e), ldexpf(1.f, e));
-}
-
 __global__ __launch_bounds__(256) void outc_bwd_hs_kernel(const float* __restrict__ g_out, const float* __restrict__ pre,
                                                           const float* __restrict__ w, const HsRec* __restrict__ feat,
                                                           HsRec* __restrict__ g_feat, float* __restrict__ g_res,
@@ -353,29 +328,6 @@ __global__ __launch_bounds__(256) void skip_pool_merge_hs_kernel(const HsRec* __
   g_x[r] = hs_pack(gv);
 }
 
-__global__ __launch_bounds__(256) void input_grad_hs_kernel(const HsRec* __restrict__ g_in0, const float* __restrict__ g_res,
-                                                            float* __restrict__ gx, float* __restrict__ part,
-                                                            const float2* __restrict__ sc, int H, int W) {
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int n = H * W, per = (n + SIG_CHUNKS - 1) / SIG_CHUNKS;
-  const int lo = chunk * per, hi = min(n, lo + per);
-  const HsRec* g0 = g_in0 + (size_t)b * 4 * (H + 2) * (W + 2);     // group 0 of 4: channels 0 (image) and 1 (noise map)
-  const float m = sc->y, inv = 1.f / HS_ASCALE;
-  float acc = 0.f;
-  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const int y = i / W, x = i - y * W;
-    float v[8];
-    hs_unpack(g0[(size_t)(y + 1) * (W + 2) + x + 1], v);
-    gx[(size_t)b * n + i] = (v[0] * inv + g_res[(size_t)b * n + i]) * m;
-    acc += v[1] * inv;
-  }
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  __shared__ float w[4];
-  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) part[b * SIG_CHUNKS + chunk] = ((w[0] + w[1]) + (w[2] + w[3])) * m;
-}
-
 // gradient arena: one tensor per forward activation + the concat gradients of the four decoder blocks
 struct GradPlan {
   Act in0;        // 32 channels (the adjoint of the first conv is padded from 2 to 32 output channels)
@@ -415,8 +367,11 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
                           float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s, UNetArena* cached,
                           const float* cached_pre) {
   if (ctx->drunet.loaded) {
-    set_error("the DRUNet denoiser has no VJP (forward only)");
-    return PNPX_ERR_ARG;
+    if (B <= 0 || !grad_out || !grad_x || !grad_sigma) {
+      set_error("denoiser backward: need B > 0 and non-null gradients");
+      return PNPX_ERR_ARG;
+    }
+    return drunet_denoise_backward(ctx, x, sigma, sigma_stride, grad_out, grad_x, grad_sigma, B, H, W, s);
   }
   if (!ctx->has_weights) {
     set_error("denoiser backward called before pnpx_unet_load");

@@ -17,6 +17,8 @@ observation and how they are packed for the policy; here that is data (class att
 import numpy as np
 import torch
 
+from .._lib import PnpxError
+
 from .. import ops
 from ..data.batch import Batch
 from ..utils import transforms
@@ -117,10 +119,13 @@ class PnPEnv:
         nxt.update(variables=solver_state, T=ob.T + 1 / self.max_episode_step)
         return nxt
 
-    def _observation(self):
-        """Batch of the live rows: gt, variables, T and the task's ob_keys (bool entries listed in float_keys as float)."""
+    def _observation(self, rows=None, n=None):
+        """Batch of the live rows (default: the currently live ones): gt, variables, T and the task's ob_keys (bool entries
+        listed in float_keys as float)."""
         names = ('gt', 'solver', 'T') + tuple(self.ob_keys)
-        got = _take_rows([self.state[k] for k in names], self._rows, self._n_live)
+        if rows is None:
+            rows, n = self._rows, self._n_live
+        got = _take_rows([self.state[k] for k in names], rows, n)
         ob = Batch()
         for k, v in zip(names, got):
             ob['variables' if k == 'solver' else k] = v.float() if k in self.float_keys else v
@@ -173,7 +178,8 @@ class PnPEnv:
                 st['T'].fill_(self.cur_step / self.max_episode_step)
                 _put_rows([self.solver.get_output(solver_state), solver_state], [st['output'], st['solver']], rows, n)
                 self.last_metric = prev_metric
-                return self._compute_reward(), self._observation()   # observation: rows that were live during this step
+                # observation: the rows that were live DURING this step (also when the step is repeated after the compaction)
+                return self._compute_reward(), self._observation(rows, n)
 
             reward, ob = advance()
             idx_stop = action['idx_stop']
@@ -185,11 +191,31 @@ class PnPEnv:
             ctx = self._native_context(rows) if n else None
             if ctx is not None and ctx.get_option('conv_mode') == 1 and ctx.range_tripped():
                 import warnings
-                warnings.warn('half-split range guard tripped in PnPEnv.step: the step was repeated with the exact-fp32 '
-                              'convolutions and the denoiser context stays in conv_mode 0 (re-arm with '
-                              "context.set_option('range_guard', 1) + set_option('conv_mode', 1))")
                 self.range_redone_steps += 1
-                reward, ob = advance()
+                if getattr(ctx, 'is_drunet', False):
+                    # DRUNet: no fp32 family; the tripped guard has moved the context's passes 16x further inside the range
+                    # (positively homogeneous network, csrc/drunet.hip).  Repeat until a pass stays in range.
+                    guard = ctx.get_option('range_guard')
+                    for _ in range(4):
+                        ctx.set_option('range_guard', guard)           # acknowledge (synchronises); the raised shift stays
+                        reward, ob = advance()
+                        torch.cuda.synchronize(rows.device)
+                        if not ctx.range_tripped():
+                            break
+                    else:      # still out of range at the largest shift: put the rows back and fail loudly
+                        _put_rows([self.solver.get_output(live[0]), live[0]], [st['output'], st['solver']], rows, n)
+                        self.last_metric = prev_metric
+                        self._rows, self._n_live = rows, n
+                        self.cur_step -= 1
+                        raise PnpxError('half-split range guard: DRUNet activations exceed the f16 hi/lo range even on inputs '
+                                        'scaled by 2^-16; the step was rolled back')
+                    warnings.warn('half-split range guard tripped in PnPEnv.step: the step was repeated on down-scaled inputs '
+                                  f"(DRUNet context, drunet_shift = {ctx.get_option('drunet_shift')})")
+                else:
+                    warnings.warn('half-split range guard tripped in PnPEnv.step: the step was repeated with the exact-fp32 '
+                                  'convolutions and the denoiser context stays in conv_mode 0 (re-arm with '
+                                  "context.set_option('range_guard', 1) + set_option('conv_mode', 1))")
+                    reward, ob = advance()
             done = idx_stop.detach()
             all_done = self._n_live == 0
             if self.cur_step == self.max_episode_step:

@@ -39,6 +39,7 @@ class Context:
         check(_lib.lib().pnpx_ctx_create(self.device.index, C.byref(h)))
         self._h = h
         self._has_weights = False
+        self.is_drunet = False
         self._policy = None
         self.cid = next(_ctx_ids)          # integer handle for the dispatcher-registered ops (torch_ops.py)
         _ctx_by_id[self.cid] = self
@@ -64,6 +65,7 @@ class Context:
         flat = np.concatenate(chunks)
         check(_lib.lib().pnpx_unet_load(self.handle, flat.ctypes.data_as(C.c_void_p), flat.size))
         self._has_weights = True
+        self.is_drunet = False
 
     def load_drunet(self, state_dict, nb=4):
         """state_dict with KAIR's UNetRes / DRUNet key names (synth.drunet_param_specs) -> the context's denoiser."""
@@ -80,6 +82,7 @@ class Context:
         flat = np.concatenate(chunks)
         check(_lib.lib().pnpx_drunet_load(self.handle, flat.ctypes.data_as(C.c_void_p), flat.size, int(nb)))
         self._has_weights = True
+        self.is_drunet = True
 
     def load_policy(self, state_dict, num_inputs, n_det, spi_head=False):
         """state_dict with the reference's ResNetActor_* key names (tfpnp/policy/network.py) -> native actor."""

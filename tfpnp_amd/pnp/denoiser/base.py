@@ -68,7 +68,8 @@ class DRUNetDenoiser2D(UNetDenoiser2D):
     clamp(DRUNet(cat[x, sigma*1]), 0, 1)`.  The reference ships only the building blocks
     (tfpnp/pnp/denoiser/models/basicblock.py:61-101,211-227,413-419,437-446) and no checkpoint: a state_dict with KAIR's
     key names (`m_head.weight`, `m_down1.0.res.0.weight`, ... -- what drunet_gray.pth holds) or a path to one is required.
-    H and W must be multiples of 8.  Forward only (no VJP): calling it under autograd raises."""
+    H and W must be multiples of 8.  Under autograd the registered VJP re-computes the forward natively keeping every
+    ResBlock's ReLU output and back-propagates on the same kernels (csrc/drunet.hip::drunet_denoise_backward)."""
 
     def __init__(self, ckpt_path=None, state_dict=None, nb=4):
         torch.nn.Module.__init__(self)
@@ -94,6 +95,5 @@ class DRUNetDenoiser2D(UNetDenoiser2D):
         return self._ctx[idx]
 
     def forward(self, x, sigma):
-        if torch.is_grad_enabled() and (x.requires_grad or sigma.requires_grad):
-            raise NotImplementedError('DRUNetDenoiser2D is forward-only (no native VJP); run it under torch.no_grad()')
+        # no activation ring for the DRUNet: the op's registered autograd formula is the re-computing native VJP
         return T.call("unet_denoise", x, sigma, self.context(x.device).cid)
