@@ -346,7 +346,7 @@ int pnpx_ct_iadmm_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float*
 int pnpx_ct_pg(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view,
                float opnorm, const float* sigma_d, const float* tau, int param_stride, int B, int R, int T,
                void* stream);
-/* Training path of PGSolver_CT.forward: `saved` = 2*T*B*R*R floats; grads wrt (x, sigma_d, tau); work = 3*B*R*R + 2*n_view
+/* Training path of PGSolver_CT.forward: `saved` = 2*T*B*R*R floats; grads wrt (x, sigma_d, tau); work = 3*B*R*R + 1 + 2*n_view
  * floats. */
 int pnpx_ct_pg_train(pnpx_ctx* ctx, const float* vars_in, float* vars_out, const float* y0, int n_view, float opnorm,
                      const float* sigma_d, const float* tau, int param_stride, int B, int R, int T, float* saved,

@@ -13,6 +13,9 @@ from tfpnp_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+from tests import composed_solvers   # the reference's loops from differentiable ops (test infrastructure)
+composed_solvers.install()
+
 
 def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))

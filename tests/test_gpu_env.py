@@ -9,6 +9,9 @@ from tfpnp_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+from tests import composed_solvers   # the reference's loops from differentiable ops (test infrastructure)
+composed_solvers.install()
+
 
 def dev():
     return torch.device("cuda:0")

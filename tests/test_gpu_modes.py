@@ -265,8 +265,9 @@ def test_env_step_redoes_a_tripped_step_in_exact_fp32(unet_params):
             warnings.simplefilter("always")
             for i, a in enumerate(acts):
                 ob, ob_masked, reward, _, info = env.step(a)
-                assert ob.variables.shape[0] == reward.shape[0] == info["done"].shape[0] == (3, 2)[i]
-                assert ob_masked.variables.shape[0] == 2
+                # ob: the rows live DURING the step (= the action batch); reward: every item of the batch (reference: whole state)
+                assert ob.variables.shape[0] == info["done"].shape[0] == a["sigma_d"].shape[0] == (3, 2)[i]
+                assert reward.shape[0] == 3 and ob_masked.variables.shape[0] == 2
                 rows.append((ob.variables.clone(), reward.clone()))
         got[mode] = (rows, env.range_redone_steps, [str(x.message) for x in w], den.context(dev()).get_option("conv_mode"))
     assert got[0][1] == 0 and got[1][1] == 1                 # the first hot step tripped, was redone; the second ran exact

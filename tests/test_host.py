@@ -116,3 +116,29 @@ def test_shard_bounds():
         assert max(sizes) - min(sizes) <= 1
     d = shard_batch({"a": np.arange(10), "b": torch.arange(10)}, 3, 1)
     assert list(d["a"]) == [4, 5, 6] and d["b"].tolist() == [4, 5, 6]
+
+
+def test_fused_solvers_refuse_foreign_denoisers_and_prox_overrides_clearly():
+    """every solver forward is one fused native call that applies the native denoiser itself.  A denoiser without
+    a native context, or a subclass overriding prox_mapping (which the fused loop could only ignore), gets a clear
+    NotImplementedError naming the way out -- not an opaque native error, not a silently skipped override."""
+    import pytest
+    import torch
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI, PGSolver_CSMRI
+
+    class Plain(torch.nn.Module):
+        def forward(self, x, sigma):
+            return x
+
+    v = torch.zeros(1, 3, 8, 8, 2)
+    aux = (torch.zeros(1, 1, 8, 8, 2), torch.ones(1, 1, 8, 8, dtype=torch.bool))
+    par = (torch.full((1, 2), 0.1), torch.full((1, 2), 0.5))
+    with pytest.raises(NotImplementedError, match="native denoiser"):
+        ADMMSolver_CSMRI(Plain())((v, aux), par)
+
+    class Mine(PGSolver_CSMRI):
+        def prox_mapping(self, x, sigma):
+            return x * 0.5
+
+    with pytest.raises(NotImplementedError, match="overrides prox_mapping"):
+        Mine(Plain())((v[:, :1], aux), par)

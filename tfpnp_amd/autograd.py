@@ -1,12 +1,14 @@
-"""Differentiable wrappers of the native ops -- the training path of the reference.
+"""Differentiable wrappers of the native ops -- building blocks of the reference's training path.
 
 The reference trains its policy through the solver: PnPEnv.forward (tfpnp/env/base.py:193-206) runs
 solver.forward under autograd and back-propagates the critic's value / the PSNR reward into the policy's
-(sigma_d, mu, tau) outputs (tfpnp/trainer/mddpg/trainer.py:171-192).  The fused native solver loops are
-inference-only; when gradients are required the solvers in tfpnp_amd/tasks fall back to the reference's own
-iteration written with these differentiable building blocks:
-  * denoise(x, sigma)      native forward, native VJP (pnpx_unet_denoise_backward: re-computation + transposed
-                           MFMA convolutions), both dispatcher-registered ops (torch.ops.pnpx.*, torch_ops.py)
+(sigma_d, mu, tau) outputs (tfpnp/trainer/mddpg/trainer.py:171-192).  The solvers in tfpnp_amd/tasks do that with
+FUSED native training loops (pnpx_*_train keeps what its pnpx_*_backward needs; one call each way per solver call).
+This module is the other way to differentiate the path -- the same iteration composed step by step from ops that each
+carry a native VJP -- used by user code that changes an iteration, and by the tests as the independent check of the
+fused loops (tests/composed_solvers.py):
+  * denoise(x, sigma)      native forward, native VJP (pnpx_unet_denoise_backward: activations from the training ring or
+                           re-computed, transposed MFMA convolutions), dispatcher-registered ops (torch_ops.py)
   * fft2 / ifft2 / plain FFTs   native; the transforms are unitary, so the VJP is the inverse transform
   * radon forward / backprojection   native; each is the other's VJP (the unmatched pair torch_radon also uses)
 and ordinary PyTorch pointwise autograd for the O(N) glue (masks, blends, dual updates).

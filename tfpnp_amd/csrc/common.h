@@ -113,6 +113,9 @@ struct PolicyNet {
 
 // number of independent launch chains for a B-image denoiser forward (unet.hip; option "chains", 0 = automatic)
 int launch_chains(const pnpx_ctx* ctx, int B, int H, int W);
+// a launch-chain fan-out failed half way: drain the side streams before the error is returned, so that nothing queued on them
+// is still writing the shared arena / output buffers when the caller (or the next call) re-uses them
+void join_side_streams_after_failure(pnpx_ctx* ctx);
 // DRUNet denoiser (drunet.hip): packed weights per MFMA launch in state_dict order + its own activation arena
 struct DruNet {
   bool loaded = false;

@@ -451,8 +451,12 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
     const int lo = (int)((long long)B * c / chains), hi = (int)((long long)B * (c + 1) / chains);
     hipStream_t st = c ? ctx->side_streams[c - 1] : s;
     if (c) PNPX_HIP(hipStreamWaitEvent(st, ctx->side_fork, 0));
-    PNPX_TRY(run(lo, hi - lo, x + lo * px, sigma + (size_t)lo * sigma_stride, out + lo * px, out_pre ? out_pre + lo * px : nullptr,
-                 st));
+    const int rc = run(lo, hi - lo, x + lo * px, sigma + (size_t)lo * sigma_stride, out + lo * px, out_pre ? out_pre + lo * px : nullptr,
+                       st);
+    if (rc != PNPX_OK) {
+      join_side_streams_after_failure(ctx);
+      return rc;
+    }
     if (c) PNPX_HIP(hipEventRecord(ctx->side_joins[c - 1], st));
   }
   for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, ctx->side_joins[c - 1], 0));

@@ -748,7 +748,11 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
     const int lo = (int)((long long)B * c / chains), hi = (int)((long long)B * (c + 1) / chains);
     hipStream_t st = c ? ctx->side_streams[c - 1] : s;
     if (c) PNPX_HIP(hipStreamWaitEvent(st, ctx->side_fork, 0));
-    PNPX_TRY(run(lo, hi - lo, ob + (size_t)lo * N.num_inputs * H * W, probs + (size_t)lo * 2, det + (size_t)lo * N.n_det, st));
+    const int rc = run(lo, hi - lo, ob + (size_t)lo * N.num_inputs * H * W, probs + (size_t)lo * 2, det + (size_t)lo * N.n_det, st);
+    if (rc != PNPX_OK) {
+      join_side_streams_after_failure(ctx);
+      return rc;
+    }
     if (c) PNPX_HIP(hipEventRecord(ctx->side_joins[c - 1], st));
   }
   for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, ctx->side_joins[c - 1], 0));

@@ -1179,7 +1179,9 @@ int pnpx_ct_pg_backward(pnpx_ctx* ctx, int n_view, float opnorm, const float* si
     PNPX_HIP(hipMemcpyAsync(grad_vars_in, grad_vars_out, sizeof(float) * n, hipMemcpyDeviceToDevice, s));
     if (T == 0) return PNPX_OK;
     CtScratch C;
-    float2* cs_home = reinterpret_cast<float2*>(work + 3 * n);
+    // (cos, sin) table behind the three n-float buffers, at an EVEN float offset: 3 * n is odd for odd B * R * R and a float2
+    // array needs 8-byte alignment (work holds 3 * n + 1 + 2 * n_view floats)
+    float2* cs_home = reinterpret_cast<float2*>(work + ((3 * n + 1) & ~(size_t)1));
     PNPX_TRY(ct_scratch(ctx, B, R, n_view, 0, s, &C, cs_home, true));
     const float op2 = (float)((double)opnorm * (double)opnorm);
     float *gd = work, *J = work + n, *c_tau = work + 2 * n;

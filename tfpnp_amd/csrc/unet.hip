@@ -558,6 +558,10 @@ int launch_chains(const pnpx_ctx* ctx, int B, int H, int W) {
   return n > B ? B : (n < 1 ? 1 : n);
 }
 
+void join_side_streams_after_failure(pnpx_ctx* ctx) {
+  for (hipStream_t st : ctx->side_streams) (void)hipStreamSynchronize(st);
+}
+
 int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
                  int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena, int mode, bool keep_all) {
   if (ctx->drunet.loaded) {   // the context's denoiser is a DRUNet (drunet.hip)
@@ -605,8 +609,12 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
       hipStream_t st = c ? ctx->side_streams[c - 1] : s;
       if (c) PNPX_HIP(hipStreamWaitEvent(st, ctx->side_fork, 0));
       Recorder none{nullptr, st};
-      PNPX_TRY(unet_forward_hs(ctx, ar, P, x + lo * px, sigma + (size_t)lo * sigma_stride, sigma_stride, out + lo * px,
-                               out_pre ? out_pre + lo * px : nullptr, hi - lo, H, W, st, none, keep_all, lo));
+      const int rc = unet_forward_hs(ctx, ar, P, x + lo * px, sigma + (size_t)lo * sigma_stride, sigma_stride, out + lo * px,
+                                     out_pre ? out_pre + lo * px : nullptr, hi - lo, H, W, st, none, keep_all, lo);
+      if (rc != PNPX_OK) {
+        join_side_streams_after_failure(ctx);
+        return rc;
+      }
       if (c) PNPX_HIP(hipEventRecord(ctx->side_joins[c - 1], st));
     }
     for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, ctx->side_joins[c - 1], 0));

@@ -828,7 +828,7 @@ def ct_pg_backward(ctx, n_view, opnorm, sigma_d, tau, saved, grad_out, iter_num=
     gin = torch.empty_like(g)
     gs = _hyper_grads(T, B, 2, g.device)
     if B and T:
-        work = torch.empty(3 * B * R * R + 2 * int(n_view), dtype=torch.float32, device=g.device)
+        work = torch.empty(3 * B * R * R + 1 + 2 * int(n_view), dtype=torch.float32, device=g.device)   # +1: float2 table at an even offset
         with torch.cuda.device(g.device):
             check(_lib.lib().pnpx_ct_pg_backward(ctx.handle, int(n_view), float(opnorm), *[_p(p) for p in ps], ps[0].shape[1],
                                                  _p(saved), _p(g), _p(gin), *[_p(x) for x in gs], _p(work), B, R, T,

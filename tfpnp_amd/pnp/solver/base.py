@@ -64,7 +64,20 @@ class PnPSolver(nn.Module):
 
     # native context of the denoiser for the device the state lives on
     def _ctx(self, t):
-        return self.denoiser.context(t.device)
+        """The fused native loops (tfpnp_amd/tasks/*) run the denoiser prox INSIDE one libpnpx call, so they need a native
+        denoiser and cannot honour a Python override of prox_mapping: both cases fail here with a clear message instead of
+        an opaque native error (or a silently ignored override)."""
+        if type(self).prox_mapping is not PnPSolver.prox_mapping:
+            raise NotImplementedError(
+                f'{type(self).__name__} overrides prox_mapping(), but its forward() is one fused native call that applies the '
+                'native denoiser itself; compose the iteration from tfpnp_amd.autograd building blocks instead '
+                '(tests/composed_solvers.py shows every loop written that way)')
+        ctx_of = getattr(self.denoiser, 'context', None)
+        if ctx_of is None:
+            raise NotImplementedError(
+                f'{type(self).__name__} needs a native denoiser (tfpnp_amd.pnp.UNetDenoiser2D / DRUNetDenoiser2D); got '
+                f'{type(self.denoiser).__name__}, which has no native context')
+        return ctx_of(t.device)
 
 
 class ADMMSolver(PnPSolver):

@@ -4,22 +4,11 @@ solver(inputs, parameters, iter_num=None) with inputs = (variables, (y0, mask)),
 filter_hyperparameter(action); returns the next state tensor.  Each forward is ONE native call that runs all
 iter_num inner iterations (denoiser prox + masked-FFT data prox + dual update) on the caller's stream.
 """
-import torch
-
 from .. import autograd as A
 from .. import torch_ops as T
 from ..env.base import PnPEnv
 from ..pnp.solver.base import ADMMSolver, HQSSolver, PGSolver, APGSolver, REDADMMSolver, AMPSolver
 from ..utils import transforms
-
-
-def _v5(t, B):
-    return t.reshape(B, 1, 1, 1, 1)
-
-
-def _blend(k, y0, m, mu):
-    """k[mask] = ((mu*k) + y0)[mask] / (1 + mu)   (tasks/csmri/solver.py:49-51) without in-place writes."""
-    return torch.where(m, (mu * k + y0) / (1 + mu), k)
 
 
 class CSMRIMixin:
@@ -43,19 +32,6 @@ class ADMMSolver_CSMRI(CSMRIMixin, ADMMSolver):
                           self._ctx(variables).cid)[0]
         return T.call("csmri_admm", variables, y0, mask, sigma_d, mu, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
-    def _forward_autograd(self, variables, y0, mask, sigma_d, mu, iter_num):
-        """The reference's loop (tasks/csmri/solver.py:43-55) from differentiable building blocks: the composition the
-        fused native VJP (pnpx_csmri_admm_backward) is tested against; the other solvers' training paths look like this."""
-        x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
-        B = x.shape[0]
-        m = (mask != 0).unsqueeze(-1)
-        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
-            x = A.r2c(self.prox_mapping(A.c2r(z - u), sigma_d[:, i]))
-            z = A.fft2(_blend(A.fft2(x + u), y0, m, _v5(mu[:, i], B)), inverse=True)
-            u = u + x - z
-        return torch.cat((x, z, u), dim=1)
-
-
 class HQSSolver_CSMRI(CSMRIMixin, HQSSolver):
     """tasks/csmri/solver.py:60-89"""
 
@@ -66,18 +42,6 @@ class HQSSolver_CSMRI(CSMRIMixin, HQSSolver):
             return T.call("csmri_hqs_train", variables, y0, mask, sigma_d, mu, -1 if iter_num is None else iter_num,
                           self._ctx(variables).cid)[0]
         return T.call("csmri_hqs", variables, y0, mask, sigma_d, mu, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
-
-
-    def _forward_autograd(self, variables, y0, mask, sigma_d, mu, iter_num):
-        """The reference's loop (tasks/csmri/solver.py:76-85) from differentiable building blocks: what the fused native VJP
-        (pnpx_csmri_hqs_backward) is tested against."""
-        x, z = torch.split(variables, variables.shape[1] // 2, dim=1)
-        B, m = x.shape[0], (mask != 0).unsqueeze(-1)
-        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
-            x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
-            z = A.fft2(_blend(A.fft2(x), y0, m, _v5(mu[:, i], B)), inverse=True)
-        return torch.cat([x, z], dim=1)
-
 
 class PGSolver_CSMRI(CSMRIMixin, PGSolver):
     """tasks/csmri/solver.py:92-120"""
@@ -90,18 +54,6 @@ class PGSolver_CSMRI(CSMRIMixin, PGSolver):
                           self._ctx(variables).cid)[0]
         return T.call("csmri_pg", variables, y0, mask, sigma_d, tau, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
-
-    def _forward_autograd(self, variables, y0, mask, sigma_d, tau, iter_num):
-        """The reference's loop (tasks/csmri/solver.py:107-116) from differentiable building blocks: what the fused native
-        VJP (pnpx_csmri_pg_backward) is tested against."""
-        x, B, m = variables, variables.shape[0], (mask != 0).unsqueeze(-1)
-        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
-            temp = torch.where(m, A.fft2(x) - y0, torch.zeros_like(y0))
-            z = x - _v5(tau[:, i], B) * A.fft2(temp, inverse=True)
-            x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
-        return x
-
-
 class APGSolver_CSMRI(CSMRIMixin, APGSolver):
     """tasks/csmri/solver.py:123-165"""
 
@@ -113,21 +65,6 @@ class APGSolver_CSMRI(CSMRIMixin, APGSolver):
                           self._ctx(variables).cid)[0]
         return T.call("csmri_apg", variables, y0, mask, sigma_d, tau, beta, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
-
-    def _forward_autograd(self, variables, y0, mask, sigma_d, tau, beta, iter_num):
-        """The reference's loop (tasks/csmri/solver.py:141-159) from differentiable building blocks: what the fused native VJP
-        (pnpx_csmri_apg_backward) is tested against."""
-        x, s = torch.split(variables, variables.shape[1] // 2, dim=1)
-        B, m = x.shape[0], (mask != 0).unsqueeze(-1)
-        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
-            temp = torch.where(m, A.fft2(s) - y0, torch.zeros_like(y0))
-            z = s - _v5(tau[:, i], B) * A.fft2(temp, inverse=True)
-            x_prev = x
-            x = A.r2c(self.prox_mapping(A.c2r(z), sigma_d[:, i]))
-            s = x + _v5(beta[:, i], B) * (x - x_prev)
-        return torch.cat([x, s], dim=1)
-
-
 class REDADMMSolver_CSMRI(CSMRIMixin, REDADMMSolver):
     """tasks/csmri/solver.py:168-204"""
 
@@ -138,21 +75,6 @@ class REDADMMSolver_CSMRI(CSMRIMixin, REDADMMSolver):
             return T.call("csmri_redadmm_train", variables, y0, mask, sigma_d, mu, lamda,
                           -1 if iter_num is None else iter_num, self._ctx(variables).cid)[0]
         return T.call("csmri_redadmm", variables, y0, mask, sigma_d, mu, lamda, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
-
-
-    def _forward_autograd(self, variables, y0, mask, sigma_d, mu, lamda, iter_num):
-        """The reference's loop (tasks/csmri/solver.py:183-200) from differentiable building blocks: what the fused native VJP
-        (pnpx_csmri_redadmm_backward) is tested against."""
-        x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
-        B, m = x.shape[0], (mask != 0).unsqueeze(-1)
-        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
-            _mu, _la = _v5(mu[:, i], B), _v5(lamda[:, i], B)
-            x_half = A.r2c(self.prox_mapping(A.c2r(x), sigma_d[:, i]))
-            x = (_la * x_half + _mu * (z - u)) / (_mu + _la)
-            z = A.fft2(_blend(A.fft2(x + u), y0, m, _mu), inverse=True)
-            u = u + x - z
-        return torch.cat([x, z, u], dim=1)
-
 
 class AMPSolver_CSMRI(CSMRIMixin, AMPSolver):
     """tasks/csmri/solver.py:207-250: broken in the reference (undefined self.prox_fun at :238)."""

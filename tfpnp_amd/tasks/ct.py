@@ -36,23 +36,6 @@ class IADMMSolver_CT(CTMixin, IADMMSolver):
         return T.call("ct_iadmm", variables, y0, n_view, float(radon.opnorm), sigma_d, mu, tau, -1 if iter_num is None else iter_num,
                       self._ctx(variables).cid)
 
-
-    def _forward_autograd(self, variables, y0, sigma_d, mu, tau, iter_num):
-        """The reference's loop (tasks/ct/solver.py:32-49) from differentiable building blocks: what the fused native VJP
-        (pnpx_ct_iadmm_backward) is tested against."""
-        n_view = int(y0.shape[2])
-        radon = self.radon_generator(variables.shape[-1], n_view, device=variables.device)
-        x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
-        B, R = x.shape[0], x.shape[-1]
-        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
-            x = self.prox_mapping(z - u, sigma_d[:, i])
-            _tau, _mu = tau[:, i].reshape(B, 1, 1, 1), mu[:, i].reshape(B, 1, 1, 1)
-            g = A.radon_backprojection(A.radon_forward(z, n_view) - y0, R) / radon.opnorm ** 2
-            z = z - _tau * (g + _mu * (z - (x + u)))
-            u = u + x - z
-        return torch.cat([x, z, u], dim=1)
-
-
 class PGSolver_CT(CTMixin, PGSolver):
     """tasks/ct/solver.py:56-87"""
 
@@ -69,18 +52,6 @@ class PGSolver_CT(CTMixin, PGSolver):
             return T.call("ct_pg_train", variables, y0, n_view, float(radon.opnorm), sigma_d, tau,
                           -1 if iter_num is None else iter_num, self._ctx(variables).cid)[0]
         return T.call("ct_pg", variables, y0, n_view, float(radon.opnorm), sigma_d, tau, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
-
-
-    def _forward_autograd(self, variables, y0, sigma_d, tau, iter_num):
-        """The reference's loop (tasks/ct/solver.py:73-83) from differentiable building blocks."""
-        n_view = int(y0.shape[2])
-        radon = self.radon_generator(variables.shape[-1], n_view, device=variables.device)
-        x, B, R = variables, variables.shape[0], variables.shape[-1]
-        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
-            g = A.radon_backprojection(A.radon_forward(x, n_view) - y0, R) / radon.opnorm ** 2
-            x = self.prox_mapping(x - tau[:, i].reshape(B, 1, 1, 1) * g, sigma_d[:, i])
-        return x
-
 
 _solver_map = {'iadmm': IADMMSolver_CT, 'pg': PGSolver_CT}
 

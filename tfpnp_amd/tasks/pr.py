@@ -35,24 +35,6 @@ class IADMMSolver_PR(PRMixin, IADMMSolver):
                           self._ctx(variables).cid)[0]
         return T.call("pr_iadmm", variables, y0, mask, sigma_d, mu, tau, -1 if iter_num is None else iter_num, self._ctx(variables).cid)
 
-
-    def _forward_autograd(self, variables, y0, mask, sigma_d, mu, tau, iter_num):
-        """The reference's loop (tasks/pr/solver.py:49-72) from differentiable building blocks: what the fused native VJP
-        (pnpx_pr_iadmm_backward) is tested against."""
-        x, z, u = torch.split(variables, variables.shape[1] // 3, dim=1)
-        B, S = x.shape[0], mask.shape[1]
-        for i in range(sigma_d.shape[-1] if iter_num is None else iter_num):
-            x = A.r2c(self.prox_mapping(A.c2r(z - u), sigma_d[:, i]))
-            _tau, _mu = tau[:, i].reshape(B, 1, 1, 1, 1), mu[:, i].reshape(B, 1, 1, 1, 1)
-            Az = A.fft2(A.cmul(z.repeat(1, S, 1, 1, 1), mask), centered=False)                  # cdp_forward
-            y_hat = (Az ** 2).sum(dim=-1).sqrt()
-            q = ((y_hat - y0) / y_hat).unsqueeze(-1)
-            g = A.cmul(A.fft2(q * Az, inverse=True, centered=False), A.conj(mask)).mean(1, keepdim=True)  # cdp_backward
-            z = z - _tau * (g + _mu * (z - (x + u)))
-            u = u + x - z
-        return torch.cat([x, z, u], dim=1)
-
-
 class PGSolver_PR(PRMixin, PGSolver):
     """tasks/pr/solver.py:79-112: the reference applies `~mask` to the float CDP mask and the CS-MRI fft2 to PR
     data (:102-103), which raises on any input; it is not runnable there, so no native loop exists."""

@@ -7,6 +7,8 @@ import torch
 from tfpnp_amd import synth
 from tfpnp_amd.pnp import UNetDenoiser2D
 from tfpnp_amd.tasks import csmri
+from tests import composed_solvers
+composed_solvers.install()      # the composed (step-by-step autograd) loops live with the tests
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 256
