@@ -50,3 +50,14 @@ def test_bench_without_gpu_fails_loudly():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "MI355X" in (r.stderr + r.stdout)
+
+
+def test_bench_self_launches_eight_ranks_strong_uneven():
+    """`bench.py --gpus 8 --scaling strong` on BASELINE config #3's env batch of 36: 5/5/5/5/4/4/4/4 items per rank, one
+    exchange per env step, every rank's rewards on rank 0, same reward sum as one process running all 36."""
+    eight = _run("--gpus", "8", "--scaling", "strong", "--batch", "36")
+    assert eight["n_gpus"] == 8 and eight["world_size_seen"] == 8 and eight["scaling"] == "strong"
+    assert eight["config"]["global_batch"] == 36 and eight["reward_rows_seen"] == 36
+    assert eight["collectives_per_env_step"] == 1.0
+    one = _run("--gpus", "1", "--batch", "36")
+    assert abs(one["reward_sum"] - eight["reward_sum"]) < 1e-4 * abs(one["reward_sum"])

@@ -260,3 +260,70 @@ def test_strong_split_of_one_env_batch_world2():
         bounds = [D.shard_bounds(48, g, r) for r in range(g)]
         assert bounds[0][0] == 0 and bounds[-1][1] == 48 and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
         assert max(h - l for l, h in bounds) - min(h - l for l, h in bounds) <= 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# World size 8 (the node the driver scales to): BASELINE config #3's env batch of 36 does not divide by 8 -- shards of
+# 5/5/5/5/4/4/4/4 -- through ShardedEnv with per-item early stopping; ranks finish at different steps and keep joining the
+# one collective per env step until the whole batch is done.
+def _episode8_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from tfpnp_amd import dist as D
+    from tfpnp_amd.env.base import PnPEnv
+    D.init_from_env(backend="gloo")
+    counts = _count_collectives()
+
+    class StubEnv(PnPEnv):
+        ob_keys = ()
+
+    n_global = 36
+    lo, hi = D.shard_bounds(n_global, world, rank)
+    rs = np.random.RandomState(0)
+    gt_all = torch.from_numpy(rs.rand(n_global, 1, 4, 4).astype(np.float32))
+    gt = gt_all[lo:hi].clone()
+    data = {'gt': gt, 'x0': torch.zeros_like(gt), 'output': torch.zeros_like(gt)}
+    env = StubEnv(None, _StubSolver(), max_episode_step=6)
+    env.metric_fn = lambda out, g: -((out - g) ** 2).reshape(out.shape[0], -1).mean(1, keepdim=True)
+    senv = D.ShardedEnv(env)
+    senv.reset(data, pre_sharded=True, n_global=n_global)          # every rank built only its own rows
+    stop_at = 1 + (torch.arange(n_global) * 7) % 5           # item i stops after step 1..5 (global, deterministic)
+    log = []
+    for step in range(1, 7):
+        live = env.idx_left.clone() if not senv._local_done else torch.empty(0, dtype=torch.long)
+        action = {'mu': torch.full((len(live),), 0.5), 'idx_stop': (stop_at[lo:hi][live] <= step).long()}
+        before = dict(counts)
+        _, rewards, finished, info = senv.step(action)
+        made = {k: v - before.get(k, 0) for k, v in counts.items() if v != before.get(k, 0)}
+        assert made == {"all_gather_into_tensor": 1}, made
+        log.append((rewards.view(-1).tolist(), info['done'].tolist(), finished))
+        if finished:
+            break
+    q.put((rank, (lo, hi), log))
+    dist.destroy_process_group()
+
+
+def test_sharded_env_episode_world8_uneven_36():
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_episode8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (b, log) for r, b, log in (q.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [res[r][0][1] - res[r][0][0] for r in range(world)] == [5, 5, 5, 5, 4, 4, 4, 4]
+    assert res[0][0] == (0, 5) and res[7][0] == (32, 36)
+    for r in range(1, world):
+        assert res[r][1] == res[0][1]                           # every rank holds the same global trajectory
+    log = res[0][1]
+    stop_at = [1 + (i * 7) % 5 for i in range(36)]
+    assert len(log) == 5 and [f for _, _, f in log] == [False] * 4 + [True]
+    for step, (rew, done, _) in enumerate(log, start=1):
+        assert len(rew) == 36 and done == [s <= step for s in stop_at]
+        for i in range(36):       # an item earns a reward exactly while it is live (stopped items: zero rows, still gathered)
+            assert (rew[i] > 0) == (stop_at[i] >= step), (step, i)
