@@ -237,6 +237,10 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_fft_tile = value;
     return PNPX_OK;
   }
+  if (is("fft_fast") && (value == 0 || value == 1)) {
+    ctx->opt_fft_fast = value;
+    return PNPX_OK;
+  }
   if (is("fft_affine") && (value == 0 || value == 1)) {
     ctx->opt_fft_affine = value;
     return PNPX_OK;
@@ -296,6 +300,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fold_first")) *value = ctx->opt_fold_first;
   else if (is("policy_s2_hs")) *value = ctx->opt_policy_s2_hs;
   else if (is("fft_affine")) *value = ctx->opt_fft_affine;
+  else if (is("fft_fast")) *value = ctx->opt_fft_fast;
   else if (is("fft_tile")) *value = ctx->opt_fft_tile;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
   else if (is("train_cache_gb")) *value = ctx->opt_train_cache_gb;

@@ -163,6 +163,7 @@ struct pnpx_ctx {
   int opt_fold_first = 0;          // opt-in: first convolution folded into the loader of the second one (conv_hs WREG == 2;
                                    // bit-identical, 400 MB less HBM traffic per forward, time-neutral: 5.835 vs 5.841 ms)
   int opt_fft_tile = 0;            // complex points per FFT workgroup tile (0 = FFT_TILE_POINTS)
+  int opt_fft_fast = 1;            // N = 256 lines on the register-radix-16 FFT kernels (fft_lds.h fft256_*)
   int opt_fft_affine = 1;          // XCD-affine block -> image mapping of the FFT passes (fft_lds.h)
   int opt_chains = 0;              // denoiser forward as n independent launch chains over slices of the batch (0 = auto)
   std::vector<hipStream_t> side_streams;

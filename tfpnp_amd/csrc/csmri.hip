@@ -88,6 +88,21 @@ struct MidBlend {  // k[mask] = ((mu*k) + y0)[mask] / (1 + mu)      tasks/csmri/
     const float den = addr(1.f, mu);
     return make_float2(divr(addr(mulr(mu, v.x), y.x), den), divr(addr(mulr(mu, v.y), y.y), den));
   }
+  // the same in two halves for the fused 256-point column kernel (fft_lds.h MidHasFetch): reads first, arithmetic later
+  struct Pre {
+    float2 y;
+    int m;
+  };
+  __device__ Pre fetch(int b, int ky, int kx) const {
+    const size_t o = (size_t)b * k.HW + (size_t)ky * k.W + kx;
+    return Pre{k.y0[o], (int)k.mask[o]};
+  }
+  __device__ float2 apply(const Pre& p, int b, float2 v) const {
+    if (!p.m) return v;
+    const float mu = k.par[(size_t)b * k.stride];
+    const float den = addr(1.f, mu);
+    return make_float2(divr(addr(mulr(mu, v.x), p.y.x), den), divr(addr(mulr(mu, v.y), p.y.y), den));
+  }
 };
 struct MidBlendSave {  // MidBlend that also keeps the k-space image BEFORE the blend (training path: d blend / d mu needs it)
   KSpace k;
@@ -142,6 +157,20 @@ struct StoreAdmm {  // z = ifft2c(k); u = u + x - z; emits Re(z - u_new) (+ x as
     uo.at(b, y, x) = un;
     d.at(b, y, x) = subr(zv.x, un.x);
     if (write_x) xo.at(b, y, x) = make_float2(xv, 0.f);
+  }
+  // the same in two halves for the 256-point row kernel (fft_lds.h FunctorHasFetch): the reads of u and x go out with the
+  // tile's own loads.  Safe: a workgroup reads and writes only its own pixels, and the outputs never alias the inputs.
+  struct Pre {
+    float2 uu;
+    float xv;
+  };
+  __device__ Pre fetch(int b, int y, int x) const { return Pre{ui.at(b, y, x), xr.at(b, y, x)}; }
+  __device__ void apply(const Pre& p, int b, int y, int x, float2 zv) const {
+    const float2 un = make_float2(subr(addr(p.uu.x, p.xv), zv.x), subr(addr(p.uu.y, 0.f), zv.y));
+    z.at(b, y, x) = zv;
+    uo.at(b, y, x) = un;
+    d.at(b, y, x) = subr(zv.x, un.x);
+    if (write_x) xo.at(b, y, x) = make_float2(p.xv, 0.f);
   }
 };
 // Backward of one ADMM iteration after the data step's adjoint: gs = cotangent of (x + u).

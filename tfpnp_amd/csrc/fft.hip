@@ -93,6 +93,15 @@ int make_fft_plan(pnpx_ctx* ctx, int n_img, int H, int W, bool centered, FftPlan
   P->grid_cols = dim3((W + lc - 1) / lc, n_img);
   P->lds_rows = sizeof(float2) * 2 * (size_t)lr * (W + 1);
   P->lds_cols = sizeof(float2) * 2 * (size_t)lc * (H + 1);
+  // 256-point lines: the register-radix-16 kernels (16-line tiles; option fft_fast, default on)
+  if (ctx->opt_fft_fast) {
+    P->fast256_rows = (W == 256 && H % FFT256_LINES == 0);
+    P->fast256_cols = (H == 256 && W % FFT256_LINES == 0);
+    if (ctx->opt_fft_affine && n_img >= 8) {
+      if (P->fast256_rows) P->rows.affine = 1;
+      if (P->fast256_cols) P->cols.affine = 1;
+    }
+  }
   return PNPX_OK;
 }
 

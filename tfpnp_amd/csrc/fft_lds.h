@@ -14,6 +14,9 @@
 // Load / Mid / Store functors fuse the neighbouring pointwise work (x+u, k-space blend, dual update ...)
 // into the passes, so a fused prox step is: row pass -> column pass (fwd, pointwise, inverse) -> row pass.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace pnpx {
@@ -211,6 +214,9 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_rows_kernel(PassGeom g, Load 
 struct MidNone {
   __device__ float2 operator()(int, int, int, float2 v) const { return v; }
 };
+struct MidNonePre {   // placeholder type for functors without a fetch / apply split
+  struct Pre {};
+};
 
 template <bool INV, bool FUSED, class Load, class Mid, class Store>
 __global__ __launch_bounds__(FFT_THREADS) void fft_cols_kernel(PassGeom g, Load ld, Mid mid, Store st) {
@@ -253,6 +259,166 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols_kernel(PassGeom g, Load 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ N = 256 fast path (r4)
+// 256 = 16 x 16: a thread holds 16 points of one line in registers, so a 256-point transform is two radix-16 register
+// butterflies with ONE exchange through LDS in between (the generic Stockham path: four radix-4 stages, each a full LDS
+// round trip + barrier).  Index split  n = n1 + 16 n2,  k = 16 k1 + k2:
+//     X[16 k1 + k2] = sum_n1 W16^(n1 k1) * [ W256^(n1 k2) * sum_n2 x[n1 + 16 n2] W16^(n2 k2) ]
+// step 1: thread n1 loads x[n1 + 16 n2] (16 consecutive lanes = 128 contiguous bytes per n2), 16-point FFT over n2, twiddle;
+// exchange; step 2: thread k2 holds the 16 values over n1, 16-point FFT -> X[16 k1 + k2] (again 128-byte runs per k1).
+// A tile is 16 lines (4096 points, 34 KiB of LDS): rows = 16 image rows, columns = 16 ADJACENT columns, whose loads are the
+// same 128-byte runs (the generic column tile is 4 columns = 32-byte pieces).  In the fused column pass the forward result
+// X[k2 + 16 k1] sits in exactly the (n1, n2) register layout the inverse transform starts from: forward FFT -> k-space
+// functor -> inverse FFT without another re-layout.  Centering signs: (-1)^n = (-1)^n1 and (-1)^(k + 128) = (-1)^k2 are
+// per-thread constants.
+template <bool INV>
+__device__ __forceinline__ float2 cmulw(float2 v, float c, float s) {   // v * (c - i s)  (INV: v * (c + i s))
+  return INV ? make_float2(v.x * c - v.y * s, v.y * c + v.x * s) : make_float2(v.x * c + v.y * s, v.y * c - v.x * s);
+}
+template <bool INV>
+__device__ __forceinline__ void dft4(float2 a0, float2 a1, float2 a2, float2 a3, float2& o0, float2& o1, float2& o2, float2& o3) {
+  const float2 s02 = make_float2(a0.x + a2.x, a0.y + a2.y), d02 = make_float2(a0.x - a2.x, a0.y - a2.y);
+  const float2 s13 = make_float2(a1.x + a3.x, a1.y + a3.y), d13 = make_float2(a1.x - a3.x, a1.y - a3.y);
+  const float2 j = INV ? make_float2(-d13.y, d13.x) : make_float2(d13.y, -d13.x);   // (+-i) * d13
+  o0 = make_float2(s02.x + s13.x, s02.y + s13.y);
+  o2 = make_float2(s02.x - s13.x, s02.y - s13.y);
+  o1 = make_float2(d02.x + j.x, d02.y + j.y);
+  o3 = make_float2(d02.x - j.x, d02.y - j.y);
+}
+// in-place 16-point DFT, natural order in and out:  v[k] <- sum_n v[n] W16^(n k),  W16 = exp(-+ 2 pi i / 16)
+template <bool INV>
+__device__ __forceinline__ void fft16_reg(float2 (&v)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, C2 = 0.70710678118654752f;
+  float2 T[4][4];   // T[na][kb], n = na + 4 nb, k = 4 ka + kb
+#pragma unroll
+  for (int na = 0; na < 4; ++na) dft4<INV>(v[na], v[na + 4], v[na + 8], v[na + 12], T[na][0], T[na][1], T[na][2], T[na][3]);
+  // W16^(na kb): exponents 1, 2, 3 | 2, 4, 6 | 3, 6, 9
+  T[1][1] = cmulw<INV>(T[1][1], C1, S1);
+  T[1][2] = cmulw<INV>(T[1][2], C2, C2);
+  T[1][3] = cmulw<INV>(T[1][3], S1, C1);
+  T[2][1] = cmulw<INV>(T[2][1], C2, C2);
+  T[2][2] = cmulw<INV>(T[2][2], 0.f, 1.f);
+  T[2][3] = cmulw<INV>(T[2][3], -C2, C2);
+  T[3][1] = cmulw<INV>(T[3][1], S1, C1);
+  T[3][2] = cmulw<INV>(T[3][2], -C2, C2);
+  T[3][3] = cmulw<INV>(T[3][3], -C1, -S1);
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) dft4<INV>(T[0][kb], T[1][kb], T[2][kb], T[3][kb], v[kb], v[4 + kb], v[8 + kb], v[12 + kb]);
+}
+
+constexpr int FFT256_LINES = 16;
+constexpr int FFT256_LDS_F2 = 16 * 16 * 17;   // float2 words of the exchange buffer (34 KiB)
+
+// one 256-point transform per 16 threads.  `ex`: the workgroup's exchange buffer; `row_major`: threads of a line are the 16
+// consecutive lanes (row tiles: lane = index within the line) or strided by 16 (column tiles: lane = column).  `lin`: line
+// of the tile (0..15), `i`: this thread's n1 (then k2).  tw: W256^(i * m), m = 0..15 (forward sign).
+template <bool INV, bool ROWS>
+__device__ __forceinline__ void fft256_reg(float2 (&v)[16], float2* ex, int lin, int i, const float2 (&tw)[16]) {
+  fft16_reg<INV>(v);
+#pragma unroll
+  for (int k2 = 1; k2 < 16; ++k2) v[k2] = cmulw<INV>(v[k2], tw[k2].x, -tw[k2].y);   // table holds exp(-i t): c = x, s = -y
+  // exchange: written as [n1 = i][k2], read as [n1][k2 = i].  ROWS: word = (lin * 16 + n1) * 17 + k2 (lanes = n1: stride 17
+  // words = 34 dwords, conflict-free; reads contiguous over k2).  Columns: word = (n1 * 17 + k2) * 16 + lin (lanes = lin:
+  // contiguous both ways; the wave's four n1 / k2 values are 16 * 17 resp. 16 words apart = 32 mod 64 dwords).
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) ex[ROWS ? (lin * 16 + i) * 17 + k2 : (i * 17 + k2) * 16 + lin] = v[k2];
+  __syncthreads();
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) v[n1] = ex[ROWS ? (lin * 16 + n1) * 17 + i : (n1 * 17 + i) * 16 + lin];
+  fft16_reg<INV>(v);
+}
+
+// (the split functors of the fused passes: see MidHasFetch below; a Store with fetch(b, y, x) -> Pre / apply(pre, b, y, x, v)
+// has its global READS issued beside the tile's loads instead of behind the transform)
+template <class M, class = void>
+struct FunctorHasFetch : std::false_type {};
+template <class M>
+struct FunctorHasFetch<M, std::void_t<decltype(std::declval<const M&>().fetch(0, 0, 0))>> : std::true_type {};
+struct NoPre {
+  struct Pre {};
+};
+
+template <bool INV, class Load, class Store>
+__global__ __launch_bounds__(FFT_THREADS) void fft256_rows_kernel(PassGeom g, Load ld, Store st) {
+  __shared__ float2 ex[FFT256_LDS_F2];
+  const int i = threadIdx.x & 15, l = threadIdx.x >> 4;
+  int b, part;
+  xcd_affine_decode(blockIdx.x, g.H / FFT256_LINES, g.n_img, g.affine, &b, &part);
+  const int y = part * FFT256_LINES + l;
+  float2 tw[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) tw[m] = g.tw[(i * m) & 255];
+  const float sg = (g.centered && (i & 1)) ? -1.f : 1.f;     // (-1)^n on the way in, (-1)^(k + 128) on the way out
+  float2 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float2 t = ld(b, y, i + 16 * j);
+    v[j] = make_float2(t.x * sg, t.y * sg);
+  }
+  constexpr bool PREFETCH = FunctorHasFetch<Store>::value;
+  [[maybe_unused]] typename std::conditional<PREFETCH, Store, NoPre>::type::Pre pf[PREFETCH ? 16 : 1];
+  if constexpr (PREFETCH) {
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) pf[k1] = st.fetch(b, y, 16 * k1 + i);
+  }
+  fft256_reg<INV, true>(v, ex, l, i, tw);
+  const float sc = g.scale * sg;
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) {
+    const float2 o = make_float2(v[k1].x * sc, v[k1].y * sc);
+    if constexpr (PREFETCH) st.apply(pf[k1], b, y, 16 * k1 + i, o);
+    else st(b, y, 16 * k1 + i, o);
+  }
+}
+
+// A k-space functor may split itself into fetch(b, ky, kx) -> Pre (its global reads: measurements, mask ...) and
+// apply(pre, v): the fused column kernel then issues those reads up front, beside the tile's own loads, instead of behind the
+// forward transform (a second exposed memory latency per workgroup: 31 -> 2x us on the CS-MRI blend pass).
+template <class M>
+using MidHasFetch = FunctorHasFetch<M>;
+
+template <bool INV, bool FUSED, class Load, class Mid, class Store>
+__global__ __launch_bounds__(FFT_THREADS) void fft256_cols_kernel(PassGeom g, Load ld, Mid mid, Store st) {
+  __shared__ float2 ex[FFT256_LDS_F2];
+  const int c = threadIdx.x & 15, i = threadIdx.x >> 4;
+  int b, xt;
+  xcd_affine_decode(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, g.n_img, g.affine, &b, &xt);
+  const int x = xt * FFT256_LINES + c;
+  float2 tw[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) tw[m] = g.tw[(i * m) & 255];
+  const float sg = (g.centered && (i & 1)) ? -1.f : 1.f;
+  float2 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float2 t = ld(b, i + 16 * j, x);
+    v[j] = make_float2(t.x * sg, t.y * sg);
+  }
+  constexpr bool PREFETCH = FUSED && MidHasFetch<Mid>::value;
+  [[maybe_unused]] typename std::conditional<PREFETCH, Mid, MidNonePre>::type::Pre pf[PREFETCH ? 16 : 1];
+  if constexpr (PREFETCH) {
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) pf[k1] = mid.fetch(b, 16 * k1 + i, x);
+  }
+  fft256_reg<INV, false>(v, ex, c, i, tw);
+  const float sc = g.scale * sg;
+  if (FUSED) {
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+      const float2 in = make_float2(v[k1].x * sc, v[k1].y * sc);
+      float2 t;
+      if constexpr (PREFETCH) t = mid.apply(pf[k1], b, in);
+      else t = mid(b, 16 * k1 + i, x, in);
+      v[k1] = make_float2(t.x * sg, t.y * sg);               // (-1)^ky of the inverse transform's input
+    }
+    __syncthreads();                                          // everyone has read the first exchange
+    fft256_reg<!INV, false>(v, ex, c, i, tw);
+  }
+#pragma unroll
+  for (int y1 = 0; y1 < 16; ++y1) st(b, 16 * y1 + i, x, make_float2(v[y1].x * sc, v[y1].y * sc));
+}
+
 // ---- common functors
 struct LoadC {  // complex [n_img, H, W, 2]
   const float2* p;
@@ -276,6 +442,8 @@ struct FftPlan2D {
   PassGeom rows, cols;
   dim3 grid_rows, grid_cols;
   size_t lds_rows, lds_cols;
+  // N = 256 register-radix-16 kernels (fft256_*_kernel) instead of the generic LDS Stockham passes
+  bool fast256_rows = false, fast256_cols = false;
 };
 
 // Fills the launch geometry for an H x W transform over n_img images; tw tables come from the context.
@@ -283,6 +451,12 @@ int make_fft_plan(pnpx_ctx* ctx, int n_img, int H, int W, bool centered, FftPlan
 
 template <bool INV, class Load, class Store>
 int launch_rows(const FftPlan2D& P, Load ld, Store st, hipStream_t s) {
+  if (P.fast256_rows) {
+    hipLaunchKernelGGL((fft256_rows_kernel<INV, Load, Store>), dim3(P.rows.n_img * (P.rows.H / FFT256_LINES)), dim3(FFT_THREADS), 0, s,
+                       P.rows, ld, st);
+    PNPX_LAUNCH_CHECK();
+    return PNPX_OK;
+  }
   hipLaunchKernelGGL((fft_rows_kernel<INV, Load, Store>), P.grid_rows, dim3(FFT_THREADS), P.lds_rows, s, P.rows, ld,
                      st);
   PNPX_LAUNCH_CHECK();
@@ -290,6 +464,12 @@ int launch_rows(const FftPlan2D& P, Load ld, Store st, hipStream_t s) {
 }
 template <bool INV, bool FUSED, class Load, class Mid, class Store>
 int launch_cols(const FftPlan2D& P, Load ld, Mid mid, Store st, hipStream_t s) {
+  if (P.fast256_cols) {
+    hipLaunchKernelGGL((fft256_cols_kernel<INV, FUSED, Load, Mid, Store>), dim3(P.cols.W / FFT256_LINES, P.cols.n_img), dim3(FFT_THREADS),
+                       0, s, P.cols, ld, mid, st);
+    PNPX_LAUNCH_CHECK();
+    return PNPX_OK;
+  }
   hipLaunchKernelGGL((fft_cols_kernel<INV, FUSED, Load, Mid, Store>), P.grid_cols, dim3(FFT_THREADS), P.lds_cols, s,
                      P.cols, ld, mid, st);
   PNPX_LAUNCH_CHECK();
