@@ -538,6 +538,72 @@ __global__ void radon_backproject_kernel(const float* __restrict__ sino, float* 
   }
   img[i] = scale == 1.f ? acc : divr(acc, scale);
 }
+// The same backprojection with the sinogram staged in LDS (r4).  A workgroup = one 32 x 32-pixel tile of one image, four
+// pixels per thread.  For a view the tile's pixels project into a window of at most 31 (|cos| + |sin|) + 2 < 48 detector bins:
+// the window (64 bins, zeros outside the detector) of EVERY view is copied to LDS once -- V x 256 bytes -- and the per-view
+// loop reads its two interpolation taps from there instead of issuing two dependent global gathers per sample (the r3 kernel:
+// 55 us at B = 32, 256 x 256, 30 views, bound by the gather rate).  Same arithmetic in the same order per pixel; an
+// out-of-range tap multiplies a stored zero instead of being skipped (acc + 0 = acc).
+constexpr int RBP_T = 32, RBP_WIN = 64;
+__global__ __launch_bounds__(256) void radon_backproject_lds_kernel(const float* __restrict__ sino, float* __restrict__ img,
+                                                                    const float2* __restrict__ cs, int R, int V, int det, float scale) {
+  extern __shared__ float rb_lds[];          // [V][RBP_WIN] taps, then [V] window origins (as int)
+  int* base = reinterpret_cast<int*>(rb_lds + (size_t)V * RBP_WIN);
+  const int b = blockIdx.z, x0 = blockIdx.x * RBP_T, y0 = blockIdx.y * RBP_T;
+  const float off = (float)R / 2.f - 0.5f, half = (float)det / 2.f - 0.5f;
+  for (int e = threadIdx.x; e < V * RBP_WIN; e += 256) {
+    const int v = e / RBP_WIN, k = e - v * RBP_WIN;
+    const float c = cs[v].x, sn = cs[v].y;
+    const float xa = (float)x0 - off, xb = (float)(x0 + RBP_T - 1) - off, ya = (float)y0 - off, yb = (float)(y0 + RBP_T - 1) - off;
+    const float lo = fminf(xa * c, xb * c) + fminf(ya * sn, yb * sn) + half;
+    const int s_lo = (int)floorf(lo) - 2;      // two bins of slack against the rounding of this bound vs the per-pixel values
+    const int sidx = s_lo + k;
+    rb_lds[e] = (sidx >= 0 && sidx < det) ? sino[((size_t)b * V + v) * det + sidx] : 0.f;
+    if (k == 0) base[v] = s_lo;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int x = x0 + tx;
+  const float xs = subr((float)min(x, R - 1), off);     // (pixels past the image edge compute inside the window, are not stored)
+  float ys[4], acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ys[j] = subr((float)min(y0 + ty + 8 * j, R - 1), off);
+    acc[j] = 0.f;
+  }
+  for (int v = 0; v < V; ++v) {
+    const float2 t = cs[v];
+    const float* row = rb_lds + v * RBP_WIN - base[v];
+    const float xc = mulr(xs, t.x);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sp = addr(addr(xc, mulr(ys[j], t.y)), half);
+      const float f0 = floorf(sp);
+      const int s0 = (int)f0;
+      const float f = subr(sp, f0);
+      acc[j] = addr(acc[j], mulr(row[s0], subr(1.f, f)));
+      acc[j] = addr(acc[j], mulr(row[s0 + 1], f));
+    }
+  }
+  if (x < R) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + ty + 8 * j;
+      if (y < R) img[((size_t)b * R + y) * R + x] = scale == 1.f ? acc[j] : divr(acc[j], scale);
+    }
+  }
+}
+static void launch_radon_backproject(const float* sino, float* img, const float2* cs, int R, int V, int det, int B, float scale,
+                                     hipStream_t s) {
+  const size_t lds = (size_t)V * RBP_WIN * sizeof(float) + (size_t)V * sizeof(int);
+  if (lds <= 60 * 1024 && B <= 65535) {
+    hipLaunchKernelGGL(radon_backproject_lds_kernel, dim3((R + RBP_T - 1) / RBP_T, (R + RBP_T - 1) / RBP_T, B), dim3(256), lds, s, sino, img,
+                       cs, R, V, det, scale);
+  } else {   // very many views: the per-pixel gather kernel
+    hipLaunchKernelGGL(radon_backproject_kernel, dim3((unsigned)(((size_t)B * R * R + 255) / 256)), dim3(256), 0, s, sino, img, cs, R, V,
+                       det, B, scale);
+  }
+}
 // z = z - tau*(g + mu*(z - (x+u))); u = u + x - z; d = z - u                tasks/ct/solver.py:46-49
 __global__ void ct_update_kernel(const float* __restrict__ g, const float* __restrict__ xr, const float* zin,
                                  const float* uin, float* xout, float* zout, float* uout, size_t istride,
@@ -947,8 +1013,7 @@ int pnpx_radon_backprojection(pnpx_ctx* ctx, const float* sino, float* img, int 
   const float2* cs;
   int det;
   PNPX_TRY(upload_cs(ctx, R, n_view, s, &cv, &cs, &det));
-  hipLaunchKernelGGL(radon_backproject_kernel, g1((size_t)B * R * R), dim3(256), 0, s, sino, img, cs, R, n_view, det,
-                     B, 1.f);
+  launch_radon_backproject(sino, img, cs, R, n_view, det, B, 1.f, s);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
@@ -992,8 +1057,7 @@ static int ct_normal_op(const CtScratch& C, const float* img, size_t istride, co
                         int n_view, int B, hipStream_t s) {
   launch_radon_forward(img, istride, sub, C.sino, C.cs, C.pad, R, n_view, C.det, B, s);
   PNPX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(radon_backproject_kernel, g1((size_t)R * R * B), dim3(256), 0, s, C.sino, out, C.cs, R, n_view, C.det, B,
-                     op2);
+  launch_radon_backproject(C.sino, out, C.cs, R, n_view, C.det, B, op2, s);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
