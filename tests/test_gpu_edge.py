@@ -437,3 +437,47 @@ def test_radon_forward_shape_sweep_vs_oracle():
         ref = O.radon_forward(torch.from_numpy(img), angles, det)
         out = T.Radon_norm(R, V, device=dev()).forward(torch.from_numpy(img).to(dev())).cpu()
         assert float((out - ref).abs().max() / ref.abs().max()) < 2e-6, (R, V, B)
+
+
+def test_fft_beside_a_running_denoiser_is_not_disturbed(unet_params):
+    """Regression (r4): on this pool's MI355X boxes a wave executing packed-fp32 VALU instructions on a CU that also hosts another
+    kernel's dense f16 MFMA wave computes wrong values in lanes 48-63 (tools/stress_aggressor.py reproduces it without any library
+    code).  The FFT passes of a second context used to be such victims whenever another context's conv_hs ran (60-90 % of the
+    transforms wrong on affected boxes).  The library is now built without packed-fp32 instructions and conv_hs keeps LDS-using
+    neighbours off its CUs: every transform computed beside 150 denoiser forwards must equal the solo result bit for bit."""
+    import threading
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.utils import transforms as T
+    for (B, H) in [(6, 256), (3, 64)]:
+        den = UNetDenoiser2D(state_dict=unet_params)
+        x = torch.rand(B, 1, H, H, device=dev())
+        s = torch.full((B,), 0.1, device=dev())
+        c = torch.randn(B, 1, H, H, 2, device=dev())
+        ref_d, ref_f = den(x, s).clone(), T.fft2(c).clone()
+        torch.cuda.synchronize()
+        stop, bad, n = threading.Event(), [0, 0], [0, 0]
+
+        def run_denoiser():
+            st = torch.cuda.Stream(device=dev())
+            with torch.cuda.stream(st):
+                for _ in range(150):
+                    n[0] += 1
+                    bad[0] += int(not torch.equal(den(x, s), ref_d))
+            st.synchronize()
+            stop.set()
+
+        def run_fft():
+            st = torch.cuda.Stream(device=dev())
+            with torch.cuda.stream(st):
+                while not stop.is_set():
+                    n[1] += 1
+                    bad[1] += int(not torch.equal(T.fft2(c), ref_f))
+            st.synchronize()
+
+        ts = [threading.Thread(target=run_denoiser), threading.Thread(target=run_fft)]
+        for th in ts:
+            th.start()
+        for th in ts:
+            th.join()
+        print(f"  B={B} {H}x{H}: {bad[0]} of {n[0]} denoiser forwards, {bad[1]} of {n[1]} transforms differ from the solo results")
+        assert bad == [0, 0] and n[1] > 20

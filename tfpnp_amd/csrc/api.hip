@@ -161,8 +161,7 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx) {
   for (auto e : ctx->events) (void)hipEventDestroy(e);
   if (ctx->range_flag_host) (void)hipHostFree(ctx->range_flag_host);
   for (hipStream_t st : ctx->side_streams) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : ctx->side_joins) (void)hipEventDestroy(ev);
-  if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+  for (hipEvent_t ev : ctx->ev_pool) (void)hipEventDestroy(ev);
   delete ctx;
   return PNPX_OK;
 }

@@ -167,8 +167,12 @@ struct pnpx_ctx {
   int opt_fft_affine = 1;          // XCD-affine block -> image mapping of the FFT passes (fft_lds.h)
   int opt_chains = 0;              // denoiser forward as n independent launch chains over slices of the batch (0 = auto)
   std::vector<hipStream_t> side_streams;
-  std::vector<hipEvent_t> side_joins;
-  hipEvent_t side_fork = nullptr;
+  // fork / join events of the launch chains: a ROTATING pool.  An event must not be re-recorded while a hipStreamWaitEvent on
+  // its previous record may still sit un-submitted in another stream's host-side queue: with one fork event and one join event
+  // per side stream re-recorded every call, two host threads driving two contexts on one GPU lost joins (a slice's output read
+  // before it was written: one item of a batch wrong, 15 of 25 stress runs; r4, tools/stress_threads.py).
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_next = 0;
   int opt_wreg = 2;                // weights-in-registers instances for the 32 -> 32 channel layers (0 off, 1 / 2 = shape)
   int opt_range_guard = 1;         // 0 off, 1 sticky flag + latch to conv_mode 0, 2 strict (sync + transparent re-run)
   int opt_train_cache_gb = -1;     // training path: keep the activations of up to this many GiB of denoiser forwards for
@@ -216,6 +220,34 @@ struct pnpx_ctx {
 };
 
 namespace pnpx {
+
+int chain_event(pnpx_ctx* ctx, hipEvent_t* ev);        // next event of the rotating pool (unet.hip)
+int chain_streams(pnpx_ctx* ctx, int chains);          // make sure chains - 1 side streams exist
+// Run `chains` contiguous slices of a B-item batch as independent launch chains: slice 0 on the caller's stream `s`, the others
+// on the context's side streams, forked from / joined back into `s` by events.  run_slice(lo, hi, stream) -> status.
+template <class F>
+int fan_out_chains(pnpx_ctx* ctx, int chains, int B, hipStream_t s, F&& run_slice) {
+  PNPX_TRY(chain_streams(ctx, chains));
+  hipEvent_t fork = nullptr, joins[16] = {};
+  PNPX_TRY(chain_event(ctx, &fork));
+  PNPX_HIP(hipEventRecord(fork, s));
+  for (int c = chains - 1; c >= 0; --c) {       // the caller's stream takes slice 0 last: its host-side issue overlaps
+    const int lo = (int)((long long)B * c / chains), hi = (int)((long long)B * (c + 1) / chains);
+    hipStream_t st = c ? ctx->side_streams[c - 1] : s;
+    if (c) PNPX_HIP(hipStreamWaitEvent(st, fork, 0));
+    const int rc = run_slice(lo, hi, st);
+    if (rc != PNPX_OK) {
+      join_side_streams_after_failure(ctx);    // nothing queued on a side stream may outlive the failing call
+      return rc;
+    }
+    if (c) {
+      PNPX_TRY(chain_event(ctx, &joins[c]));
+      PNPX_HIP(hipEventRecord(joins[c], st));
+    }
+  }
+  for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, joins[c], 0));
+  return PNPX_OK;
+}
 
 int ctx_reserve_unet(pnpx_ctx* ctx, int B, int H, int W);   // main arena, ctx->conv_mode
 int reserve_arena(pnpx_ctx* ctx, UNetArena& ar, int mode, int B, int H, int W, size_t extra_bytes);

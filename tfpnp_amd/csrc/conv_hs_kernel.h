@@ -88,9 +88,12 @@ struct HsGeom {
   static constexpr int XWIN_OFF = 2 * STAGE + BIAS_BYTES;
   static constexpr int XWIN_BYTES = WREG == 2 ? ((XWIN_W * XWIN_H * 4 + 255) & ~255) : 0;
   static constexpr int LDS_USED = 2 * STAGE + BIAS_BYTES + XWIN_BYTES;
-  // One workgroup per CU BY CONSTRUCTION: the request is padded past half of the 160 KiB so that two workgroups can
-  // never be co-resident (see DESIGN.md "co-residency"); the persistent grid is <= 256 workgroups.
-  static constexpr int LDS_BYTES = LDS_USED > 82 * 1024 ? LDS_USED : 82 * 1024;
+  // One workgroup per CU BY CONSTRUCTION, and NO other workgroup that needs LDS beside it: every instance requests the CU's whole
+  // 160 KiB.  (r1-r3 padded the request past 80 KiB, which kept a second conv_hs workgroup out but let small-LDS kernels of other
+  // streams in.  On this pool's MI355X boxes a wave executing packed-fp32 VALU instructions on a CU that hosts another kernel's
+  // dense f16 MFMA wave computes wrong values in lanes 48-63 -- tools/stress_aggressor.py, DESIGN.md appendix r4 -- so conv_hs
+  // keeps LDS-using neighbours off its CUs; kernels without LDS can still share the CU's free registers.)
+  static constexpr int LDS_BYTES = 160 * 1024;
   static constexpr int MTB = MT / 32;
   static constexpr int NS = NI + NWJ;
   static constexpr int NST = MTB * NBW * 4;             // 16-byte record stores per wave and tile
@@ -901,7 +904,7 @@ inline int ensure_dyn_lds(const void* func, int bytes) {
 template <int MT, int NBW, int MBW, int NW, int EPI, int UPS = 0, int WREG = 0, int TAPS = 0x1FF>
 static int launch_hs_cfg(const ConvHsArgs& a0, int B, hipStream_t s) {
   using G = HsGeom<MT, NBW, MBW, NW, WREG, TAPS>;
-  constexpr int LDS_REQ = G::LDS_BYTES + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES;
+  constexpr int LDS_REQ = UPS ? G::LDS_USED + 3 * HsUpsGeom<MBW, NW * NBW>::BYTES : G::LDS_BYTES;   // UPS: window pool behind the used part
   static_assert(G::LDS_USED + UPS * 3 * HsUpsGeom<MBW, NW * NBW>::BYTES <= 160 * 1024, "no LDS room for the low-resolution windows");
   PNPX_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&conv_hs_kernel<MT, NBW, MBW, NW, EPI, UPS, WREG, TAPS>), LDS_REQ));
   ConvHsArgs a = a0;

@@ -436,31 +436,10 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
 
   const int chains = keep_mids ? 1 : launch_chains(ctx, B, H, W);
   if (chains <= 1) return run(0, B, x, sigma, out, out_pre, s);
-  while ((int)ctx->side_streams.size() < chains - 1) {
-    hipStream_t st = nullptr;
-    hipEvent_t ev = nullptr;
-    PNPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    ctx->side_streams.push_back(st);
-    PNPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    ctx->side_joins.push_back(ev);
-  }
-  if (!ctx->side_fork) PNPX_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
   const size_t px = (size_t)H * W;
-  PNPX_HIP(hipEventRecord(ctx->side_fork, s));
-  for (int c = chains - 1; c >= 0; --c) {       // the caller's stream takes slice 0 last: its host-side issue overlaps
-    const int lo = (int)((long long)B * c / chains), hi = (int)((long long)B * (c + 1) / chains);
-    hipStream_t st = c ? ctx->side_streams[c - 1] : s;
-    if (c) PNPX_HIP(hipStreamWaitEvent(st, ctx->side_fork, 0));
-    const int rc = run(lo, hi - lo, x + lo * px, sigma + (size_t)lo * sigma_stride, out + lo * px, out_pre ? out_pre + lo * px : nullptr,
-                       st);
-    if (rc != PNPX_OK) {
-      join_side_streams_after_failure(ctx);
-      return rc;
-    }
-    if (c) PNPX_HIP(hipEventRecord(ctx->side_joins[c - 1], st));
-  }
-  for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, ctx->side_joins[c - 1], 0));
-  return PNPX_OK;
+  return fan_out_chains(ctx, chains, B, s, [&](int lo, int hi, hipStream_t st) -> int {
+    return run(lo, hi - lo, x + lo * px, sigma + (size_t)lo * sigma_stride, out + lo * px, out_pre ? out_pre + lo * px : nullptr, st);
+  });
 }
 
 

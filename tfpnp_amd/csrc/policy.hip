@@ -734,29 +734,9 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
     if (chains > B) chains = B;
   }
   if (chains <= 1) return run(0, B, ob, probs, det, s);
-  while ((int)ctx->side_streams.size() < chains - 1) {
-    hipStream_t st = nullptr;
-    hipEvent_t ev = nullptr;
-    PNPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    ctx->side_streams.push_back(st);
-    PNPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    ctx->side_joins.push_back(ev);
-  }
-  if (!ctx->side_fork) PNPX_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
-  PNPX_HIP(hipEventRecord(ctx->side_fork, s));
-  for (int c = chains - 1; c >= 0; --c) {       // the caller's stream takes slice 0 last: its host-side issue overlaps
-    const int lo = (int)((long long)B * c / chains), hi = (int)((long long)B * (c + 1) / chains);
-    hipStream_t st = c ? ctx->side_streams[c - 1] : s;
-    if (c) PNPX_HIP(hipStreamWaitEvent(st, ctx->side_fork, 0));
-    const int rc = run(lo, hi - lo, ob + (size_t)lo * N.num_inputs * H * W, probs + (size_t)lo * 2, det + (size_t)lo * N.n_det, st);
-    if (rc != PNPX_OK) {
-      join_side_streams_after_failure(ctx);
-      return rc;
-    }
-    if (c) PNPX_HIP(hipEventRecord(ctx->side_joins[c - 1], st));
-  }
-  for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, ctx->side_joins[c - 1], 0));
-  return PNPX_OK;
+  return fan_out_chains(ctx, chains, B, s, [&](int lo, int hi, hipStream_t st) -> int {
+    return run(lo, hi - lo, ob + (size_t)lo * N.num_inputs * H * W, probs + (size_t)lo * 2, det + (size_t)lo * N.n_det, st);
+  });
 }
 
 }  // namespace pnpx

@@ -573,6 +573,30 @@ int launch_chains(const pnpx_ctx* ctx, int B, int H, int W) {
 void join_side_streams_after_failure(pnpx_ctx* ctx) {
   for (hipStream_t st : ctx->side_streams) (void)hipStreamSynchronize(st);
 }
+int chain_streams(pnpx_ctx* ctx, int chains) {
+  if (chains > 16) {
+    set_error("launch chains: at most 16 slices");
+    return PNPX_ERR_ARG;
+  }
+  while ((int)ctx->side_streams.size() < chains - 1) {
+    hipStream_t st = nullptr;
+    PNPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ctx->side_streams.push_back(st);
+  }
+  return PNPX_OK;
+}
+int chain_event(pnpx_ctx* ctx, hipEvent_t* ev) {
+  constexpr size_t POOL = 256;     // a call uses `chains` events: an event comes round again >= 32 calls later
+  if (ctx->ev_pool.size() < POOL) {
+    hipEvent_t e = nullptr;
+    PNPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->ev_pool.push_back(e);
+    *ev = e;
+    return PNPX_OK;
+  }
+  *ev = ctx->ev_pool[ctx->ev_next++ % POOL];
+  return PNPX_OK;
+}
 
 int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre,
                  int B, int H, int W, hipStream_t s, ProfileSink* prof, UNetArena* arena, int mode, bool keep_all) {
@@ -605,32 +629,12 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     // tiles at the deep levels) and each costs ~10 us of fill / drain, so slices that run side by side keep more CUs
     // busy.  (At B = 48 the chip sits at its power cap for the whole forward and overlap buys nothing: measured 5.90 vs
     // 5.90 ms)  Per-image results do not depend on the slicing (bit-identical, tested).
-    while ((int)ctx->side_streams.size() < chains - 1) {
-      hipStream_t st = nullptr;
-      hipEvent_t ev = nullptr;
-      PNPX_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-      ctx->side_streams.push_back(st);
-      PNPX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      ctx->side_joins.push_back(ev);
-    }
-    if (!ctx->side_fork) PNPX_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
     const size_t px = (size_t)H * W;
-    PNPX_HIP(hipEventRecord(ctx->side_fork, s));
-    for (int c = chains - 1; c >= 0; --c) {       // the caller's stream takes slice 0 last: its host-side issue overlaps
-      const int lo = (int)((long long)B * c / chains), hi = (int)((long long)B * (c + 1) / chains);
-      hipStream_t st = c ? ctx->side_streams[c - 1] : s;
-      if (c) PNPX_HIP(hipStreamWaitEvent(st, ctx->side_fork, 0));
+    return fan_out_chains(ctx, chains, B, s, [&](int lo, int hi, hipStream_t st) -> int {
       Recorder none{nullptr, st};
-      const int rc = unet_forward_hs(ctx, ar, P, x + lo * px, sigma + (size_t)lo * sigma_stride, sigma_stride, out + lo * px,
-                                     out_pre ? out_pre + lo * px : nullptr, hi - lo, H, W, st, none, keep_all, lo);
-      if (rc != PNPX_OK) {
-        join_side_streams_after_failure(ctx);
-        return rc;
-      }
-      if (c) PNPX_HIP(hipEventRecord(ctx->side_joins[c - 1], st));
-    }
-    for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, ctx->side_joins[c - 1], 0));
-    return PNPX_OK;
+      return unet_forward_hs(ctx, ar, P, x + lo * px, sigma + (size_t)lo * sigma_stride, sigma_stride, out + lo * px,
+                             out_pre ? out_pre + lo * px : nullptr, hi - lo, H, W, st, none, keep_all, lo);
+    });
   }
   if (hs) return unet_forward_hs(ctx, ar, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec, keep_all);
 
