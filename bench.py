@@ -351,7 +351,7 @@ def forward_split(den, dev, x, sigma, n_fwd=12, reps=3):
     for _ in range(reps):
         for name, ms, f in ops.unet_profile(ctx, x, sigma):
             per[name] = per.get(name, 0.0) + ms
-            if name == "conv3x3":
+            if name in ("conv3x3", "conv3x3_wino"):
                 fl += f
     tot = sum(per.values())
     return whole_ms, {k: v / tot for k, v in per.items()}, fl / reps, tot / reps
@@ -363,7 +363,7 @@ def roofline(den, dev, x, sigma):
     (forward_split: bracketed whole forwards x the per-kernel share)."""
     B, _, H, W = x.shape
     whole_ms, shares, conv_fl, profiled_ms = forward_split(den, dev, x, sigma)
-    conv_ms = whole_ms * shares.get("conv3x3", 0.0)
+    conv_ms = whole_ms * (shares.get("conv3x3", 0.0) + shares.get("conv3x3_wino", 0.0))
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12
     return {
         "bound": "mfma",
@@ -420,8 +420,8 @@ def batch_table(solver, dev, H, W, ratio, sizes=(6, 12, 24, 48), T=ACTION_PACK, 
 
 
 def fp32_mode(params, data, actions, dev, B, H, W, steps, warmup):
-    """The exact-fp32 MFMA convolution family (conv_mode 0, csrc/conv3x3.hip; arithmetic identical in kind to the
-    reference's fp32) on the same episode with the same --steps / --warmup as the headline, and its own roofline against
+    """The fp32 MFMA convolution family (conv_mode 0: csrc/conv3x3_wino.hip on the >= 64-channel layers, csrc/conv3x3.hip on
+    the rest; fp32 arithmetic throughout, like the reference's) on the same episode with the same --steps / --warmup as the headline, and its own roofline against
     the 157.3 TF/s fp32-MFMA peak (profiles/r3_bench_kernel_stats_fp32.md is the rocprofv3 summary of this leg)."""
     den = UNetDenoiser2D(state_dict=params, conv_mode=0)
     env = CSMRIEnv(None, ADMMSolver_CSMRI(den), max_episode_step=N_POLICY_STEPS)
@@ -433,23 +433,34 @@ def fp32_mode(params, data, actions, dev, B, H, W, steps, warmup):
     for _ in range(max(1, warmup)):
         episode()
     torch.cuda.synchronize()
+    sampler = PowerSampler()
     t0 = time.perf_counter()
     for _ in range(steps):
         episode()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    power = sampler.stop()
     x = env.state["output"].detach().clone()
     sigma = actions[-1]["sigma_d"][:, -1].contiguous()
     whole_ms, shares, conv_fl, _ = forward_split(den, dev, x, sigma, n_fwd=6)
-    conv_ms = whole_ms * shares.get("conv3x3", 0.0)
+    conv_ms = whole_ms * (shares.get("conv3x3", 0.0) + shares.get("conv3x3_wino", 0.0))
     tf = conv_fl / (conv_ms * 1e-3) / 1e12
+    # FLOPs the matrix pipe executes: the Winograd layers (>= 64 channels, sizes divisible by 16) do 16 products per 2x2 outputs, not 36
+    wino_fl = sum(f for name, _, f in ops.unet_profile(den.context(dev), x, sigma) if name == "conv3x3_wino")
+    executed = conv_fl - wino_fl * (1.0 - 16.0 / 36.0)
+    tf_exec = executed / (conv_ms * 1e-3) / 1e12
     return {"value": N_POLICY_STEPS * ACTION_PACK / dt, "unit": "iters/s", "steps": steps, "warmup": max(1, warmup),
-            "ms_per_step": 1e3 * dt, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 FMA chain)",
+            "ms_per_step": 1e3 * dt, "dtype": "f32 (v_mfma_f32_32x32x2_f32; Winograd F(2x2,3x3) on the >= 64-channel layers)",
             "iters_per_s": N_POLICY_STEPS * ACTION_PACK / dt,
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (27 launches per denoiser forward)",
-                         "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / PEAK_FP32_MFMA_TFLOPS, "conv_ms_per_forward": conv_ms,
-                         "denoiser_ms_per_forward": whole_ms, "traffic": None}}
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_f32_kernel + conv3x3_mfma_kernel (27 launches per denoiser forward)",
+                         "achieved": tf_exec, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf_exec / PEAK_FP32_MFMA_TFLOPS,
+                         "achieved_note": "EXECUTED MFMA FLOPs / time (the honest utilisation of the fp32 matrix pipe); the "
+                                          "algorithmic rate of the same launches is `algorithmic_tflops`",
+                         "algorithmic_tflops": tf, "algorithmic_flops_per_forward": conv_fl,
+                         "executed_mfma_flops_per_forward": executed,
+                         "conv_ms_per_forward": conv_ms,
+                         "denoiser_ms_per_forward": whole_ms, "traffic": None, "power": power}}
 
 
 def pmc_traffic(B, H, W):

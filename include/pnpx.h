@@ -49,7 +49,11 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx);
 int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
 /* Options (the library reads no environment variables).
  *  "conv_mode": 1 (default) = half-split f16 MFMA convolutions (fp32-class accuracy, 3 MFMAs per product,
- *      csrc/conv_hs.hip); 0 = plain fp32 MFMA convolutions (csrc/conv3x3.hip).  Both meet the 1e-4 bar.
+ *      csrc/conv_hs.hip); 0 = plain fp32 MFMA convolutions (csrc/conv3x3.hip, and csrc/conv3x3_wino.hip for the layers
+ *      "fp32_winograd" covers).  Both meet the 1e-4 bar.
+ *  "fp32_winograd" (default 1): in conv_mode 0, layers with cout % 64 == 0 (sources % 16, H and W % 16) or cout % 32 == 0
+ *      (sources % 8, H % 16, W % 32) run as Winograd F(2x2,3x3) in fp32 (1.3-1.8x per layer; 7e-7 from the fp64 oracle where
+ *      the direct kernel is 1.1e-6 -- same accuracy class, different summation order).  0 = the direct kernel on every layer.
  *  "range_guard": the half-split kernels carry activations as f16 hi+lo pairs of 16*v, i.e. |v| < 4095.  Their
  *      epilogues set a sticky flag when a stored value leaves that range or is NaN.
  *      1 (default): the flag is looked at (no synchronisation) at the top of the next call; once seen, the context

@@ -236,6 +236,10 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_fft_tile = value;
     return PNPX_OK;
   }
+  if (is("fp32_winograd") && (value == 0 || value == 1)) {
+    ctx->opt_fp32_winograd = value;
+    return PNPX_OK;
+  }
   if (is("fft_fast") && (value == 0 || value == 1)) {
     ctx->opt_fft_fast = value;
     return PNPX_OK;
@@ -300,6 +304,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("policy_s2_hs")) *value = ctx->opt_policy_s2_hs;
   else if (is("fft_affine")) *value = ctx->opt_fft_affine;
   else if (is("fft_fast")) *value = ctx->opt_fft_fast;
+  else if (is("fp32_winograd")) *value = ctx->opt_fp32_winograd;
   else if (is("fft_tile")) *value = ctx->opt_fft_tile;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
   else if (is("train_cache_gb")) *value = ctx->opt_train_cache_gb;
@@ -380,6 +385,21 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
     ctx->conv[i].cout = L[i].cout;
     ctx->conv[i].mt = mt;
     ctx->conv[i].cc = cc;
+  }
+  // Winograd F(2x2,3x3) transformed weights for the fp32 family (conv3x3_wino.hip), layers conv3x3_wino_packs() accepts
+  size_t uoff[27];
+  {
+    const float* wsrc = params_host;
+    for (int i = 0; i < 27; ++i) {
+      uoff[i] = 0;
+      if (conv3x3_wino_packs(L[i].cout, L[i].cin)) {
+        align();
+        uoff[i] = host.size();
+        host.resize(host.size() + conv3x3_wino_floats(L[i].cout, L[i].cin));
+        pack_conv_weights_wino(wsrc, L[i].cout, L[i].cin, host.data() + uoff[i]);
+      }
+      wsrc += (size_t)L[i].cin * L[i].cout * 9 + L[i].cout;
+    }
   }
   // half-split (f16 hi/lo) packing of the same convolutions for conv_hs.hip
   size_t hoff[27];
@@ -473,6 +493,7 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
   for (int i = 0; i < 27; ++i) {
     ctx->conv[i].w = d + woff[i];
     ctx->conv[i].b = d + boff[i];
+    ctx->conv_wino_u[i] = uoff[i] ? d + uoff[i] : nullptr;
     ctx->conv_hs[i].w = reinterpret_cast<char*>(d + hoff[i]);
     ctx->conv_bwd[i].w = d + toff[i];
     ctx->conv_bwd[i].b = nullptr;

@@ -183,6 +183,8 @@ struct pnpx_ctx {
   unsigned* range_flag_host = nullptr;   // pinned host allocation
   unsigned* range_flag_dev = nullptr;    // its device address
   bool range_tripped = false;            // latched by the host once the flag was seen set (cleared by set_option)
+  float* conv_wino_u[27] = {};     // Winograd-transformed fp32 weights of the layers conv3x3_wino.hip can run (else null)
+  int opt_fp32_winograd = 1;       // conv_mode 0: run those layers as F(2x2,3x3) (fp32 arithmetic, 2.25x fewer MFMAs; 0 = the direct kernel everywhere)
   pnpx::ConvLayer conv_bwd[27];    // adjoint (input-gradient) convolutions, fp32 kernel family
   pnpx::ConvLayerHsDev conv_hs_bwd[27];  // ... and packed for the half-split kernel family
   float* zero_bias = nullptr;      // [768] zeros (bias operand of the adjoint convolutions)

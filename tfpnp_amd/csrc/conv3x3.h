@@ -34,6 +34,15 @@ int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const
                         hipStream_t s, const char* dmask_hs = nullptr);
 // w[cout][cin][3][3] -> packed weights of the adjoint convolution: wt[ci][co][tap] = w[co][ci][8 - tap], with the
 // adjoint's output channels (= cin) zero-padded to cout_pad.
+// Winograd F(2x2, 3x3) variant of the same layer on the fp32 MFMA (conv3x3_wino.hip; option fp32_winograd).  cout a multiple of 64:
+// both sources multiples of 16 channels, H and W multiples of 16; otherwise cout a multiple of 32: sources multiples of 8 channels,
+// H a multiple of 16, W of 32.  u: pack_conv_weights_wino's output.
+bool conv3x3_wino_ok(int C0, int C1, int cout, int H, int W);
+bool conv3x3_wino_packs(int cout, int cin);   // the layer gets Winograd weights at load time
+size_t conv3x3_wino_floats(int cout, int cin);
+void pack_conv_weights_wino(const float* w, int cout, int cin, float* dst);
+int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
+                        float* out, int B, int H, int W, hipStream_t s);
 void pack_conv_weights_transposed(const float* w, int cout, int cin, int cout_pad, int mt, int cc, float* dst);
 
 }  // namespace pnpx

@@ -1,0 +1,501 @@
+// Winograd F(2x2, 3x3) on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) for the 3x3 layers of the fp32 kernel family with cout % 32 == 0
+// (option fp32_winograd; conv_mode 0 layouts: padded planar fp32 activations, common.h).
+//
+// Replaces the same Conv2d 3x3 + bias + LeakyReLU layers as conv3x3.hip (tfpnp/pnp/denoiser/models/unet.py:8-31) with 16 instead
+// of 36 multiplications per 2x2 output tile.  The round-4 probe of the same algebra on the half-split f16 kernel lost
+// (profiles/r4_winograd_probe.md): there a product costs 6 matrix-pipe clocks per k-value and the input transform (fp32 VALU plus
+// the hi/lo re-split) and the LDS traffic of 16 positions (~135 KB per stage) bound the stage, not the MFMAs.  Here a product
+// costs 32 clocks per k-value: a pipeline stage is 2048 clocks of matrix work against the SAME ~1000 clocks of LDS traffic and
+// ~300 of VALU, so the MFMA count is what counts -- PROVIDED the side work is issued between the MFMAs (stage()).
+//
+// Dataflow, 64-cout tile (Cfg<64>; Cfg<32> differs in the constants only -- see Cfg).  One workgroup = 4 waves, one per SIMD;
+// 64 couts x 64 tiles = a 16 x 16-pixel region; persistent, XCD-grouped walk:
+//   wave (wm, wn) owns cout block wm x tile block wn and all 16 Winograd positions: 16 accumulators of 32 x 32 = all 256 AGPRs,
+//   addressed by name from inline assembly (see below).
+//   K is walked in chunks of 16 input channels, a chunk in four stages (position rows a = 0..3; 4 positions x 8 MFMAs per wave).
+//   Per stage the transformed weights U[a][0..3] of the chunk (16 KiB, packed on the host from an fp64 transform) arrive by 16-byte
+//   LDS-DMA three stages ahead (ring of 4); the raw 18 x 18 x 16-channel halo of the NEXT chunk arrives by dword LDS-DMA gather
+//   during stage 0 (two buffers); V[a][0..3] = row a of B^T d B is computed by all 256 threads one stage ahead (constants +-1).
+//   MFMA k-slot (lane half kg, step m) = input channel 8 kg + m of the chunk, for A and B alike, so a lane's 8 operands per position
+//   are two ds_read_b128 each.  Output transform A^T M A in registers, bias + LeakyReLU, 8-byte stores.
+//
+// Measured (B = 48, 256 x 256, profiles/r4_fp32_winograd.md): 1.4 - 1.8x over conv3x3.hip on the 64-cout-tile layers (e.g. 256 -> 256
+// at 32 x 32: 0.469 -> 0.272 ms), 1.3 - 1.4x on the 32-cout-tile (full-resolution) layers; all 27 convolutions 15.4 -> 10.1 ms
+// (184 TF/s algorithmic against the 157 TF/s fp32 MFMA peak).  Relative error vs the fp64 oracle 7e-7 (direct kernel: 1.1e-6;
+// fewer, shorter sums).
+#include <cmath>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+#include "conv3x3.h"
+
+namespace pnpx {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Two tile shapes.  CT = couts per workgroup tile:
+//   CT 64: region 16 x 16 px = 64 tiles, K chunks of 16 channels, waves 2 (cout blocks) x 2 (tile blocks), 32 MFMAs per stage
+//   CT 32: region 16 x 32 px = 128 tiles, K chunks of  8 channels, waves 1 x 4 (tile blocks),             16 MFMAs per stage
+// (a 32-cout tile with 16-channel chunks would need 174 KB of LDS for its 128-tile halo and V buffers).  V is 16 KiB per stage in both.
+template <int CT_>
+struct Cfg {
+  static constexpr int CT = CT_;
+  static constexpr int CK = (CT == 64) ? 16 : 8;          // input channels per chunk
+  static constexpr int HALVES = CK / 8;                   // 16-byte operand reads per position and operand
+  static constexpr int KS = CK / 2;                       // MFMA k-steps per position
+  static constexpr int NM = 4 * KS;                       // MFMAs per stage and wave
+  static constexpr int RPXW = (CT == 64) ? 16 : 32;       // region width in pixels (height 16)
+  static constexpr int TX = RPXW / 2, NT = 8 * TX;        // tiles per row, per region
+  static constexpr int RW = RPXW + 2, RPX = 18 * RW;      // raw halo
+  static constexpr int RAW_ELEMS = CK * RPX;
+  static constexpr int RAW_INSTR = (RAW_ELEMS + 63) / 64; // dword gathers of 64 lanes: 81 / 77
+  static constexpr int RAW_BYTES = RAW_INSTR * 256;
+  static constexpr int RAW_PER_WAVE = (RAW_INSTR + 3) / 4;
+  static_assert(RAW_INSTR % 4 == 1, "wave 0 issues one gather more than the others");
+  static constexpr int UQ = 16 * CK * CT;                 // bytes of one stage's weights: 4 positions x CK x CT floats
+  static constexpr int NUW = UQ / 4096;                   // 16-byte LDS-DMA instructions per wave and stage: 4 / 1
+  static constexpr int VQ = 16384, NU = 4;
+  static constexpr int OFF_U = 0, OFF_V = NU * UQ, OFF_RAW = OFF_V + 2 * VQ;
+  static constexpr int LDS_USED = OFF_RAW + 2 * RAW_BYTES;   // 139776 / 88576
+  // side-work slots behind the MFMAs of a stage (stage()): transform slices per slot, weight-DMA slot, halo gathers per slot
+  static constexpr int TS = (CT == 64) ? 1 : 2;
+  static constexpr int U_SLOT = NM / 2;
+  static constexpr int RPS = (CT == 64) ? 2 : 3;
+  static_assert(2 + 12 / TS <= U_SLOT && (NM - U_SLOT - 1) * RPS >= RAW_PER_WAVE, "side work fits behind the MFMAs");
+};
+constexpr int LDS_REQ = 160 * 1024;                 // the whole CU (see conv_hs_kernel.h: no LDS-using neighbours)
+
+struct WinoArgs {
+  const float* in0;
+  const float* in1;
+  const float* u;      // [cout/CT][cin/CK][a 4][b 4][kg 2][half][m CT][4] fp32
+  const float* bias;
+  float* out;
+  int B, H, W, Hp, Wp, C0, C1, Cout, nct, nch, rx, ry;
+  float slope;
+};
+
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the builtin widens every lane offset to a
+// 64-bit VGPR pair (21 + 4 pairs live across the whole kernel here), which is what pushed this kernel into scratch
+__device__ __forceinline__ void glds4(const void* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// accumulator IDX (0..15) = AGPRs 16 * IDX .. 16 * IDX + 15, by name
+#define WINO_MFMA(IDX, x, y) \
+  asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(x), "v"(y), "n"(16 * (IDX)), "n"(16 * (IDX) + 15))
+#define WINO_MFMA_FROM_ZERO(IDX, x, y) \
+  asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, 0" ::"v"(x), "v"(y), "n"(16 * (IDX)), "n"(16 * (IDX) + 15))
+
+template <int CT>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
+  using C = Cfg<CT>;
+  constexpr int CK = C::CK, HALVES = C::HALVES, KS = C::KS, NM = C::NM, TX = C::TX, NT = C::NT, RW = C::RW, RPX = C::RPX;
+  constexpr int RAW_ELEMS = C::RAW_ELEMS, RAW_BYTES = C::RAW_BYTES, RAW_PER_WAVE = C::RAW_PER_WAVE;
+  constexpr int UQ = C::UQ, NUW = C::NUW, VQ = C::VQ, OFF_U = C::OFF_U, OFF_V = C::OFF_V, OFF_RAW = C::OFF_RAW;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int HpWp = a.Hp * a.Wp;
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+  const int nregions = a.rx * a.ry * a.B;
+  const int nx = (gridDim.x % 8 == 0 && nregions >= 32) ? 8 : 1;       // XCD-grouped walk as conv_hs (siblings share the halo in L2)
+  const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx, nslot = gridDim.x / nx;
+
+  struct Tile {
+    int ct, b, x0, y0;
+    const float* s0;   // halo origin in channel 0 of the first source
+    const float* s1;   // ... of the second source, pre-offset by -C0 channels
+    const float* w;
+    bool ok;
+  };
+  auto decode = [&](int k) {
+    Tile T;
+    const int j = slot + nslot * k;
+    const int q = j / a.nct;
+    T.ct = j - q * a.nct;
+    const int reg = nx * q + xcd;
+    T.ok = reg < nregions;
+    const int t1 = reg / a.rx;
+    const int tx = reg - t1 * a.rx;
+    const int t2 = t1 / a.ry;
+    const int ty = t1 - t2 * a.ry;
+    T.b = t2;
+    T.x0 = tx * C::RPXW;
+    T.y0 = ty * 16;
+    const size_t pix = (size_t)T.y0 * a.Wp + T.x0 + (PADL - 1);
+    T.s0 = a.in0 + (size_t)T.b * a.C0 * HpWp + pix;
+    T.s1 = a.in1 + ((long long)T.b * a.C1 - a.C0) * (long long)HpWp + (long long)pix;
+    T.w = a.u + (size_t)T.ct * a.nch * 4 * (UQ / 4);
+    return T;
+  };
+
+  // byte offsets of this lane's halo elements from the chunk's origin: unsigned 32-bit, so the gather is one SGPR base + one VGPR each
+  unsigned roff[RAW_PER_WAVE];
+#pragma unroll
+  for (int k = 0; k < RAW_PER_WAVE; ++k) {
+    const int idx = (wave + 4 * k) * 64 + lane;
+    const int c = idx / RPX, r = idx - c * RPX;
+    const int hy = r / RW, hx = r - hy * RW;
+    roff[k] = (idx < RAW_ELEMS) ? 4u * (unsigned)(c * HpWp + hy * a.Wp + hx) : 0u;
+  }
+  auto issue_raw = [&](const float* s0, const float* s1, int c, int rbuf) {
+    const float* src = ((CK * c < a.C0) ? s0 : s1) + (size_t)CK * c * HpWp;
+    const unsigned dst = lds0 + OFF_RAW + rbuf * RAW_BYTES + wave * 256;
+#pragma unroll
+    for (int k = 0; k < RAW_PER_WAVE; ++k)
+      if (k < RAW_PER_WAVE - 1 || wave == 0) glds4(src, roff[k], dst + k * 1024);
+  };
+  const unsigned uoff = lane * 16u;
+  auto issue_u = [&](const float* w, int c, int aa) {
+    const float* s = w + ((size_t)c * 4 + aa) * (UQ / 4) + wave * 256;
+#pragma unroll
+    for (int k = 0; k < NUW; ++k) glds16(s + k * 1024, uoff, lds0 + OFF_U + aa * UQ + (wave + 4 * k) * 1024);
+  };
+
+  // transform role: one tile and 4 channels of the chunk per thread.  CT 64: tile = lane, channels 8 * tkg + 4 * thf .. + 3 by wave;
+  // CT 32: tile = tid & 127, channels 4 * tkg .. + 3 with tkg = tid >> 7
+  const int tt = (CT == 64) ? lane : (tid & 127);
+  const int tkg = (CT == 64) ? (wave & 1) : (wave >> 1), thf = (CT == 64) ? (wave >> 1) : 0;
+  const int tty = tt / TX, ttx = tt % TX;
+  const int t_rd = (((tkg * (CK / 2) + thf * 4) * RPX) + (2 * tty) * RW + 2 * ttx) * 4;
+  const int t_wr = (((tkg * HALVES + thf) * NT) + tt) * 16;          // + b * 4096
+
+  const int wm = (CT == 64) ? (wave & 1) : 0, wn = (CT == 64) ? (wave >> 1) : wave;
+  const int l31 = lane & 31, kg = lane >> 5;
+  const int a_lane = ((kg * HALVES) * CT + wm * 32 + l31) * 16;      // + half * CT * 16 + b * UQ / 4
+  const int b_lane = ((kg * HALVES) * NT + wn * 32 + l31) * 16;      // + half * NT * 16 + b * 4096
+  // The 16 accumulators (position (A, b) = AGPRs 16 * (4 A + b) .. + 15, all 256) are addressed by NAME from inline assembly.
+  // As C++ values the register allocator split their live ranges across VGPRs and scratch (161 spills, reloads inside every
+  // stage); by name they never move.  The compiler must not use AGPRs itself: it has no reason to while the kernel's VGPR
+  // demand stays far below 256 (167 here; check after a change: no v_accvgpr_* outside the ASM blocks of the ISA, no spills),
+  // and the clobber below makes the kernel descriptor allocate all 256 (.agpr_count in the code object's metadata).
+  asm volatile("" ::: "a0", "a255");
+
+  // the work of one transform (row TA of B^T d B for this thread's tile and 4 channels -> V[vbuf][0..3]), cut into 12 slices that
+  // stage() drops between its MFMAs: 4 x (8 halo reads), 4 x (4 adds), 4 x (4 adds + one 16-byte write)
+  struct Tr {
+    float d[2][4][4];   // [row RA / RB][channel][x]
+    float r[4][4];      // [x][channel]
+  };
+  auto transform_slice = [&](auto ta_tag, int sl, Tr& t, int rbuf, int vbuf) {
+    constexpr int A = decltype(ta_tag)::value;
+    constexpr int RA = (A == 0) ? 0 : (A == 2 ? 2 : 1);
+    constexpr int RB = (A == 0) ? 2 : (A == 1 ? 2 : (A == 2 ? 1 : 3));
+    if (sl < 4) {
+      const int e = sl;
+      const char* rb = lds + OFF_RAW + rbuf * RAW_BYTES + t_rd;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        t.d[0][e][x] = *reinterpret_cast<const float*>(rb + (e * RPX + RA * RW + x) * 4);
+        t.d[1][e][x] = *reinterpret_cast<const float*>(rb + (e * RPX + RB * RW + x) * 4);
+      }
+    } else if (sl < 8) {
+      const int e = sl - 4;
+#pragma unroll
+      for (int x = 0; x < 4; ++x)      // rows of B^T: d0 - d2, d1 + d2, d2 - d1, d1 - d3
+        t.r[x][e] = (A == 1) ? t.d[0][e][x] + t.d[1][e][x] : t.d[0][e][x] - t.d[1][e][x];
+    } else {
+      const int bb = sl - 8;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = (bb == 0) ? t.r[0][e] - t.r[2][e] : (bb == 1) ? t.r[1][e] + t.r[2][e] : (bb == 2) ? t.r[2][e] - t.r[1][e] : t.r[1][e] - t.r[3][e];
+      *reinterpret_cast<f32x4*>(lds + OFF_V + vbuf * VQ + t_wr + bb * 4096) = v;
+    }
+  };
+  // the whole transform at once (prologue only)
+  auto transform = [&](auto ta_tag, int rbuf, int vbuf) {
+    Tr t;
+#pragma unroll
+    for (int sl = 0; sl < 12; ++sl) transform_slice(ta_tag, sl, t, rbuf, vbuf);
+  };
+
+  // One pipeline stage = position row A: 32 MFMAs per wave (4 positions x 8 k-steps), issued one at a time with a slice of the
+  // stage's other work behind each so that the matrix pipe (64 clocks per MFMA) never waits for the wave's VALU / LDS / DMA issue:
+  //   before MFMA 0     A/B operands of positions 0, 1                                   (8 ds_read_b128)
+  //   MFMA  0 ..  1     A/B operands of positions 2, 3                                   (8 ds_read_b128)
+  //   MFMA  2 .. 13     the transform of the NEXT stage's V (row TA), 12 slices
+  //   MFMA 16           this stage's weight slice by LDS-DMA                              (4 x 16 B per lane)
+  //   MFMA 17 .. 27     the next chunk's halo by LDS-DMA (stage 0 only)                   (2 dword gathers each)
+  // The fences pin that order; left alone the scheduler puts all the side work first and the MFMAs in one block behind it.
+  // (No run-time conditions in here: a stage has to stay ONE basic block, or the compiler peels and unswitches the chunk loop into
+  //  versions with a branch behind every MFMA, and the first chunk of every tile ran ~6x slower than the others.)
+  struct Side {
+    int t_rbuf, t_vbuf;    // transform row TA of halo buffer t_rbuf into V[t_vbuf]
+    const float* u_src;    // weight slice u_src -> ring slot u_slot
+    int u_slot;
+    const float* raw_src;  // RAW stages: halo of the chunk at raw_src -> halo buffer raw_buf
+    int raw_buf;
+  };
+  auto stage = [&](auto a_tag, auto ta_tag, auto raw_tag, auto zero_tag, const Side& sd) {
+    constexpr int A = decltype(a_tag)::value;
+    constexpr bool RAW = decltype(raw_tag)::value;
+    constexpr bool ZERO = decltype(zero_tag)::value;   // first chunk of a tile: the first MFMA of each position starts from C = 0
+    const char* ua = lds + OFF_U + A * UQ + a_lane;
+    const char* vb = lds + OFF_V + (A & 1) * VQ + b_lane;
+    f32x4 af[4][HALVES], bf[4][HALVES];
+    Tr t;
+    auto operands = [&](int b) {
+#pragma unroll
+      for (int h = 0; h < HALVES; ++h) {
+        af[b][h] = *reinterpret_cast<const f32x4*>(ua + b * (UQ / 4) + h * (CT * 16));
+        bf[b][h] = *reinterpret_cast<const f32x4*>(vb + b * 4096 + h * (NT * 16));
+      }
+    };
+    operands(0);
+    operands(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair)
+#pragma unroll
+      for (int m = 0; m < KS; ++m)
+#pragma unroll
+        for (int bl = 0; bl < 2; ++bl) {
+          const int b = 2 * pair + bl;
+          const int sl = pair * (2 * KS) + m * 2 + bl;
+          {
+            const float x = af[b][m >> 2][m & 3], y = bf[b][m >> 2][m & 3];
+            const bool from_zero = ZERO && m == 0;
+            switch (b) {
+              case 0: if (from_zero) WINO_MFMA_FROM_ZERO(4 * A + 0, x, y); else WINO_MFMA(4 * A + 0, x, y); break;
+              case 1: if (from_zero) WINO_MFMA_FROM_ZERO(4 * A + 1, x, y); else WINO_MFMA(4 * A + 1, x, y); break;
+              case 2: if (from_zero) WINO_MFMA_FROM_ZERO(4 * A + 2, x, y); else WINO_MFMA(4 * A + 2, x, y); break;
+              default: if (from_zero) WINO_MFMA_FROM_ZERO(4 * A + 3, x, y); else WINO_MFMA(4 * A + 3, x, y); break;
+            }
+          }
+          if (sl < 2) operands(2 + sl);
+          else if (sl < 2 + 12 / C::TS) {
+#pragma unroll
+            for (int q = 0; q < C::TS; ++q) transform_slice(ta_tag, (sl - 2) * C::TS + q, t, sd.t_rbuf, sd.t_vbuf);
+          } else if (sl == C::U_SLOT) {
+            const float* s = sd.u_src + wave * 256;
+#pragma unroll
+            for (int k = 0; k < NUW; ++k) glds16(s + k * 1024, uoff, lds0 + OFF_U + sd.u_slot * UQ + (wave + 4 * k) * 1024);
+          } else if (sl > C::U_SLOT) {
+            if (RAW) {
+              const unsigned dst = lds0 + OFF_RAW + sd.raw_buf * RAW_BYTES + wave * 256;
+#pragma unroll
+              for (int k = C::RPS * (sl - C::U_SLOT - 1); k < C::RPS * (sl - C::U_SLOT); ++k)
+                if (k < RAW_PER_WAVE - 1 || (k == RAW_PER_WAVE - 1 && wave == 0)) glds4(sd.raw_src, roff[k], dst + k * 1024);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+  };
+
+  auto epilogue = [&](const Tile& T) {
+    const int tile = wn * 32 + l31, ty = tile / TX, tx = tile % TX;
+    const int cbase = T.ct * CT + wm * 32 + 4 * kg;              // C layout: row = (r & 3) + 8 * (r >> 2) + 4 * kg
+    float* ob = a.out + ((size_t)T.b * a.Cout) * HpWp + (size_t)(T.y0 + 2 * ty + 1) * a.Wp + T.x0 + 2 * tx + PADL;
+    // the last MFMAs were issued before the stage's closing barrier; their results must have left the matrix pipe before an
+    // AGPR read (a software-visible hazard on gfx950 that the compiler cannot see through the named registers)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = a.bias[cbase + (r & 3) + 8 * (r >> 2)];
+    static_for<16>([&](auto r_tag) {
+      constexpr int R = decltype(r_tag)::value;
+      float t0[4], t1[4];
+      static_for<4>([&](auto i_tag) {
+        constexpr int I = decltype(i_tag)::value;
+        float m0, m1, m2, m3;
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(m0) : "n"(16 * (4 * I + 0) + R));
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(m1) : "n"(16 * (4 * I + 1) + R));
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(m2) : "n"(16 * (4 * I + 2) + R));
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(m3) : "n"(16 * (4 * I + 3) + R));
+        t0[I] = m0 + m1 + m2;
+        t1[I] = m1 - m2 - m3;
+      });
+      const int co = cbase + (R & 3) + 8 * (R >> 2);
+      const float bias = bias_r[R];
+      float y00 = t0[0] + t0[1] + t0[2] + bias, y10 = t0[1] - t0[2] - t0[3] + bias;
+      float y01 = t1[0] + t1[1] + t1[2] + bias, y11 = t1[1] - t1[2] - t1[3] + bias;
+      y00 = y00 > 0.f ? y00 : y00 * a.slope;
+      y01 = y01 > 0.f ? y01 : y01 * a.slope;
+      y10 = y10 > 0.f ? y10 : y10 * a.slope;
+      y11 = y11 > 0.f ? y11 : y11 * a.slope;
+      float* o = ob + (size_t)co * HpWp;
+      *reinterpret_cast<f32x2*>(o) = (f32x2){y00, y01};
+      *reinterpret_cast<f32x2*>(o + a.Wp) = (f32x2){y10, y11};
+    });
+  };
+
+  auto sync_all = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  // end of a stage: this wave's LDS-DMA for the NEXT stage (and, at a = 2, the next chunk's halo) has landed -- a counted wait:
+  // N = VMEM operations issued after it (younger weight slices, halo pieces, the previous tile's stores) that may stay in flight
+  auto sync_counted = [&](auto n_tag) {
+    constexpr int N = decltype(n_tag)::value;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __syncthreads();
+  };
+  constexpr int NST = 32;                  // 8-byte stores per wave and tile
+  constexpr int NRAW = RAW_PER_WAVE - 1;   // halo gathers per wave (wave 0 issues one more: counted conservatively)
+
+  int k = 0;
+  Tile T = decode(0);
+  if (!T.ok) return;
+  issue_raw(T.s0, T.s1, 0, 0);
+  issue_u(T.w, 0, 0);
+  issue_u(T.w, 0, 1);
+  issue_u(T.w, 0, 2);
+  sync_all();
+  transform(std::integral_constant<int, 0>{}, 0, 0);
+  sync_all();
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using Yes = std::true_type;
+  using No = std::false_type;
+  // One chunk of 16 input channels = four stages.  FIRST: the chunk follows an epilogue, whose NST stores sit in the VMEM queue
+  // between the weight slices of the previous stage and this one's.  "n" names the chunk after this one (in the next tile after a
+  // tile's last chunk; after the very last chunk of the walk it is this tile's chunk 0 again: the loads land in buffers nobody reads,
+  // which costs one chunk of DMA per workgroup and keeps every stage free of conditions).
+  auto chunk = [&](auto first_tag, const float* w_c, const float* nu, const float* nraw, int rcur) {
+    constexpr int EPI = decltype(first_tag)::value ? NST : 0;
+    const int rnext = rcur ^ 1;
+    stage(I0{}, I1{}, Yes{}, first_tag, Side{rcur, 1, w_c + 3 * (UQ / 4), 3, nraw, rnext});
+    sync_counted(std::integral_constant<int, NUW + EPI + NUW + NRAW>{});
+    stage(I1{}, I2{}, No{}, first_tag, Side{rcur, 0, nu, 0, nullptr, 0});
+    sync_counted(std::integral_constant<int, EPI + NUW + NRAW + NUW>{});
+    stage(I2{}, I3{}, No{}, first_tag, Side{rcur, 1, nu + (UQ / 4), 1, nullptr, 0});
+    sync_counted(std::integral_constant<int, 2 * NUW>{});
+    stage(I3{}, I0{}, No{}, first_tag, Side{rnext, 0, nu + 2 * (UQ / 4), 2, nullptr, 0});
+    sync_counted(std::integral_constant<int, 2 * NUW>{});
+  };
+  auto raw_of = [&](const Tile& X, int c) { return ((CK * c < a.C0) ? X.s0 : X.s1) + (size_t)CK * c * HpWp; };
+
+  int cc = 0;
+  for (;;) {
+    Tile Tn = decode(k + 1);
+    const bool more = Tn.ok;
+    if (!more) Tn = T;
+    for (int c = 0; c < a.nch; ++c, ++cc) {
+      const bool last_c = (c == a.nch - 1);
+      const float* w_c = T.w + (size_t)c * 4 * (UQ / 4);
+      const float* nu = last_c ? Tn.w : w_c + 4 * (UQ / 4);
+      const float* nraw = last_c ? raw_of(Tn, 0) : raw_of(T, c + 1);
+      if (c == 0) chunk(Yes{}, w_c, nu, nraw, cc & 1);
+      else chunk(No{}, w_c, nu, nraw, cc & 1);
+    }
+    epilogue(T);
+    if (!more) break;
+    T = Tn;
+    ++k;
+  }
+  sync_all();   // the surplus loads of the last chunk
+}
+
+}  // namespace
+
+// cout tile of a layer: 64 where it divides, else 32; 0 = the direct kernel (conv3x3.hip) runs the layer
+static int wino_ct(int C0, int C1, int cout, int H, int W) {
+  if (C0 <= 0 || H < 16 || H % 16 != 0) return 0;
+  if (cout % 64 == 0) return (C0 % 16 == 0 && C1 % 16 == 0 && W % 16 == 0) ? 64 : 0;   // (the packing follows cout alone)
+  if (cout % 32 == 0) return (C0 % 8 == 0 && C1 % 8 == 0 && W % 32 == 0) ? 32 : 0;
+  return 0;
+}
+bool conv3x3_wino_ok(int C0, int C1, int cout, int H, int W) { return wino_ct(C0, C1, cout, H, W) != 0; }
+
+bool conv3x3_wino_packs(int cout, int cin) { return (cout % 64 == 0 && cin % 16 == 0) || (cout % 32 == 0 && cin % 8 == 0); }
+
+size_t conv3x3_wino_floats(int cout, int cin) { return (size_t)cout * cin * 16; }
+
+// w[cout][cin][3][3] -> U = G g G^T in fp64 -> [cout/CT][cin/CK][a][b][kg 2][half][m CT][4] fp32, CT = 64 (CK 16) where 64 divides
+// cout, else 32 (CK 8): the tile shape is a property of the layer, so one packing per layer
+void pack_conv_weights_wino(const float* w, int cout, int cin, float* dst) {
+  static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  const int CT = (cout % 64 == 0) ? 64 : 32, CK = (CT == 64) ? 16 : 8, HALVES = CK / 8;
+  const int nct = cout / CT, nch = cin / CK;
+  for (int ct = 0; ct < nct; ++ct)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int m = 0; m < CT; ++m)
+        for (int kgi = 0; kgi < 2; ++kgi)
+          for (int hf = 0; hf < HALVES; ++hf)
+            for (int e = 0; e < 4; ++e) {
+              const int co = ct * CT + m, ci = ch * CK + kgi * (CK / 2) + hf * 4 + e;
+              const float* g = w + ((size_t)co * cin + ci) * 9;
+              for (int aa = 0; aa < 4; ++aa)
+                for (int bb = 0; bb < 4; ++bb) {
+                  double s = 0;
+                  for (int k2 = 0; k2 < 3; ++k2)
+                    for (int l = 0; l < 3; ++l) s += G[aa][k2] * (double)g[k2 * 3 + l] * G[bb][l];
+                  const size_t o = ((((((size_t)ct * nch + ch) * 4 + aa) * 4 + bb) * 2 + kgi) * HALVES + hf) * CT * 4 + (size_t)m * 4 + e;
+                  dst[o] = (float)s;
+                }
+            }
+}
+
+template <int CT>
+static int launch_wino(WinoArgs a, hipStream_t s) {
+  using C = Cfg<CT>;
+  a.nct = a.Cout / CT;
+  a.nch = (a.C0 + a.C1) / C::CK;
+  a.rx = a.W / C::RPXW;
+  a.ry = a.H / 16;
+  static bool attr_done[64] = {};
+  int dev = 0;
+  PNPX_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+    PNPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ));
+    attr_done[dev] = true;
+  }
+  const long long ntiles = (long long)a.rx * a.ry * a.B * a.nct;
+  long long grid = 256;
+  if (grid >= ntiles) grid = ntiles;
+  else if ((grid / 8) % a.nct != 0 && grid >= 8LL * a.nct) grid -= grid % (8 * a.nct);
+  hipLaunchKernelGGL(conv3x3_wino_f32_kernel<CT>, dim3((unsigned)grid), dim3(256), LDS_REQ, s, a);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+
+int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
+                        float* out, int B, int H, int W, hipStream_t s) {
+  const int ct = wino_ct(C0, C1, cout, H, W);
+  if (!ct) {
+    set_error("conv3x3_wino: unsupported geometry (%d + %d -> %d channels, %d x %d)", C0, C1, cout, H, W);
+    return PNPX_ERR_SHAPE;
+  }
+  WinoArgs a;
+  a.in0 = in0;
+  a.in1 = in1 ? in1 : in0;
+  a.u = u;
+  a.bias = bias;
+  a.out = out;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.Hp = padded_h(H);
+  a.Wp = padded_w(W);
+  a.C0 = C0;
+  a.C1 = C1;
+  a.Cout = cout;
+  a.slope = 0.2f;
+  return ct == 64 ? launch_wino<64>(a, s) : launch_wino<32>(a, s);
+}
+
+}  // namespace pnpx

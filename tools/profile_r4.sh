@@ -10,6 +10,10 @@ BOPT="--steps 2 --warmup 1 --no-cpu-baseline --no-batch-table --no-fp32-mode"
 $R --stats -d $O/bench -o bench -- python bench.py $BOPT > $O/bench.log 2>&1
 python tools/rocpd_stats.py $O/bench/bench_results.db > $O/r4_bench_kernel_stats.md
 grep '^{' $O/bench.log | tail -1 > $O/r4_bench_profiled.json
+# the fp32 family (conv_mode 0: Winograd + direct fp32 MFMA kernels) through the same command
+$R --stats -d $O/bench32 -o bench -- python bench.py $BOPT --ctx-option conv_mode=0 > $O/bench32.log 2>&1
+python tools/rocpd_stats.py $O/bench32/bench_results.db > $O/r4_bench_kernel_stats_fp32.md
+grep '^{' $O/bench32.log | tail -1 > $O/r4_bench_profiled_fp32.json
 T="python tools/bench_tasks.py"
 $R --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $O/task_sq -o p -- $T > $O/task_sq.log 2>&1
 $R --pmc FETCH_SIZE -d $O/task_fetch -o p -- $T > $O/task_fetch.log 2>&1
