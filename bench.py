@@ -156,7 +156,9 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32 values as f16 hi+lo pairs (22-bit significand); 3 f16 MFMAs per product, f32 accumulate",
+        "dtype": ("f32 values as f16 hi+lo pairs (22-bit significand); 3 f16 MFMAs per product, f32 accumulate"
+                  if den.context(dev).get_option("conv_mode") == 1 else
+                  "f32 (v_mfma_f32_32x32x2_f32; Winograd F(2x2,3x3) on the layers with cout % 32 == 0)"),
         "data": "synthetic",
         "config": {
             "workload": f"CS-MRI ADMM {H}x{W} env_batch=" + (f"{n_global} global ({B} on rank 0)" if strong else f"{B}/GPU") +
@@ -182,7 +184,7 @@ def main():
         out["roofline"]["power"] = power
         if power and power.get("gfx_clk_mhz_avg"):
             # the same dense-f16 peak at the clock the power cap actually allowed during the timed region
-            peak_at_clk = PEAK_HS_TFLOPS * power["gfx_clk_mhz_avg"] / 2400.0
+            peak_at_clk = out["roofline"]["peak"] * power["gfx_clk_mhz_avg"] / 2400.0
             out["roofline"]["frac_of_peak_at_measured_clock"] = out["roofline"]["achieved"] / peak_at_clk
     if rank == 0 and world == 1 and not args.no_batch_table:
         out["batch_table"] = batch_table(solver, dev, H, W, args.ratio)
@@ -338,7 +340,8 @@ def forward_split(den, dev, x, sigma, n_fwd=12, reps=3):
                serialises the launch chains and adds a gap per launch, so its absolute sum is a few per cent longer
                than a real forward; only the ratios are used)."""
     ctx = den.context(dev)
-    den(x, sigma)
+    for _ in range(4):          # clocks and caches in the state of a running episode
+        den(x, sigma)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
@@ -362,6 +365,8 @@ def roofline(den, dev, x, sigma):
     (2*9*Cin*Cout*H*W*B per launch) / time of exactly those launches inside a steady-state production forward
     (forward_split: bracketed whole forwards x the per-kernel share)."""
     B, _, H, W = x.shape
+    if den.context(dev).get_option("conv_mode") == 0:      # --ctx-option conv_mode=0: the whole line is the fp32 family's
+        return roofline_fp32(den, dev, x, sigma, n_fwd=12)
     whole_ms, shares, conv_fl, profiled_ms = forward_split(den, dev, x, sigma)
     conv_ms = whole_ms * (shares.get("conv3x3", 0.0) + shares.get("conv3x3_wino", 0.0))
     achieved = conv_fl / (conv_ms * 1e-3) / 1e12
@@ -442,25 +447,28 @@ def fp32_mode(params, data, actions, dev, B, H, W, steps, warmup):
     power = sampler.stop()
     x = env.state["output"].detach().clone()
     sigma = actions[-1]["sigma_d"][:, -1].contiguous()
-    whole_ms, shares, conv_fl, _ = forward_split(den, dev, x, sigma, n_fwd=6)
+    rl = roofline_fp32(den, dev, x, sigma)
+    rl["power"] = power
+    return {"value": N_POLICY_STEPS * ACTION_PACK / dt, "unit": "iters/s", "steps": steps, "warmup": max(1, warmup),
+            "ms_per_step": 1e3 * dt, "dtype": "f32 (v_mfma_f32_32x32x2_f32; Winograd F(2x2,3x3) on the layers with cout % 32 == 0)",
+            "iters_per_s": N_POLICY_STEPS * ACTION_PACK / dt, "roofline": rl}
+
+
+def roofline_fp32(den, dev, x, sigma, n_fwd=12):
+    """Roofline of the fp32 convolution family (conv_mode 0) against the 157.3 TF/s fp32-MFMA peak: `achieved` counts the FLOPs
+    the matrix pipe EXECUTES (Winograd layers: 16 products per 2x2 outputs, not 36); the algorithmic rate is given beside it."""
+    whole_ms, shares, conv_fl, _ = forward_split(den, dev, x, sigma, n_fwd=n_fwd)
     conv_ms = whole_ms * (shares.get("conv3x3", 0.0) + shares.get("conv3x3_wino", 0.0))
     tf = conv_fl / (conv_ms * 1e-3) / 1e12
-    # FLOPs the matrix pipe executes: the Winograd layers (>= 64 channels, sizes divisible by 16) do 16 products per 2x2 outputs, not 36
     wino_fl = sum(f for name, _, f in ops.unet_profile(den.context(dev), x, sigma) if name == "conv3x3_wino")
     executed = conv_fl - wino_fl * (1.0 - 16.0 / 36.0)
     tf_exec = executed / (conv_ms * 1e-3) / 1e12
-    return {"value": N_POLICY_STEPS * ACTION_PACK / dt, "unit": "iters/s", "steps": steps, "warmup": max(1, warmup),
-            "ms_per_step": 1e3 * dt, "dtype": "f32 (v_mfma_f32_32x32x2_f32; Winograd F(2x2,3x3) on the >= 64-channel layers)",
-            "iters_per_s": N_POLICY_STEPS * ACTION_PACK / dt,
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_wino_f32_kernel + conv3x3_mfma_kernel (27 launches per denoiser forward)",
-                         "achieved": tf_exec, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf_exec / PEAK_FP32_MFMA_TFLOPS,
-                         "achieved_note": "EXECUTED MFMA FLOPs / time (the honest utilisation of the fp32 matrix pipe); the "
-                                          "algorithmic rate of the same launches is `algorithmic_tflops`",
-                         "algorithmic_tflops": tf, "algorithmic_flops_per_forward": conv_fl,
-                         "executed_mfma_flops_per_forward": executed,
-                         "conv_ms_per_forward": conv_ms,
-                         "denoiser_ms_per_forward": whole_ms, "traffic": None, "power": power}}
+    return {"bound": "mfma", "kernel": "conv3x3_wino_f32_kernel<64|32> + conv3x3_mfma_kernel (27 launches per denoiser forward)",
+            "achieved": tf_exec, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / PEAK_FP32_MFMA_TFLOPS,
+            "achieved_note": "EXECUTED MFMA FLOPs / time (the honest utilisation of the fp32 matrix pipe); the algorithmic rate "
+                             "of the same launches is `algorithmic_tflops`",
+            "algorithmic_tflops": tf, "algorithmic_flops_per_forward": conv_fl, "executed_mfma_flops_per_forward": executed,
+            "conv_ms_per_forward": conv_ms, "denoiser_ms_per_forward": whole_ms, "traffic": None}
 
 
 def pmc_traffic(B, H, W):

@@ -109,7 +109,8 @@ int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* 
  * inside every solver entry below -- runs the DRUNet (out = clamp(net(cat[x, sigma*1]), 0, 1), H and W multiples of 8);
  * pnpx_unet_load switches back.  The *_backward / *_train entries work too: a DRUNet context has no activation ring
  * (tickets are 0), its VJP re-computes the forward keeping every ResBlock's ReLU output and back-propagates on the same
- * kernel family.  Range guard: a DRUNet context never switches to conv_mode 0; the bias-free ReLU network is positively
+ * kernel family.  conv_mode 0 runs the DRUNet forward in fp32 arithmetic throughout (csrc/drunet_f32.hip; the *_backward /
+ * *_train entries return PNPX_ERR_ARG there).  Range guard: it never switches a DRUNet context to conv_mode 0; the bias-free ReLU network is positively
  * homogeneous, so a tripped guard makes later passes (range_guard 1) or the very call (range_guard 2, repeated) run on
  * inputs scaled by 2^-4k with the tail multiplying back (option "drunet_shift" reads / sets 4k in 0..16). */
 size_t pnpx_drunet_num_params(int nb);

@@ -304,3 +304,56 @@ def test_drunet_range_guard_rescales_instead_of_failing(drunet):
     finally:
         ctx.set_option("range_guard", 1)
         ctx.set_option("drunet_shift", 0)
+
+
+# ----------------------------------------------------------------------------- conv_mode 0: fp32 arithmetic throughout (r4)
+@pytest.fixture(scope="module")
+def drunet_f32():
+    from tfpnp_amd.pnp import DRUNetDenoiser2D
+    return DRUNetDenoiser2D(state_dict=synth.make_drunet_params(0), conv_mode=0)
+
+
+@pytest.mark.parametrize("B,H,W,seed", DRUNET_CASES)
+def test_drunet_fp32_mode_golden(drunet_f32, B, H, W, seed):
+    """The precision-matched mode (csrc/drunet_f32.hip: fp32 MFMA kernels, Winograd where the level is a multiple of 16,
+    the direct kernel elsewhere) against the same reference-built goldens as the half-split mode."""
+    g = golden(f"drunet_B{B}_{H}x{W}")
+    x, sigma = denoiser_inputs(B, H, W, seed)
+    post, pre = drunet_f32.forward_preclamp(t(x).to(dev()), t(sigma).to(dev()))
+    e_pre, e_post = rel(pre, g["pre"]), rel(post, g["post"])
+    print(f"DRUNet fp32 mode {B}x{H}x{W}: pre-clamp {e_pre:.2e}  clamped {e_post:.2e}")
+    assert e_pre < 2e-5 and e_post < 2e-5
+    assert torch.equal(drunet_f32(t(x).to(dev()), t(sigma).to(dev())), post)
+
+
+def test_drunet_fp32_mode_full_size_vs_oracle_and_half_split(drunet, drunet_f32):
+    """256 x 256: both kernel families against the fp64 oracle (the fp32 family must be at least as close as fp32 round-off
+    allows), against each other, Winograd on vs off, batch-order independence and arena reuse."""
+    x, sigma = denoiser_inputs(3, 256, 256, 65)
+    p64 = {k: torch.as_tensor(v).double() for k, v in synth.make_drunet_params(0).items()}
+    with torch.no_grad():
+        want = O.drunet_forward(torch.cat([t(x).double(), torch.ones(3, 1, 256, 256, dtype=torch.float64) * t(sigma).double().view(3, 1, 1, 1)], 1), p64)
+    xt, st = t(x).to(dev()), t(sigma).to(dev())
+    _, pre32 = drunet_f32.forward_preclamp(xt, st)
+    _, pre_hs = drunet.forward_preclamp(xt, st)
+    e32, ehs = rel(pre32, want), rel(pre_hs, want)
+    print(f"DRUNet 3x256x256 vs fp64 oracle: fp32 mode {e32:.2e}, half-split {ehs:.2e}; fp32 vs half-split {rel(pre32, pre_hs.cpu()):.2e}")
+    assert e32 < 5e-6 and ehs < 2e-5
+    ctx = drunet_f32.context(dev())
+    ctx.set_option("fp32_winograd", 0)
+    _, direct = drunet_f32.forward_preclamp(xt, st)
+    ctx.set_option("fp32_winograd", 1)
+    assert not torch.equal(direct, pre32) and rel(direct, want) < 5e-6
+    perm = torch.tensor([2, 0, 1])
+    _, pre2 = drunet_f32.forward_preclamp(xt[perm], st[perm])
+    assert torch.equal(pre2.cpu(), pre32.cpu()[perm])
+    _, pre1 = drunet_f32.forward_preclamp(xt[1:2], st[1:2])
+    assert torch.equal(pre1.cpu(), pre32.cpu()[1:2])
+
+
+def test_drunet_fp32_mode_refuses_the_vjp_clearly(drunet_f32):
+    x, sigma = denoiser_inputs(1, 32, 32, 3)
+    xt = t(x).to(dev()).requires_grad_(True)
+    from tfpnp_amd._lib import PnpxError
+    with pytest.raises(PnpxError, match="half-split"):
+        drunet_f32(xt, t(sigma).to(dev())).sum().backward()

@@ -137,6 +137,13 @@ struct DruNet {
   std::vector<ConvLayerHsDev> layers_bwd;
   const float* tail_bwd_w = nullptr;   // [64][2][3][3]: conv_first_hs_kernel weights of the tail's adjoint (1 -> 64 channels)
   DeviceBuf weights, arena, arena_grad;
+  // conv_mode 0 (drunet_f32.hip): fp32 packings of the same layers, made on first use from the host copy of the parameters
+  std::vector<float> params_host;
+  bool f32_ready = false;
+  std::vector<ConvLayer> f32_layers;       // direct fp32 MFMA kernel
+  std::vector<const float*> f32_wino;      // Winograd weights of the 3x3 ResBlock layers (else null)
+  DeviceBuf f32_weights, f32_arena;
+  int f32_capB = 0, f32_capH = 0, f32_capW = 0;
   int capB = 0, capH = 0, capW = 0;
   bool arena_keeps = false;            // the arena has room for every ResBlock's middle activation (backward pass)
   int gcapB = 0, gcapH = 0, gcapW = 0;
@@ -315,6 +322,9 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
 int drunet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out,
                             float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s);
 void drunet_free(pnpx_ctx* ctx);
+int drunet_denoise_f32(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre, int B, int H,
+                       int W, hipStream_t s);
+void drunet_f32_free(pnpx_ctx* ctx);
 
 // Policy actor (policy.hip)
 size_t policy_num_params(int num_inputs, int n_det, int spi_head);

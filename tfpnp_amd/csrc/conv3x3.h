@@ -22,6 +22,7 @@ struct ConvArgs {
   int mode;
   const float* dmask;
   const char* dmask_hs = nullptr;
+  const float* res = nullptr;   // mode 0: added after the activation (same geometry as `out`; the ResBlock skip of the DRUNet)
 };
 
 int conv_pack_mt(int cout);
@@ -29,6 +30,9 @@ int conv_pack_cc(int cin);
 void pack_conv_weights(const float* w, int cout, int cin, int mt, int cc, float* dst);
 int launch_conv3x3(const ConvLayer& L, const float* in0, int C0, const float* in1, int C1, float* out, int B,
                    int H, int W, hipStream_t s);
+// ... with a chosen negative slope (0.2 = the UNet's LeakyReLU, 0 = ReLU, 1 = linear) and an optional residual operand
+int launch_conv3x3_act(const ConvLayer& L, const float* in0, int C0, const float* in1, int C1, float* out, int B,
+                       int H, int W, float slope, const float* res, hipStream_t s);
 // Input-gradient convolution: L holds the transposed, tap-flipped weights (pack_conv_weights_transposed).
 int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const float* dmask, int B, int H, int W,
                         hipStream_t s, const char* dmask_hs = nullptr);
@@ -42,7 +46,7 @@ bool conv3x3_wino_packs(int cout, int cin);   // the layer gets Winograd weights
 size_t conv3x3_wino_floats(int cout, int cin);
 void pack_conv_weights_wino(const float* w, int cout, int cin, float* dst);
 int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
-                        float* out, int B, int H, int W, hipStream_t s);
+                        float* out, int B, int H, int W, hipStream_t s, float slope = 0.2f, const float* res = nullptr);
 void pack_conv_weights_transposed(const float* w, int cout, int cin, int cout_pad, int mt, int cc, float* dst);
 
 }  // namespace pnpx

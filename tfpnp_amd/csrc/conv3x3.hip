@@ -199,8 +199,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
         for (int r = 0; r < 16; ++r) {
           const size_t ro = (size_t)((r & 3) + 8 * (r >> 2)) * HpWp;
           float v = acc[m][n][r] + bias[r];
-          if (a.mode == 0) v = v > 0.f ? v : v * a.slope;
-          else if (a.mode == 2) v = a.dmask[off + ro] > 0.f ? v : v * a.slope;
+          if (a.mode == 0) {
+            v = v > 0.f ? v : v * a.slope;
+            if (a.res) v += a.res[off + ro];
+          } else if (a.mode == 2) v = a.dmask[off + ro] > 0.f ? v : v * a.slope;
           else if (a.mode == 4) v = ((hsbits >> r) & 1u) ? v : v * a.slope;
           o[ro] = v;
         }
@@ -241,6 +243,11 @@ int conv_pack_cc(int cin) { return cin % 8 == 0 ? 8 : 2; }
 
 int launch_conv3x3(const ConvLayer& L, const float* in0, int C0, const float* in1, int C1, float* out, int B,
                    int H, int W, hipStream_t s) {
+  return launch_conv3x3_act(L, in0, C0, in1, C1, out, B, H, W, 0.2f, nullptr, s);
+}
+
+int launch_conv3x3_act(const ConvLayer& L, const float* in0, int C0, const float* in1, int C1, float* out, int B,
+                       int H, int W, float slope, const float* res, hipStream_t s) {
   if (C0 + C1 != L.cin || C0 % L.cc != 0 || C1 % L.cc != 0 || L.cout % L.mt != 0) {
     set_error("conv3x3: channel split %d+%d incompatible with packed layer (cin %d, cc %d)", C0, C1, L.cin, L.cc);
     return PNPX_ERR_SHAPE;
@@ -258,9 +265,10 @@ int launch_conv3x3(const ConvLayer& L, const float* in0, int C0, const float* in
   a.Hp = padded_h(H);
   a.Wp = padded_w(W);
   a.nct = L.cout / L.mt;
-  a.slope = 0.2f;
+  a.slope = slope;
   a.mode = 0;
   a.dmask = nullptr;
+  a.res = res;
   if (L.mt == 64 && L.cc == 8) return launch_mt_cc<64, 8>(a, B, s);
   if (L.mt == 32 && L.cc == 8) return launch_mt_cc<32, 8>(a, B, s);
   if (L.mt == 32 && L.cc == 2) return launch_mt_cc<32, 2>(a, B, s);

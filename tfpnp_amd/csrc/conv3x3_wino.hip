@@ -44,6 +44,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //   CT 64: region 16 x 16 px = 64 tiles, K chunks of 16 channels, waves 2 (cout blocks) x 2 (tile blocks), 32 MFMAs per stage
 //   CT 32: region 16 x 32 px = 128 tiles, K chunks of  8 channels, waves 1 x 4 (tile blocks),             16 MFMAs per stage
 // (a 32-cout tile with 16-channel chunks would need 174 KB of LDS for its 128-tile halo and V buffers).  V is 16 KiB per stage in both.
+// Diagnostic builds (tools/wino_ablate.sh): -DWINO_ABL=bits removes parts of a stage (results are then wrong; timing only):
+// 1 the closing wait + barrier, 2 the transform, 4 the operand reads, 8 the LDS-DMA issue, 16 the MFMAs, 32 the epilogue's stores,
+// 64 its bias loads, 128 its residual loads.
+#ifndef WINO_ABL
+#define WINO_ABL 0
+#endif
+
 template <int CT_>
 struct Cfg {
   static constexpr int CT = CT_;
@@ -64,11 +71,6 @@ struct Cfg {
   static constexpr int VQ = 16384, NU = 4;
   static constexpr int OFF_U = 0, OFF_V = NU * UQ, OFF_RAW = OFF_V + 2 * VQ;
   static constexpr int LDS_USED = OFF_RAW + 2 * RAW_BYTES;   // 139776 / 88576
-  // side-work slots behind the MFMAs of a stage (stage()): transform slices per slot, weight-DMA slot, halo gathers per slot
-  static constexpr int TS = (CT == 64) ? 1 : 2;
-  static constexpr int U_SLOT = NM / 2;
-  static constexpr int RPS = (CT == 64) ? 2 : 3;
-  static_assert(2 + 12 / TS <= U_SLOT && (NM - U_SLOT - 1) * RPS >= RAW_PER_WAVE, "side work fits behind the MFMAs");
 };
 constexpr int LDS_REQ = 160 * 1024;                 // the whole CU (see conv_hs_kernel.h: no LDS-using neighbours)
 
@@ -77,6 +79,7 @@ struct WinoArgs {
   const float* in1;
   const float* u;      // [cout/CT][cin/CK][a 4][b 4][kg 2][half][m CT][4] fp32
   const float* bias;
+  const float* res;    // optional: added after the activation (same geometry as out)
   float* out;
   int B, H, W, Hp, Wp, C0, C1, Cout, nct, nch, rx, ry;
   float slope;
@@ -109,7 +112,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int CT>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
   using C = Cfg<CT>;
-  constexpr int CK = C::CK, HALVES = C::HALVES, KS = C::KS, NM = C::NM, TX = C::TX, NT = C::NT, RW = C::RW, RPX = C::RPX;
+  constexpr int CK = C::CK, HALVES = C::HALVES, KS = C::KS, TX = C::TX, NT = C::NT, RW = C::RW, RPX = C::RPX;
   constexpr int RAW_ELEMS = C::RAW_ELEMS, RAW_BYTES = C::RAW_BYTES, RAW_PER_WAVE = C::RAW_PER_WAVE;
   constexpr int UQ = C::UQ, NUW = C::NUW, VQ = C::VQ, OFF_U = C::OFF_U, OFF_V = C::OFF_V, OFF_RAW = C::OFF_RAW;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -232,11 +235,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
 
   // One pipeline stage = position row A: 32 MFMAs per wave (4 positions x 8 k-steps), issued one at a time with a slice of the
   // stage's other work behind each so that the matrix pipe (64 clocks per MFMA) never waits for the wave's VALU / LDS / DMA issue:
-  //   before MFMA 0     A/B operands of positions 0, 1                                   (8 ds_read_b128)
-  //   MFMA  0 ..  1     A/B operands of positions 2, 3                                   (8 ds_read_b128)
-  //   MFMA  2 .. 13     the transform of the NEXT stage's V (row TA), 12 slices
-  //   MFMA 16           this stage's weight slice by LDS-DMA                              (4 x 16 B per lane)
-  //   MFMA 17 .. 27     the next chunk's halo by LDS-DMA (stage 0 only)                   (2 dword gathers each)
+  //   before MFMA 0     the operands MFMA 0 / 1 need; the rest of the stage's 16 operand reads and the 16 halo reads of the NEXT
+  //                     stage's transform (row TA) follow in the first 10 slots, the transform's arithmetic and V writes in the
+  //                     next 8, then this stage's weight slice and (stage 0) the next chunk's halo by LDS-DMA  -- see side()
   // The fences pin that order; left alone the scheduler puts all the side work first and the MFMAs in one block behind it.
   // (No run-time conditions in here: a stage has to stay ONE basic block, or the compiler peels and unswitches the chunk loop into
   //  versions with a branch behind every MFMA, and the first chunk of every tile ran ~6x slower than the others.)
@@ -255,15 +256,62 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
     const char* vb = lds + OFF_V + (A & 1) * VQ + b_lane;
     f32x4 af[4][HALVES], bf[4][HALVES];
     Tr t;
-    auto operands = [&](int b) {
+    auto operand = [&](int b, int h) {
+      if (WINO_ABL & 4) {
+        af[b][h] = bf[b][h] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        return;
+      }
+      af[b][h] = *reinterpret_cast<const f32x4*>(ua + b * (UQ / 4) + h * (CT * 16));
+      bf[b][h] = *reinterpret_cast<const f32x4*>(vb + b * 4096 + h * (NT * 16));
+    };
+    auto tslice = [&](int q) {
+      if (!(WINO_ABL & 2)) transform_slice(ta_tag, q, t, sd.t_rbuf, sd.t_vbuf);
+    };
+    auto dma_u = [&]() {
+      if (WINO_ABL & 8) return;
+      const float* s = sd.u_src + wave * 256;
 #pragma unroll
-      for (int h = 0; h < HALVES; ++h) {
-        af[b][h] = *reinterpret_cast<const f32x4*>(ua + b * (UQ / 4) + h * (CT * 16));
-        bf[b][h] = *reinterpret_cast<const f32x4*>(vb + b * 4096 + h * (NT * 16));
+      for (int k = 0; k < NUW; ++k) glds16(s + k * 1024, uoff, lds0 + OFF_U + sd.u_slot * UQ + (wave + 4 * k) * 1024);
+    };
+    auto dma_raw = [&](int k0, int k1) {
+      if (RAW && !(WINO_ABL & 8)) {
+        const unsigned dst = lds0 + OFF_RAW + sd.raw_buf * RAW_BYTES + wave * 256;
+#pragma unroll
+        for (int k = k0; k < k1; ++k)
+          if (k < RAW_PER_WAVE - 1 || (k == RAW_PER_WAVE - 1 && wave == 0)) glds4(sd.raw_src, roff[k], dst + k * 1024);
       }
     };
-    operands(0);
-    operands(1);
+    // The side work behind MFMA number sl.  LDS reads (16 operand reads, 16 halo reads per lane) are spread over the first
+    // half of the stage: issued in one burst behind the barrier they queue ~770 clocks of LDS time into a 500-clock window and
+    // the wave stalls on its transform reads; the second half carries the VALU part, the V writes and the DMA issue.
+    auto side = [&](int sl) {
+      if (CT == 64) {
+        if (sl == 0) operand(0, 1);
+        else if (sl == 1) operand(1, 1);
+        else if (sl < 10) {
+          const int q = sl - 2;                      // even: halo reads of channel q / 2; odd: one operand pair of positions 2, 3
+          if ((q & 1) == 0) tslice(q >> 1);
+          else operand(2 + (q >> 2), (q >> 1) & 1);
+        } else if (sl < 18) tslice(4 + (sl - 10));
+        else if (sl == 18) dma_u();
+        else dma_raw(2 * (sl - 19), 2 * (sl - 19) + 2);
+      } else {
+        if (sl == 0) tslice(0);
+        else if (sl == 1) operand(2, 0);
+        else if (sl == 2) tslice(1);
+        else if (sl == 3) operand(3, 0);
+        else if (sl == 4) tslice(2);
+        else if (sl == 5) tslice(3);
+        else if (sl < 10) {
+          tslice(4 + 2 * (sl - 6));
+          tslice(5 + 2 * (sl - 6));
+        } else if (sl == 10) dma_u();
+        else dma_raw(4 * (sl - 11), 4 * (sl - 11) + 4);
+      }
+    };
+    // before the first MFMA: what its first k-steps need (positions 0, 1; for CT 64 only their first 8-channel half)
+    operand(0, 0);
+    operand(1, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int pair = 0; pair < 2; ++pair)
@@ -276,29 +324,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
           {
             const float x = af[b][m >> 2][m & 3], y = bf[b][m >> 2][m & 3];
             const bool from_zero = ZERO && m == 0;
-            switch (b) {
+            if (!(WINO_ABL & 16)) switch (b) {
               case 0: if (from_zero) WINO_MFMA_FROM_ZERO(4 * A + 0, x, y); else WINO_MFMA(4 * A + 0, x, y); break;
               case 1: if (from_zero) WINO_MFMA_FROM_ZERO(4 * A + 1, x, y); else WINO_MFMA(4 * A + 1, x, y); break;
               case 2: if (from_zero) WINO_MFMA_FROM_ZERO(4 * A + 2, x, y); else WINO_MFMA(4 * A + 2, x, y); break;
               default: if (from_zero) WINO_MFMA_FROM_ZERO(4 * A + 3, x, y); else WINO_MFMA(4 * A + 3, x, y); break;
             }
           }
-          if (sl < 2) operands(2 + sl);
-          else if (sl < 2 + 12 / C::TS) {
-#pragma unroll
-            for (int q = 0; q < C::TS; ++q) transform_slice(ta_tag, (sl - 2) * C::TS + q, t, sd.t_rbuf, sd.t_vbuf);
-          } else if (sl == C::U_SLOT) {
-            const float* s = sd.u_src + wave * 256;
-#pragma unroll
-            for (int k = 0; k < NUW; ++k) glds16(s + k * 1024, uoff, lds0 + OFF_U + sd.u_slot * UQ + (wave + 4 * k) * 1024);
-          } else if (sl > C::U_SLOT) {
-            if (RAW) {
-              const unsigned dst = lds0 + OFF_RAW + sd.raw_buf * RAW_BYTES + wave * 256;
-#pragma unroll
-              for (int k = C::RPS * (sl - C::U_SLOT - 1); k < C::RPS * (sl - C::U_SLOT); ++k)
-                if (k < RAW_PER_WAVE - 1 || (k == RAW_PER_WAVE - 1 && wave == 0)) glds4(sd.raw_src, roff[k], dst + k * 1024);
-            }
-          }
+          side(sl);
           __builtin_amdgcn_sched_barrier(0);
         }
   };
@@ -312,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float bias_r[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bias_r[r] = a.bias[cbase + (r & 3) + 8 * (r >> 2)];
+    for (int r = 0; r < 16; ++r) bias_r[r] = (WINO_ABL & 64) ? 0.f : a.bias[cbase + (r & 3) + 8 * (r >> 2)];
     static_for<16>([&](auto r_tag) {
       constexpr int R = decltype(r_tag)::value;
       float t0[4], t1[4];
@@ -335,8 +368,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
       y10 = y10 > 0.f ? y10 : y10 * a.slope;
       y11 = y11 > 0.f ? y11 : y11 * a.slope;
       float* o = ob + (size_t)co * HpWp;
-      *reinterpret_cast<f32x2*>(o) = (f32x2){y00, y01};
-      *reinterpret_cast<f32x2*>(o + a.Wp) = (f32x2){y10, y11};
+      if (a.res && !(WINO_ABL & 128)) {
+        const float* rp = a.res + (o - a.out);
+        const f32x2 r0 = *reinterpret_cast<const f32x2*>(rp), r1 = *reinterpret_cast<const f32x2*>(rp + a.Wp);
+        y00 += r0[0];
+        y01 += r0[1];
+        y10 += r1[0];
+        y11 += r1[1];
+      }
+      if (!(WINO_ABL & 32) || y00 == 1.2345e-33f) {
+        *reinterpret_cast<f32x2*>(o) = (f32x2){y00, y01};
+        *reinterpret_cast<f32x2*>(o + a.Wp) = (f32x2){y10, y11};
+      }
     });
   };
 
@@ -348,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
   // N = VMEM operations issued after it (younger weight slices, halo pieces, the previous tile's stores) that may stay in flight
   auto sync_counted = [&](auto n_tag) {
     constexpr int N = decltype(n_tag)::value;
+    if (WINO_ABL & 1) return;
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
     __syncthreads();
   };
@@ -474,7 +518,7 @@ static int launch_wino(WinoArgs a, hipStream_t s) {
 }
 
 int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
-                        float* out, int B, int H, int W, hipStream_t s) {
+                        float* out, int B, int H, int W, hipStream_t s, float slope, const float* res) {
   const int ct = wino_ct(C0, C1, cout, H, W);
   if (!ct) {
     set_error("conv3x3_wino: unsupported geometry (%d + %d -> %d channels, %d x %d)", C0, C1, cout, H, W);
@@ -485,6 +529,7 @@ int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float
   a.in1 = in1 ? in1 : in0;
   a.u = u;
   a.bias = bias;
+  a.res = res;
   a.out = out;
   a.B = B;
   a.H = H;
@@ -494,7 +539,7 @@ int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float
   a.C0 = C0;
   a.C1 = C1;
   a.Cout = cout;
-  a.slope = 0.2f;
+  a.slope = slope;
   return ct == 64 ? launch_wino<64>(a, s) : launch_wino<32>(a, s);
 }
 

@@ -96,6 +96,7 @@ void drunet_free(pnpx_ctx* ctx) {
   if (N.weights.p) (void)hipFree(N.weights.p);
   if (N.arena.p) (void)hipFree(N.arena.p);
   if (N.arena_grad.p) (void)hipFree(N.arena_grad.p);
+  drunet_f32_free(ctx);
   N = DruNet();
 }
 
@@ -235,6 +236,7 @@ int drunet_load(pnpx_ctx* ctx, const float* params, size_t n, int nb) {
   N.nb = nb;
   N.weights.p = p;
   N.weights.bytes = host.size() * sizeof(float);
+  N.params_host.assign(params, params + n);   // conv_mode 0 packs its own layouts from these on first use (drunet_f32.hip)
   N.loaded = true;
   return PNPX_OK;
 }
@@ -285,10 +287,11 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
     return PNPX_ERR_NO_WEIGHTS;
   }
   if (ctx->conv_mode != CONV_HS) {
-    // the DRUNet exists on the half-split kernel family only; its answer to a tripped range guard is not conv_mode 0 but a
-    // re-scaled pass (DruNet::shift: the network is positively homogeneous), so conv_mode 0 can only have been requested
-    set_error("DRUNet runs on the half-split convolutions only (conv_mode 1); conv_mode 0 was requested");
-    return PNPX_ERR_ARG;
+    if (keep_mids) {
+      set_error("DRUNet: the training forward / VJP run on the half-split convolutions only (conv_mode 1)");
+      return PNPX_ERR_ARG;
+    }
+    return drunet_denoise_f32(ctx, x, sigma, sigma_stride, out, out_pre, B, H, W, s);   // fp32 arithmetic throughout (drunet_f32.hip)
   }
   if (B <= 0 || H < 8 || W < 8 || (H & 7) || (W & 7)) {
     set_error("DRUNet: need B > 0 and H, W positive multiples of 8 (three 2x2 strided convolutions; got B=%d H=%d W=%d)", B, H, W);

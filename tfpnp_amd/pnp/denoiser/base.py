@@ -71,9 +71,11 @@ class DRUNetDenoiser2D(UNetDenoiser2D):
     H and W must be multiples of 8.  Under autograd the registered VJP re-computes the forward natively keeping every
     ResBlock's ReLU output and back-propagates on the same kernels (csrc/drunet.hip::drunet_denoise_backward)."""
 
-    def __init__(self, ckpt_path=None, state_dict=None, nb=4):
+    def __init__(self, ckpt_path=None, state_dict=None, nb=4, conv_mode=None):
+        """conv_mode: None/1 = half-split f16 MFMA convolutions (default; forward and VJP), 0 = fp32 arithmetic throughout
+        (csrc/drunet_f32.hip: Winograd / direct fp32 MFMA kernels; forward only)."""
         torch.nn.Module.__init__(self)
-        self.conv_mode = None
+        self.conv_mode = conv_mode
         self.nb = nb
         if state_dict is None:
             if ckpt_path is None:
@@ -91,6 +93,8 @@ class DRUNetDenoiser2D(UNetDenoiser2D):
         if idx not in self._ctx:
             ctx = ops.Context(torch.device('cuda', idx))
             ctx.load_drunet(self._state, nb=self.nb)
+            if self.conv_mode is not None:
+                ctx.set_option('conv_mode', self.conv_mode)
             self._ctx[idx] = ctx
         return self._ctx[idx]
 
