@@ -190,6 +190,9 @@ def main():
         out["batch_table"] = batch_table(solver, dev, H, W, args.ratio)
     if rank == 0 and world == 1 and not args.no_fp32_mode:
         out["fp32_mode"] = fp32_mode(params, data, actions, dev, B, H, W, args.steps, args.warmup)
+        # the same metric with every convolution in fp32 arithmetic (the reference's own precision), surfaced beside `value`
+        out["value_fp32_arithmetic"] = out["fp32_mode"]["value"]
+        out["ms_per_step_fp32_arithmetic"] = out["fp32_mode"]["ms_per_step"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity_rel_l2_vs_cpu"] = cpu_baseline(params, solver, dev, args, value)
         out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]

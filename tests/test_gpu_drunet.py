@@ -357,3 +357,22 @@ def test_drunet_fp32_mode_refuses_the_vjp_clearly(drunet_f32):
     from tfpnp_amd._lib import PnpxError
     with pytest.raises(PnpxError, match="half-split"):
         drunet_f32(xt, t(sigma).to(dev())).sum().backward()
+
+
+def test_drunet_fp32_mode_is_the_prox_of_the_native_solver_loops(drunet_f32):
+    """Config #5's pairing (SPI ADMM + DRUNet) with the denoiser in fp32 arithmetic, teacher-forced against the same
+    reference-built per-iteration goldens as the half-split mode."""
+    from tfpnp_amd.tasks.spi import ADMMSolver_SPI
+    g = golden("drunet_spi_B2_64x64")
+    d, sg, m = drunet_spi_case()
+    sol = ADMMSolver_SPI(drunet_f32)
+    x0, K = t(d["x0"]).to(dev()), t(d["K"]).to(dev())
+    v = sol.reset({"x0": x0})
+    for i in range(sg.shape[1]):
+        prev = t(g[f"admm_step{i}"]).to(dev()) if i else v
+        v = sol((prev, (x0, K)), (t(sg[:, i:i + 1]).to(dev()), t(m[:, i:i + 1]).to(dev())))
+        want = t(g[f"admm_step{i + 1}"])
+        x_err = rel(v[:, :1], want[:, :1])
+        zu_exact = float((v[:, 1:].cpu() == want[:, 1:]).float().mean())
+        print(f"SPI+DRUNet (fp32 mode) iteration {i + 1}: x rel {x_err:.2e}, z/u bit-equal fraction {zu_exact:.5f}")
+        assert x_err < 1e-4 and zu_exact > 0.995
