@@ -471,16 +471,17 @@ def roofline_fp32(den, dev, x, sigma, n_fwd=12):
             "achieved_note": "EXECUTED MFMA FLOPs / time (the honest utilisation of the fp32 matrix pipe); the algorithmic rate "
                              "of the same launches is `algorithmic_tflops`",
             "algorithmic_tflops": tf, "algorithmic_flops_per_forward": conv_fl, "executed_mfma_flops_per_forward": executed,
-            "conv_ms_per_forward": conv_ms, "denoiser_ms_per_forward": whole_ms, "traffic": None}
+            "conv_ms_per_forward": conv_ms, "denoiser_ms_per_forward": whole_ms,
+            "traffic": pmc_traffic(x.shape[0], x.shape[2], x.shape[3], "_fp32")}
 
 
-def pmc_traffic(B, H, W):
+def pmc_traffic(B, H, W, suffix=""):
     """HBM bytes of the conv launches of one denoiser forward, from the newest committed rocprofv3 PMC passes
     (profiles/r*_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, per MI355X_MICROARCH.md; counters cannot be collected
     inside a timed run).  Same aggregation as `achieved` (all conv launches of one forward).  None when no PMC pass
     exists for this geometry."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")))
     if not cands:
         return None
     path = cands[-1]
@@ -491,11 +492,12 @@ def pmc_traffic(B, H, W):
     if (t.get("B"), t.get("H"), t.get("W")) != (B, H, W):
         return None
     return {"bytes_per_forward": t["hbm_bytes_per_forward"], "bytes_per_conv_launch": t["hbm_bytes_per_conv_launch"],
-            "algorithmic_bytes_per_forward": conv_algorithmic_bytes(B, H, W), "source": t["source"]}
+            "algorithmic_bytes_per_forward": conv_algorithmic_bytes(B, H, W, 2 if suffix else 16), "source": t["source"]}
 
 
-def conv_algorithmic_bytes(B, H, W):
-    """Input + output activation bytes of the 27 convolutions (4 B per value: f16 hi + f16 lo), weights excluded."""
+def conv_algorithmic_bytes(B, H, W, min_cin=16):
+    """Input + output activation bytes of the 27 convolutions (4 B per value: f16 hi + f16 lo, or one fp32), weights excluded;
+    min_cin: channel count the first layer's input tensor is stored with (16 in the half-split layout, 2 in the fp32 one)."""
     blocks = [(2, 32, 0), (32, 64, 1), (64, 128, 2), (128, 256, 3), (256, 512, 4), (768, 256, 3), (384, 128, 2),
               (192, 64, 1), (96, 32, 0)]
     tot = 0
@@ -503,7 +505,7 @@ def conv_algorithmic_bytes(B, H, W):
         px = (H >> lvl) * (W >> lvl) * B
         for j in range(3):
             ci = cin if j == 0 else cout
-            tot += 4 * px * (max(ci, 16) + cout)
+            tot += 4 * px * (max(ci, min_cin) + cout)
     return tot
 
 

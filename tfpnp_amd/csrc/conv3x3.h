@@ -46,7 +46,13 @@ bool conv3x3_wino_packs(int cout, int cin);   // the layer gets Winograd weights
 size_t conv3x3_wino_floats(int cout, int cin);
 void pack_conv_weights_wino(const float* w, int cout, int cin, float* dst);
 int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
-                        float* out, int B, int H, int W, hipStream_t s, float slope = 0.2f, const float* res = nullptr);
+                        float* out, int B, int H, int W, hipStream_t s, float slope = 0.2f, const float* res = nullptr,
+                        float* pool_out = nullptr);   // pool_out: also write MaxPool2d(2) of the output (padded planar, H/2 x W/2)
+// The UNet's last 3x3 layer (-> 32 channels) with the 1x1 out-conv + input residual + clamp in its epilogue: writes img (clamped)
+// and, if given, img_pre; the 32-channel tensor never exists.  Summation order of the 1x1: two 16-channel halves, then their sum.
+bool conv3x3_wino_outc_ok(int cin, int cout, int H, int W);
+int launch_conv3x3_wino_outc(const float* u, const float* bias, const float* in0, int cin, const float* outc_w, const float* outc_b,
+                             const float* x_img, float* img, float* img_pre, int B, int H, int W, hipStream_t s);
 void pack_conv_weights_transposed(const float* w, int cout, int cin, int cout_pad, int mt, int cc, float* dst);
 
 }  // namespace pnpx

@@ -19,10 +19,10 @@
 //   MFMA k-slot (lane half kg, step m) = input channel 8 kg + m of the chunk, for A and B alike, so a lane's 8 operands per position
 //   are two ds_read_b128 each.  Output transform A^T M A in registers, bias + LeakyReLU, 8-byte stores.
 //
-// Measured (B = 48, 256 x 256, profiles/r4_fp32_winograd.md): 1.4 - 1.8x over conv3x3.hip on the 64-cout-tile layers (e.g. 256 -> 256
-// at 32 x 32: 0.469 -> 0.272 ms), 1.3 - 1.4x on the 32-cout-tile (full-resolution) layers; all 27 convolutions 15.4 -> 10.1 ms
-// (184 TF/s algorithmic against the 157 TF/s fp32 MFMA peak).  Relative error vs the fp64 oracle 7e-7 (direct kernel: 1.1e-6;
-// fewer, shorter sums).
+// Measured (B = 48, 256 x 256, profiles/r4_fp32_winograd.md): 1.5 - 2.0x over conv3x3.hip on the 64-cout-tile layers (e.g. 256 -> 256
+// at 32 x 32: 0.469 -> 0.249 ms), 1.3 - 1.6x on the 32-cout-tile (full-resolution) layers; all 27 convolutions 15.4 -> 9.2 ms
+// (200 TF/s algorithmic against the 157 TF/s fp32 MFMA peak; MFMA pipe 70 - 75 % busy on the deep layers at the ~2.05 GHz the
+// chip holds under this kernel).  Relative error vs the fp64 oracle 7e-7 (direct kernel: 1.1e-6; fewer, shorter sums).
 #include <cmath>
 #include <utility>
 #include <vector>
@@ -80,6 +80,14 @@ struct WinoArgs {
   const float* u;      // [cout/CT][cin/CK][a 4][b 4][kg 2][half][m CT][4] fp32
   const float* bias;
   const float* res;    // optional: added after the activation (same geometry as out)
+  // FUSE_OUTC instances (32-cout layer = the UNet's last): the 1x1 out-conv + residual + clamp of models/unet.py:63-66,124-131 and
+  // denoiser/base.py:32 in the epilogue; `out` (the 32-channel tensor) is then neither written nor read again
+  const float* outc_w;   // [32]
+  const float* outc_b;   // [1]
+  const float* x_img;    // [B][H][W] the network's input image (residual)
+  float* img;            // [B][H][W] clamped result
+  float* img_pre;        // [B][H][W] pre-clamp result (== img when the caller wants none: the clamped store lands second)
+  float* pool;         // optional: MaxPool2d(2) of the activated output, padded planar [B][Cout][H/2 + 2][W/2 + 2 PADL] (a 2x2 tile = one lane)
   float* out;
   int B, H, W, Hp, Wp, C0, C1, Cout, nct, nch, rx, ry;
   float slope;
@@ -109,8 +117,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define WINO_MFMA_FROM_ZERO(IDX, x, y) \
   asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, 0" ::"v"(x), "v"(y), "n"(16 * (IDX)), "n"(16 * (IDX) + 15))
 
-template <int CT>
+template <int CT, bool FUSE_OUTC>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
+  static_assert(!FUSE_OUTC || CT == 32, "the fused out-conv needs all 32 couts of a pixel in one wave");
   using C = Cfg<CT>;
   constexpr int CK = C::CK, HALVES = C::HALVES, KS = C::KS, TX = C::TX, NT = C::NT, RW = C::RW, RPX = C::RPX;
   constexpr int RAW_ELEMS = C::RAW_ELEMS, RAW_BYTES = C::RAW_BYTES, RAW_PER_WAVE = C::RAW_PER_WAVE;
@@ -177,7 +186,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
 
   // transform role: one tile and 4 channels of the chunk per thread.  CT 64: tile = lane, channels 8 * tkg + 4 * thf .. + 3 by wave;
   // CT 32: tile = tid & 127, channels 4 * tkg .. + 3 with tkg = tid >> 7
-  const int tt = (CT == 64) ? lane : (tid & 127);
+  // LDS banks: the halo reads are 8 bytes per lane at dword (2 tty) * RW + 2 ttx (+ row, + channel plane); the 16 lanes the LDS
+  // serves together must cover 16 distinct bank pairs.  CT 32: one tile row (ttx 0..15) = 16 lanes.  CT 64 (8 tiles per row, row
+  // step 36 dwords = 2 pairs mod 16): tile rows t and t + 4 are 8 pairs apart, so lanes 0-7 / 8-15 take rows (0, 4), 16-31 (1, 5), ...
+  // (with tile = lane the rows of a group overlapped in 6 of 8 pairs: the counters showed half of all LDS cycles as conflicts).
+  const int tt = (CT == 64) ? ((lane & 7) + 8 * (4 * ((lane >> 3) & 1) + (lane >> 4))) : (tid & 127);
   const int tkg = (CT == 64) ? (wave & 1) : (wave >> 1), thf = (CT == 64) ? (wave >> 1) : 0;
   const int tty = tt / TX, ttx = tt % TX;
   const int t_rd = (((tkg * (CK / 2) + thf * 4) * RPX) + (2 * tty) * RW + 2 * ttx) * 4;
@@ -208,9 +221,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
       const int e = sl;
       const char* rb = lds + OFF_RAW + rbuf * RAW_BYTES + t_rd;
 #pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        t.d[0][e][x] = *reinterpret_cast<const float*>(rb + (e * RPX + RA * RW + x) * 4);
-        t.d[1][e][x] = *reinterpret_cast<const float*>(rb + (e * RPX + RB * RW + x) * 4);
+      for (int x = 0; x < 4; x += 2) {      // 8-byte reads (the dword index is even: RPX, RW and 2 ttx are)
+        const f32x2 da = *reinterpret_cast<const f32x2*>(rb + (e * RPX + RA * RW + x) * 4);
+        const f32x2 db = *reinterpret_cast<const f32x2*>(rb + (e * RPX + RB * RW + x) * 4);
+        t.d[0][e][x] = da[0];
+        t.d[0][e][x + 1] = da[1];
+        t.d[1][e][x] = db[0];
+        t.d[1][e][x + 1] = db[1];
       }
     } else if (sl < 8) {
       const int e = sl - 4;
@@ -241,6 +258,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
   // The fences pin that order; left alone the scheduler puts all the side work first and the MFMAs in one block behind it.
   // (No run-time conditions in here: a stage has to stay ONE basic block, or the compiler peels and unswitches the chunk loop into
   //  versions with a branch behind every MFMA, and the first chunk of every tile ran ~6x slower than the others.)
+  auto sync_all = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  // end of a stage: this wave's LDS-DMA for the NEXT stage (and, at a = 2, the next chunk's halo) has landed -- a counted wait:
+  // N = VMEM operations issued after it (younger weight slices, halo pieces, the previous tile's stores) that may stay in flight
+  auto sync_counted = [&](auto n_tag) {
+    constexpr int N = decltype(n_tag)::value;
+    if (WINO_ABL & 1) return;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __syncthreads();
+  };
+  // MFMA operands of the stage in flight: [position][8-channel half].  Kernel scope: the first reads of stage s + 1 (positions 0, 1)
+  // are issued by stage s right behind its barrier, which stands a few MFMAs BEFORE the stage's end -- those MFMAs cover the LDS
+  // latency that would otherwise sit between the barrier and the next stage's first MFMA (measured time-neutral against the barrier
+  // at the very end: the head latency was not what the stage waits for).
+  f32x4 af[4][HALVES], bf[4][HALVES];
+  auto read_operand = [&](int A, int b, int h) {
+    if (WINO_ABL & 4) {
+      af[b][h] = bf[b][h] = (f32x4){1.f, 1.f, 1.f, 1.f};
+      return;
+    }
+    af[b][h] = *reinterpret_cast<const f32x4*>(lds + OFF_U + A * UQ + a_lane + b * (UQ / 4) + h * (CT * 16));
+    bf[b][h] = *reinterpret_cast<const f32x4*>(lds + OFF_V + (A & 1) * VQ + b_lane + b * 4096 + h * (NT * 16));
+  };
   struct Side {
     int t_rbuf, t_vbuf;    // transform row TA of halo buffer t_rbuf into V[t_vbuf]
     const float* u_src;    // weight slice u_src -> ring slot u_slot
@@ -248,22 +290,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
     const float* raw_src;  // RAW stages: halo of the chunk at raw_src -> halo buffer raw_buf
     int raw_buf;
   };
-  auto stage = [&](auto a_tag, auto ta_tag, auto raw_tag, auto zero_tag, const Side& sd) {
+  auto stage = [&](auto a_tag, auto ta_tag, auto raw_tag, auto zero_tag, auto wait_tag, const Side& sd) {
     constexpr int A = decltype(a_tag)::value;
     constexpr bool RAW = decltype(raw_tag)::value;
     constexpr bool ZERO = decltype(zero_tag)::value;   // first chunk of a tile: the first MFMA of each position starts from C = 0
-    const char* ua = lds + OFF_U + A * UQ + a_lane;
-    const char* vb = lds + OFF_V + (A & 1) * VQ + b_lane;
-    f32x4 af[4][HALVES], bf[4][HALVES];
     Tr t;
-    auto operand = [&](int b, int h) {
-      if (WINO_ABL & 4) {
-        af[b][h] = bf[b][h] = (f32x4){1.f, 1.f, 1.f, 1.f};
-        return;
-      }
-      af[b][h] = *reinterpret_cast<const f32x4*>(ua + b * (UQ / 4) + h * (CT * 16));
-      bf[b][h] = *reinterpret_cast<const f32x4*>(vb + b * 4096 + h * (NT * 16));
-    };
+    auto operand = [&](int b, int h) { read_operand(A, b, h); };
     auto tslice = [&](int q) {
       if (!(WINO_ABL & 2)) transform_slice(ta_tag, q, t, sd.t_rbuf, sd.t_vbuf);
     };
@@ -281,9 +313,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
           if (k < RAW_PER_WAVE - 1 || (k == RAW_PER_WAVE - 1 && wave == 0)) glds4(sd.raw_src, roff[k], dst + k * 1024);
       }
     };
-    // The side work behind MFMA number sl.  LDS reads (16 operand reads, 16 halo reads per lane) are spread over the first
-    // half of the stage: issued in one burst behind the barrier they queue ~770 clocks of LDS time into a 500-clock window and
-    // the wave stalls on its transform reads; the second half carries the VALU part, the V writes and the DMA issue.
+    // The side work behind MFMA number sl.  LDS reads (the rest of the stage's 16 operand reads, 16 halo reads per lane) are spread
+    // over the first third of the stage, then the transform's arithmetic and V writes, then the DMA issue; the stage's barrier
+    // stands behind slot BAR (everything the NEXT stage reads is complete by then: this stage's V writes and the LDS-DMA the
+    // counted wait covers; nothing reads this stage's U / V any more: the remaining MFMAs have their operands in registers).
+    constexpr int BAR = (CT == 64) ? 27 : 12;
     auto side = [&](int sl) {
       if (CT == 64) {
         if (sl == 0) operand(0, 1);
@@ -294,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
           else operand(2 + (q >> 2), (q >> 1) & 1);
         } else if (sl < 18) tslice(4 + (sl - 10));
         else if (sl == 18) dma_u();
-        else dma_raw(2 * (sl - 19), 2 * (sl - 19) + 2);
+        else if (sl <= BAR) dma_raw(3 * (sl - 19), 3 * (sl - 19) + 3);
       } else {
         if (sl == 0) tslice(0);
         else if (sl == 1) operand(2, 0);
@@ -305,14 +339,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
         else if (sl < 10) {
           tslice(4 + 2 * (sl - 6));
           tslice(5 + 2 * (sl - 6));
+          dma_raw(4 * (sl - 6), 4 * (sl - 6) + 4);
         } else if (sl == 10) dma_u();
-        else dma_raw(4 * (sl - 11), 4 * (sl - 11) + 4);
+        else if (sl == 11) dma_raw(16, RAW_PER_WAVE);
+      }
+      if (sl == BAR) {
+        sync_counted(wait_tag);
+        read_operand((A + 1) & 3, 0, 0);
+        read_operand((A + 1) & 3, 1, 0);
       }
     };
-    // before the first MFMA: what its first k-steps need (positions 0, 1; for CT 64 only their first 8-channel half)
-    operand(0, 0);
-    operand(1, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    // (the operands of the first k-steps -- positions 0, 1, first 8-channel half -- were read by the previous stage behind its barrier)
 #pragma unroll
     for (int pair = 0; pair < 2; ++pair)
 #pragma unroll
@@ -340,12 +377,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
     const int tile = wn * 32 + l31, ty = tile / TX, tx = tile % TX;
     const int cbase = T.ct * CT + wm * 32 + 4 * kg;              // C layout: row = (r & 3) + 8 * (r >> 2) + 4 * kg
     float* ob = a.out + ((size_t)T.b * a.Cout) * HpWp + (size_t)(T.y0 + 2 * ty + 1) * a.Wp + T.x0 + 2 * tx + PADL;
+    const int Hp_pool = padded_h(a.H / 2), Wp_pool = padded_w(a.W / 2);
+    const size_t HpWp_pool = (size_t)Hp_pool * Wp_pool;
+    float* pb = a.pool ? a.pool + (size_t)T.b * a.Cout * HpWp_pool + (size_t)(T.y0 / 2 + ty + 1) * Wp_pool + T.x0 / 2 + tx + PADL : nullptr;
     // the last MFMAs were issued before the stage's closing barrier; their results must have left the matrix pipe before an
     // AGPR read (a software-visible hazard on gfx950 that the compiler cannot see through the named registers)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float bias_r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias_r[r] = (WINO_ABL & 64) ? 0.f : a.bias[cbase + (r & 3) + 8 * (r >> 2)];
+    float ow[16];
+    float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;       // FUSE_OUTC: this lane's 16 channels of the 1x1 out-conv, per pixel
+    if (FUSE_OUTC) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ow[r] = a.outc_w[cbase + (r & 3) + 8 * (r >> 2)];
+    }
     static_for<16>([&](auto r_tag) {
       constexpr int R = decltype(r_tag)::value;
       float t0[4], t1[4];
@@ -376,26 +422,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
         y10 += r1[0];
         y11 += r1[1];
       }
-      if (!(WINO_ABL & 32) || y00 == 1.2345e-33f) {
+      if (FUSE_OUTC) {
+        s00 = fmaf(ow[R], y00, s00);
+        s01 = fmaf(ow[R], y01, s01);
+        s10 = fmaf(ow[R], y10, s10);
+        s11 = fmaf(ow[R], y11, s11);
+      } else if (!(WINO_ABL & 32) || y00 == 1.2345e-33f) {
         *reinterpret_cast<f32x2*>(o) = (f32x2){y00, y01};
         *reinterpret_cast<f32x2*>(o + a.Wp) = (f32x2){y10, y11};
+        if (a.pool) pb[(size_t)co * HpWp_pool] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));   // same association as maxpool2_kernel
       }
     });
+    if (FUSE_OUTC) {
+      // the other 16 channels sit in lane ^ 32; channels 0-3, 8-11, ... here (kg 0), 4-7, 12-15, ... there
+      s00 += __shfl_xor(s00, 32);
+      s01 += __shfl_xor(s01, 32);
+      s10 += __shfl_xor(s10, 32);
+      s11 += __shfl_xor(s11, 32);
+      const size_t px0 = ((size_t)T.b * a.H + T.y0 + 2 * ty) * a.W + T.x0 + 2 * tx;
+      const float ob0 = a.outc_b[0];
+      // both stores by every lane (kg 0 and 1 write identical values): the stage waits count exactly NST store instructions
+      const f32x2 xi0 = *reinterpret_cast<const f32x2*>(a.x_img + px0), xi1 = *reinterpret_cast<const f32x2*>(a.x_img + px0 + a.W);
+      const float v00 = xi0[0] + (s00 + ob0), v01 = xi0[1] + (s01 + ob0), v10 = xi1[0] + (s10 + ob0), v11 = xi1[1] + (s11 + ob0);
+      *reinterpret_cast<f32x2*>(a.img_pre + px0) = (f32x2){v00, v01};
+      *reinterpret_cast<f32x2*>(a.img_pre + px0 + a.W) = (f32x2){v10, v11};
+      *reinterpret_cast<f32x2*>(a.img + px0) = (f32x2){fminf(fmaxf(v00, 0.f), 1.f), fminf(fmaxf(v01, 0.f), 1.f)};
+      *reinterpret_cast<f32x2*>(a.img + px0 + a.W) = (f32x2){fminf(fmaxf(v10, 0.f), 1.f), fminf(fmaxf(v11, 0.f), 1.f)};
+    }
   };
 
-  auto sync_all = [&]() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-  };
-  // end of a stage: this wave's LDS-DMA for the NEXT stage (and, at a = 2, the next chunk's halo) has landed -- a counted wait:
-  // N = VMEM operations issued after it (younger weight slices, halo pieces, the previous tile's stores) that may stay in flight
-  auto sync_counted = [&](auto n_tag) {
-    constexpr int N = decltype(n_tag)::value;
-    if (WINO_ABL & 1) return;
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-    __syncthreads();
-  };
-  constexpr int NST = 32;                  // 8-byte stores per wave and tile
+  constexpr int NST = FUSE_OUTC ? 4 : 32;  // store instructions per wave and tile (a fused max-pool adds 16: the waits then err on the safe side)
   constexpr int NRAW = RAW_PER_WAVE - 1;   // halo gathers per wave (wave 0 issues one more: counted conservatively)
 
   int k = 0;
@@ -408,6 +464,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
   sync_all();
   transform(std::integral_constant<int, 0>{}, 0, 0);
   sync_all();
+  read_operand(0, 0, 0);
+  read_operand(0, 1, 0);
 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -422,14 +480,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
   auto chunk = [&](auto first_tag, const float* w_c, const float* nu, const float* nraw, int rcur) {
     constexpr int EPI = decltype(first_tag)::value ? NST : 0;
     const int rnext = rcur ^ 1;
-    stage(I0{}, I1{}, Yes{}, first_tag, Side{rcur, 1, w_c + 3 * (UQ / 4), 3, nraw, rnext});
-    sync_counted(std::integral_constant<int, NUW + EPI + NUW + NRAW>{});
-    stage(I1{}, I2{}, No{}, first_tag, Side{rcur, 0, nu, 0, nullptr, 0});
-    sync_counted(std::integral_constant<int, EPI + NUW + NRAW + NUW>{});
-    stage(I2{}, I3{}, No{}, first_tag, Side{rcur, 1, nu + (UQ / 4), 1, nullptr, 0});
-    sync_counted(std::integral_constant<int, 2 * NUW>{});
-    stage(I3{}, I0{}, No{}, first_tag, Side{rnext, 0, nu + 2 * (UQ / 4), 2, nullptr, 0});
-    sync_counted(std::integral_constant<int, 2 * NUW>{});
+    stage(I0{}, I1{}, Yes{}, first_tag, std::integral_constant<int, NUW + EPI + NUW + NRAW>{}, Side{rcur, 1, w_c + 3 * (UQ / 4), 3, nraw, rnext});
+    stage(I1{}, I2{}, No{}, first_tag, std::integral_constant<int, EPI + NUW + NRAW + NUW>{}, Side{rcur, 0, nu, 0, nullptr, 0});
+    stage(I2{}, I3{}, No{}, first_tag, std::integral_constant<int, 2 * NUW>{}, Side{rcur, 1, nu + (UQ / 4), 1, nullptr, 0});
+    stage(I3{}, I0{}, No{}, first_tag, std::integral_constant<int, 2 * NUW>{}, Side{rnext, 0, nu + 2 * (UQ / 4), 2, nullptr, 0});
   };
   auto raw_of = [&](const Tile& X, int c) { return ((CK * c < a.C0) ? X.s0 : X.s1) + (size_t)CK * c * HpWp; };
 
@@ -494,7 +548,7 @@ void pack_conv_weights_wino(const float* w, int cout, int cin, float* dst) {
             }
 }
 
-template <int CT>
+template <int CT, bool FUSE_OUTC>
 static int launch_wino(WinoArgs a, hipStream_t s) {
   using C = Cfg<CT>;
   a.nct = a.Cout / CT;
@@ -505,31 +559,64 @@ static int launch_wino(WinoArgs a, hipStream_t s) {
   int dev = 0;
   PNPX_HIP(hipGetDevice(&dev));
   if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-    PNPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ));
+    PNPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<CT, FUSE_OUTC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ));
     attr_done[dev] = true;
   }
   const long long ntiles = (long long)a.rx * a.ry * a.B * a.nct;
   long long grid = 256;
   if (grid >= ntiles) grid = ntiles;
   else if ((grid / 8) % a.nct != 0 && grid >= 8LL * a.nct) grid -= grid % (8 * a.nct);
-  hipLaunchKernelGGL(conv3x3_wino_f32_kernel<CT>, dim3((unsigned)grid), dim3(256), LDS_REQ, s, a);
+  hipLaunchKernelGGL((conv3x3_wino_f32_kernel<CT, FUSE_OUTC>), dim3((unsigned)grid), dim3(256), LDS_REQ, s, a);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
 
+// the layer can run with the UNet's out-conv fused into it (conv3x3_wino_outc)
+bool conv3x3_wino_outc_ok(int cin, int cout, int H, int W) { return cout == 32 && wino_ct(cin, 0, cout, H, W) == 32; }
+
+int launch_conv3x3_wino_outc(const float* u, const float* bias, const float* in0, int cin, const float* outc_w, const float* outc_b,
+                             const float* x_img, float* img, float* img_pre, int B, int H, int W, hipStream_t s) {
+  if (!conv3x3_wino_outc_ok(cin, 32, H, W)) {
+    set_error("conv3x3_wino_outc: unsupported geometry (%d -> 32 channels, %d x %d)", cin, H, W);
+    return PNPX_ERR_SHAPE;
+  }
+  WinoArgs a{};
+  a.in0 = in0;
+  a.in1 = in0;
+  a.u = u;
+  a.bias = bias;
+  a.out = nullptr;
+  a.outc_w = outc_w;
+  a.outc_b = outc_b;
+  a.x_img = x_img;
+  a.img = img;
+  a.img_pre = img_pre ? img_pre : img;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.Hp = padded_h(H);
+  a.Wp = padded_w(W);
+  a.C0 = cin;
+  a.C1 = 0;
+  a.Cout = 32;
+  a.slope = 0.2f;
+  return launch_wino<32, true>(a, s);
+}
+
 int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
-                        float* out, int B, int H, int W, hipStream_t s, float slope, const float* res) {
+                        float* out, int B, int H, int W, hipStream_t s, float slope, const float* res, float* pool_out) {
   const int ct = wino_ct(C0, C1, cout, H, W);
   if (!ct) {
     set_error("conv3x3_wino: unsupported geometry (%d + %d -> %d channels, %d x %d)", C0, C1, cout, H, W);
     return PNPX_ERR_SHAPE;
   }
-  WinoArgs a;
+  WinoArgs a{};
   a.in0 = in0;
   a.in1 = in1 ? in1 : in0;
   a.u = u;
   a.bias = bias;
   a.res = res;
+  a.pool = pool_out;
   a.out = out;
   a.B = B;
   a.H = H;
@@ -540,7 +627,7 @@ int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float
   a.C1 = C1;
   a.Cout = cout;
   a.slope = slope;
-  return ct == 64 ? launch_wino<64>(a, s) : launch_wino<32>(a, s);
+  return ct == 64 ? launch_wino<64, false>(a, s) : launch_wino<32, false>(a, s);
 }
 
 }  // namespace pnpx

@@ -81,41 +81,54 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
 // -- 8 loads per 4 outputs instead of 16 -- and picked by position.  Same expression per element as the scalar kernel.
 // Blocks of (x quads <= 64) x (256 / that many rows), grid.z = B * C.  Used when the output width is a multiple of 4.
 // (The pooling kernel stays scalar: four outputs per thread read 32-byte-strided 16-byte pieces and measured 0.129 vs 0.096 ms.)
+constexpr int UPS_ROWS = 4;   // output rows per thread of upsample2x_v4_kernel (the x-dependent terms are computed once per thread)
 __global__ __launch_bounds__(256) void upsample2x_v4_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w,
                                                             int Ht, int Wt, float sy, float sx) {
   const int W = 2 * w;
   const int hp = padded_h(h), wp = padded_w(w), Hp = padded_h(Ht), Wp = padded_w(Wt);
   const int xq = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (4 * xq >= W || y >= 2 * h) return;
+  const int yb = (blockIdx.y * blockDim.y + threadIdx.y) * UPS_ROWS;
+  if (4 * xq >= W || yb >= 2 * h) return;
   const size_t bc = blockIdx.z;
-  const float fy = sy * y;
-  const int y0 = (int)fy;
-  const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
-  const float ly = fy - y0, hy = 1.f - ly;
-  const float* s0 = src + bc * hp * wp + PADL + (size_t)(y0 + 1) * wp;
-  const float* s1 = src + bc * hp * wp + PADL + (size_t)(y1 + 1) * wp;
   const int xs = (int)(sx * (4 * xq));
-  float a0[4], a1[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int xi = xs + j < w ? xs + j : w - 1;
-    a0[j] = s0[xi];
-    a1[j] = s1[xi];
-  }
-  auto pick = [](const float* v, int i) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; };
-  float o[4];
+  int i0[4], i1[4], xi[4];
+  float lx[4], hx[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int x = 4 * xq + j;
     const float fx = sx * x;
     const int x0 = (int)fx;
     const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    const float lx = fx - x0, hx = 1.f - lx;
-    const int i0 = x0 - xs, i1 = x1 - xs;
-    o[j] = hy * (hx * pick(a0, i0) + lx * pick(a0, i1)) + ly * (hx * pick(a1, i0) + lx * pick(a1, i1));
+    lx[j] = fx - x0;
+    hx[j] = 1.f - lx[j];
+    i0[j] = x0 - xs;
+    i1[j] = x1 - xs;
+    xi[j] = xs + j < w ? xs + j : w - 1;
   }
-  *reinterpret_cast<float4*>(dst + bc * Hp * Wp + (size_t)(y + 1) * Wp + 4 * xq + PADL) = make_float4(o[0], o[1], o[2], o[3]);
+  auto pick = [](const float* v, int i) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; };
+  const float* sb = src + bc * hp * wp + PADL;
+  float* db = dst + bc * Hp * Wp + 4 * xq + PADL;
+#pragma unroll
+  for (int r = 0; r < UPS_ROWS; ++r) {
+    const int y = yb + r;
+    if (y >= 2 * h) break;
+    const float fy = sy * y;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = fy - y0, hy = 1.f - ly;
+    const float* s0 = sb + (size_t)(y0 + 1) * wp;
+    const float* s1 = sb + (size_t)(y1 + 1) * wp;
+    float a0[4], a1[4], o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a0[j] = s0[xi[j]];
+      a1[j] = s1[xi[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = hy * (hx[j] * pick(a0, i0[j]) + lx[j] * pick(a0, i1[j])) + ly * (hx[j] * pick(a1, i0[j]) + lx[j] * pick(a1, i1[j]));
+    *reinterpret_cast<float4*>(db + (size_t)(y + 1) * Wp) = make_float4(o[0], o[1], o[2], o[3]);
+  }
 }
 
 // outconv 1x1 (32 -> 1) + residual on channel 0 + clamp (models/unet.py:63-66,124-131; denoiser/base.py:32).
@@ -687,32 +700,40 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
                      W, padded_h(H), padded_w(W));
   PNPX_LAUNCH_CHECK();
   PNPX_TRY(rec.mark("prep_input", 0));
-  auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o) -> int {
+  // pooled: the encoder's MaxPool2d(2) of this layer's output, written by the same launch when the Winograd kernel runs the layer
+  // (one 2x2 output tile = one lane's four values); *pooled_done tells the caller whether the separate pooling kernel is still needed
+  auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o, const Act* pooled = nullptr, bool* pooled_done = nullptr) -> int {
     const ConvLayer& L = ctx->conv[li];
     const int C1 = i1 ? i1->C : 0;
+    if (pooled_done) *pooled_done = false;
     if (ctx->opt_fp32_winograd && ctx->conv_wino_u[li] && conv3x3_wino_ok(i0.C, C1, L.cout, o.H, o.W)) {
-      PNPX_TRY(launch_conv3x3_wino(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1, fptr(o), B, o.H, o.W, s));
+      PNPX_TRY(launch_conv3x3_wino(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1, fptr(o), B, o.H, o.W, s,
+                                   0.2f, nullptr, pooled ? fptr(*pooled) : nullptr));
+      if (pooled_done) *pooled_done = pooled != nullptr;
       return rec.mark("conv3x3_wino", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);   // algorithmic FLOPs; 4/9 of them executed
     } else {
       PNPX_TRY(launch_conv3x3(L, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1, fptr(o), B, o.H, o.W, s));
     }
     return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);
   };
-  auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o) -> int {
+  auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o, const Act* pooled = nullptr, bool* pooled_done = nullptr) -> int {
     const Act& ta = i1 ? P.da[lvl] : P.a[lvl];
     const Act& tb = i1 ? P.db[lvl] : P.b[lvl];
     PNPX_TRY(conv(li, i0, i1, ta));
     PNPX_TRY(conv(li + 1, ta, nullptr, tb));
-    return conv(li + 2, tb, nullptr, o);
+    return conv(li + 2, tb, nullptr, o, pooled, pooled_done);
   };
-  PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0]));
+  bool pooled = false;
+  PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0], &P.p[1], &pooled));
   for (int l = 1; l < 5; ++l) {
     const Act& src = P.x[l - 1];
-    const size_t n_pool = (size_t)B * src.C * (src.H / 2) * (src.W / 2);
-    hipLaunchKernelGGL(maxpool2_kernel, g1d(n_pool), dim3(256), 0, s, fptr(src), fptr(P.p[l]), n_pool, src.H, src.W);
-    PNPX_LAUNCH_CHECK();
-    PNPX_TRY(rec.mark("maxpool2", 0));
-    PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l]));
+    if (!pooled) {
+      const size_t n_pool = (size_t)B * src.C * (src.H / 2) * (src.W / 2);
+      hipLaunchKernelGGL(maxpool2_kernel, g1d(n_pool), dim3(256), 0, s, fptr(src), fptr(P.p[l]), n_pool, src.H, src.W);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(rec.mark("maxpool2", 0));
+    }
+    PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l], l < 4 ? &P.p[l + 1] : nullptr, &pooled));
   }
   const Act* below = &P.x[4];
   for (int l = 3; l >= 0; --l) {
@@ -722,7 +743,7 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     const size_t n_up = (size_t)B * below->C * (2 * h) * (2 * w);
     if ((2 * w) % 4 == 0 && (size_t)B * below->C <= 65535) {
       const int quads = w / 2, bx = quads >= 64 ? 64 : quads, by = 256 / bx;
-      hipLaunchKernelGGL(upsample2x_v4_kernel, dim3((quads + bx - 1) / bx, (2 * h + by - 1) / by, B * below->C), dim3(bx, by), 0, s,
+      hipLaunchKernelGGL(upsample2x_v4_kernel, dim3((quads + bx - 1) / bx, (2 * h + by * UPS_ROWS - 1) / (by * UPS_ROWS), B * below->C), dim3(bx, by), 0, s,
                          fptr(*below), fptr(P.u[l]), h, w, P.u[l].H, P.u[l].W, sy, sx);
     } else {
       hipLaunchKernelGGL(upsample2x_kernel, g1d(n_up), dim3(256), 0, s, fptr(*below), fptr(P.u[l]), n_up, h, w, P.u[l].H,
@@ -730,6 +751,17 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     }
     PNPX_LAUNCH_CHECK();
     PNPX_TRY(rec.mark("upsample2x", 0));
+    // the network's last 3x3 layer takes the 1x1 out-conv + residual + clamp into its epilogue when the Winograd kernel runs it
+    // (inference passes only: a training forward keeps the layer's output for the VJP)
+    const bool fuse_outc = l == 0 && !keep_all && ctx->opt_fuse_outc && ctx->opt_fp32_winograd && ctx->conv_wino_u[26] &&
+                           conv3x3_wino_outc_ok(ctx->conv[26].cin, ctx->conv[26].cout, H, W);
+    if (fuse_outc) {
+      PNPX_TRY(conv(24, P.x[0], &P.u[0], P.da[0]));
+      PNPX_TRY(conv(25, P.da[0], nullptr, P.db[0]));
+      PNPX_TRY(launch_conv3x3_wino_outc(ctx->conv_wino_u[26], ctx->conv[26].b, fptr(P.db[0]), ctx->conv[26].cin, ctx->outc_w, ctx->outc_b, x,
+                                        out, out_pre, B, H, W, s));
+      return rec.mark("conv3x3_wino", 2.0 * 9.0 * ctx->conv[26].cin * ctx->conv[26].cout * (double)H * W * B);
+    }
     PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l]));
     below = &P.y[l];
   }

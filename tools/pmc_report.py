@@ -83,6 +83,9 @@ if tot["n"]:
         json.dump({"B": geom[0], "H": geom[1], "W": geom[2], "conv_launches": tot["n"],
                    "hbm_bytes_per_forward": tot["bytes"], "hbm_bytes_per_conv_launch": tot["bytes"] / tot["n"],
                    "conv_us_profiled": tot["us"],
-                   "source": "profiles/" + re.sub(r"_pmc_traffic\.json$", "_denoiser_pmc_hs.md", jpath.split("/")[-1]) +
-                             " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md)"},
+                   "source": "profiles/" + (re.sub(r"_pmc_traffic_fp32\.json$", "_denoiser_pmc_fp32.md", jpath.split("/")[-1])
+                                            if jpath.endswith("_fp32.json") else
+                                            re.sub(r"_pmc_traffic\.json$", "_denoiser_pmc_hs.md", jpath.split("/")[-1])) +
+                             " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH doubled for the kernels matching "
+                             f"/{x2.pattern}/ per MI355X_MICROARCH.md)"},
                   open(jpath, "w"), indent=1)
