@@ -355,7 +355,7 @@ def test_fp32_winograd_layers_match_direct_kernel_and_oracle(unet_params):
     ctx = den.context(dev())
     assert ctx.get_option("fp32_winograd") == 1
     p64 = {k: torch.as_tensor(v).double() for k, v in unet_params.items()}
-    for B, H, W in [(2, 64, 64), (1, 128, 96), (3, 32, 64)]:
+    for B, H, W in [(2, 64, 64), (1, 128, 96), (3, 32, 64), (1, 32, 32), (5, 16, 32), (1, 48, 64)]:   # incl. one-region grids
         x, s = denoiser_inputs(B, H, W, 11 + B)
         xt, st = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
         ctx.set_option("fp32_winograd", 0)

@@ -45,9 +45,9 @@ for i, (n, ms, fl) in enumerate(acc):
     else:
         cls.setdefault(n, []).append(ms)
 if brief:
-    print("conv layers ms:", " ".join(f"{v:.3f}" for v in cls.get("conv3x3", [])))
+    print("conv layers ms:", " ".join(f"{v:.3f}" for v in cls.get("conv3x3", []) + cls.get("conv3x3_wino", [])))
     for n, v in cls.items():
-        if n != "conv3x3":
+        if n not in ("conv3x3", "conv3x3_wino"):
             print(f"{n}: {sum(v):.3f} ms over {len(v)} launches")
 print(f"total {tot:.3f} ms  conv {conv:.3f} ms  = {fl_tot/conv/1e9:.1f} TF/s   checksum {float(y.double().sum()):.10e} "
       f"lib {os.environ.get('PNPX_LIB', 'default')} " + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("PNPX_HS")))
