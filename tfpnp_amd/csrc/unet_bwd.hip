@@ -224,12 +224,20 @@ __global__ __launch_bounds__(256) void upsample_bwd_hs_kernel(const HsRec* __res
     const int rec = k >> 1, piece = k & 1;
     const int ry = rec / UB_W, rx = rec - ry * UB_W;
     const int yd = min(max(wy0 + ry, 0), H - 1), xd = min(max(wx0 + rx, 0), W - 1);
-    win[k] = gsrc[((size_t)(yd + 1) * (Wt + 2) + xd + 1) * 2 + piece];
+    // four planes [hi | lo][even | odd window column] of [UB_W][UB_W / 2] 16-byte pieces: the 16 lanes of a row (consecutive
+    // low-resolution pixels = every second window column) then read consecutive pieces -- with whole 32-byte records at a
+    // 64-byte lane stride the same reads were four-way bank-conflicted
+    win[((piece * 2 + (rx & 1)) * UB_W + ry) * (UB_W / 2) + (rx >> 1)] = gsrc[((size_t)(yd + 1) * (Wt + 2) + xd + 1) * 2 + piece];
   }
   __syncthreads();
   const int xs = xs0 + (threadIdx.x % UB_T), ys = ys0 + (threadIdx.x / UB_T);
   if (xs >= w || ys >= h) return;
-  const HsRec* wr = reinterpret_cast<const HsRec*>(win);
+  auto window = [&](int ry, int rx, float v[8]) {
+    HsRec r;
+    r.hi = *reinterpret_cast<const h8v*>(&win[((rx & 1) * UB_W + ry) * (UB_W / 2) + (rx >> 1)]);
+    r.lo = *reinterpret_cast<const h8v*>(&win[((2 + (rx & 1)) * UB_W + ry) * (UB_W / 2) + (rx >> 1)]);
+    hs_unpack(r, v);
+  };
   // interpolation weights of the 7 candidate high-resolution rows / columns 2*ys-3 .. 2*ys+3 towards THIS low-resolution
   // pixel, computed once (exactly the forward kernel's float arithmetic); the 7 x 7 loop below is fully unrolled and a
   // wave skips the (row, column) pairs none of its lanes needs -- same accumulation order as the plain double loop.
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_hs_kernel(const HsRec* __res
     for (int j = 0; j < 7; ++j) {
       if (wyv[i] != 0.f && wxv[j] != 0.f) {
         float v[8];
-        hs_unpack(wr[(oy + i) * UB_W + ox + j], v);
+        window(oy + i, ox + j, v);
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] += wyv[i] * wxv[j] * v[k];
       }
