@@ -376,3 +376,22 @@ def test_drunet_fp32_mode_is_the_prox_of_the_native_solver_loops(drunet_f32):
         zu_exact = float((v[:, 1:].cpu() == want[:, 1:]).float().mean())
         print(f"SPI+DRUNet (fp32 mode) iteration {i + 1}: x rel {x_err:.2e}, z/u bit-equal fraction {zu_exact:.5f}")
         assert x_err < 1e-4 and zu_exact > 0.995
+
+
+def test_drunet_fp32_mode_config5_image_size_matches_oracle_slice(drunet_f32):
+    """One SPI ADMM iteration at BASELINE config #5's image size (512 x 512; batch 8 of the 64) with the DRUNet prox in fp32
+    arithmetic (every level a multiple of 16: all ResBlock convolutions on the Winograd kernel); two items vs the CPU oracle."""
+    from tfpnp_amd.tasks.spi import ADMMSolver_SPI
+    B, H, W = 8, 512, 512
+    d = synth.make_spi_batch(B, H, W, K=6, seed=81)
+    sg = np.full((B, 1), 40 / 255.0, np.float32)
+    m = np.full((B, 1), 85.0, np.float32)
+    sol = ADMMSolver_SPI(drunet_f32)
+    x0, K = t(d["x0"]).to(dev()), t(d["K"]).to(dev())
+    v = sol((sol.reset({"x0": x0}), (x0, K)), (t(sg).to(dev()), t(m).to(dev())))
+    assert torch.isfinite(v).all()
+    with torch.no_grad():
+        x0c = t(d["x0"][:2])
+        want = O.spi_admm(O.DRUNetDenoiser(synth.make_drunet_params(0)), O.admm_reset(x0c), x0c, t(d["K"][:2]), t(sg[:2]),
+                          t(m[:2]))
+    assert rel(v[:2, :1], want[:, :1]) < 1e-4
