@@ -33,6 +33,9 @@ int launch_conv3x3(const ConvLayer& L, const float* in0, int C0, const float* in
 // ... with a chosen negative slope (0.2 = the UNet's LeakyReLU, 0 = ReLU, 1 = linear) and an optional residual operand
 int launch_conv3x3_act(const ConvLayer& L, const float* in0, int C0, const float* in1, int C1, float* out, int B,
                        int H, int W, float slope, const float* res, hipStream_t s);
+// 1x1 convolution on the same kernel (centre tap alone): L packed by pack_conv_weights_1x1 (mt 64, cc 8)
+int launch_conv1x1_act(const ConvLayer& L, const float* in0, float* out, int B, int H, int W, float slope, const float* res, hipStream_t s);
+void pack_conv_weights_1x1(const float* w, int cout, int cin, float* dst);
 // Input-gradient convolution: L holds the transposed, tap-flipped weights (pack_conv_weights_transposed).
 int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const float* dmask, int B, int H, int W,
                         hipStream_t s, const char* dmask_hs = nullptr);

@@ -39,7 +39,7 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_dst, 16, 0, 0);
 }
 
-template <int MT, int NBW, int CC, int MBW>
+template <int MT, int NBW, int CC, int MBW, int NTAP = 9>
 struct ConvGeom {
   static constexpr int MBH = 32 / MBW;
   static constexpr int NBLK = 4 * NBW;
@@ -52,16 +52,16 @@ struct ConvGeom {
   static constexpr int IN_INSTR = (IN_ELEMS + 63) / 64;
   static constexpr int IN_PAD = IN_INSTR * 64;
   static constexpr int NI = (IN_INSTR + 3) / 4;
-  static constexpr int W_ELEMS = 9 * CC * MT;
+  static constexpr int W_ELEMS = NTAP * CC * MT;      // NTAP 1: a 1x1 convolution = the centre tap alone
   static constexpr int W_INSTR = (W_ELEMS + 255) / 256;
   static constexpr int W_PAD = W_INSTR * 256;
   static constexpr int STAGE = IN_PAD + W_PAD;
   static constexpr int MTB = MT / 32;
 };
 
-template <int MT, int NBW, int CC, int MBW>
+template <int MT, int NBW, int CC, int MBW, int NTAP = 9>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
-  using G = ConvGeom<MT, NBW, CC, MBW>;
+  using G = ConvGeom<MT, NBW, CC, MBW, NTAP>;
   __shared__ __attribute__((aligned(16))) float lds[2 * G::STAGE];
 
   const int tid = threadIdx.x;
@@ -144,11 +144,11 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     const float* lin = lds + (ch & 1) * G::STAGE + b_lane;
     const float* lw = lds + (ch & 1) * G::STAGE + G::IN_PAD + a_lane;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int dy = NTAP == 1 ? 1 : tap / 3, dx = NTAP == 1 ? 1 : tap % 3;
       if (more) {
 #pragma unroll
-        for (int sl = tap; sl < NS; sl += 9) issue_slot(sl, nsrc, nw, nstage);
+        for (int sl = tap; sl < NS; sl += NTAP) issue_slot(sl, nsrc, nw, nstage);
       }
 #pragma unroll
       for (int cp = 0; cp < CC / 2; ++cp) {
@@ -211,14 +211,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   }
 }
 
-template <int MT, int NBW, int CC, int MBW>
+template <int MT, int NBW, int CC, int MBW, int NTAP = 9>
 static int launch_cfg(const ConvArgs& a0, int B, hipStream_t s) {
-  using G = ConvGeom<MT, NBW, CC, MBW>;
+  using G = ConvGeom<MT, NBW, CC, MBW, NTAP>;
   ConvArgs a = a0;
   a.tilesX = (a.W + G::TW - 1) / G::TW;
   a.tilesY = (a.H + G::TH - 1) / G::TH;
   const long long grid = (long long)a.nct * a.tilesX * a.tilesY * B;
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<MT, NBW, CC, MBW>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<MT, NBW, CC, MBW, NTAP>), dim3((unsigned)grid), dim3(256), 0, s, a);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
@@ -236,6 +236,45 @@ static int launch_mt_cc(const ConvArgs& a, int B, hipStream_t s) {
   if (mbw == 32) return nbw == 2 ? launch_cfg<MT, 2, CC, 32>(a, B, s) : launch_cfg<MT, 1, CC, 32>(a, B, s);
   if (mbw == 16) return nbw == 2 ? launch_cfg<MT, 2, CC, 16>(a, B, s) : launch_cfg<MT, 1, CC, 16>(a, B, s);
   return nbw == 2 ? launch_cfg<MT, 2, CC, 8>(a, B, s) : launch_cfg<MT, 1, CC, 8>(a, B, s);
+}
+
+// 1x1 convolution (+ bias, LeakyReLU(slope), optional residual) on the same kernel with the centre tap alone: cout % 64 == 0,
+// cin % 8 == 0, weights packed by pack_conv_weights_1x1 (the DRUNet's strided / transposed 2x2 layers in fp32 mode)
+int launch_conv1x1_act(const ConvLayer& L, const float* in0, float* out, int B, int H, int W, float slope, const float* res, hipStream_t s) {
+  if (L.mt != 64 || L.cc != 8 || L.cin % 8 != 0 || L.cout % 64 != 0) {
+    set_error("conv1x1: unsupported packing (cin %d cout %d mt %d cc %d)", L.cin, L.cout, L.mt, L.cc);
+    return PNPX_ERR_SHAPE;
+  }
+  ConvArgs a;
+  a.in0 = in0;
+  a.C0 = L.cin;
+  a.in1 = in0;
+  a.C1 = 0;
+  a.wpk = L.w;
+  a.bias = L.b;
+  a.out = out;
+  a.H = H;
+  a.W = W;
+  a.Hp = padded_h(H);
+  a.Wp = padded_w(W);
+  a.nct = L.cout / 64;
+  a.slope = slope;
+  a.mode = 0;
+  a.dmask = nullptr;
+  a.res = res;
+  const int mbw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
+  if (mbw == 32) return launch_cfg<64, 2, 8, 32, 1>(a, B, s);
+  if (mbw == 16) return launch_cfg<64, 2, 8, 16, 1>(a, B, s);
+  return launch_cfg<64, 2, 8, 8, 1>(a, B, s);
+}
+
+// w[cout][cin] -> [cout/64][cin/8][8][64]
+void pack_conv_weights_1x1(const float* w, int cout, int cin, float* dst) {
+  const int nct = cout / 64, nch = cin / 8;
+  for (int ct = 0; ct < nct; ++ct)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int c = 0; c < 8; ++c)
+        for (int m = 0; m < 64; ++m) dst[(((size_t)ct * nch + ch) * 8 + c) * 64 + m] = w[(size_t)(ct * 64 + m) * cin + ch * 8 + c];
 }
 
 int conv_pack_mt(int cout) { return cout >= 64 ? 64 : 32; }

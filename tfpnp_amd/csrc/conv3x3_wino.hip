@@ -117,7 +117,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define WINO_MFMA_FROM_ZERO(IDX, x, y) \
   asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, 0" ::"v"(x), "v"(y), "n"(16 * (IDX)), "n"(16 * (IDX) + 15))
 
-template <int CT, bool FUSE_OUTC>
+template <int CT, bool FUSE_OUTC, bool RES>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
   static_assert(!FUSE_OUTC || CT == 32, "the fused out-conv needs all 32 couts of a pixel in one wave");
   using C = Cfg<CT>;
@@ -386,6 +386,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
     float bias_r[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias_r[r] = (WINO_ABL & 64) ? 0.f : a.bias[cbase + (r & 3) + 8 * (r >> 2)];
+    // RES instances (the DRUNet's ResBlock skip): all 32 residual pairs up front -- loaded per row behind a run-time condition they
+    // cost sixteen serialised load latencies per tile
+    f32x2 rs0[RES ? 16 : 1], rs1[RES ? 16 : 1];
+    if (RES && !(WINO_ABL & 128)) {
+      const float* rb = a.res + (ob - a.out);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* rp = rb + (size_t)(cbase + (r & 3) + 8 * (r >> 2)) * HpWp;
+        rs0[r] = *reinterpret_cast<const f32x2*>(rp);
+        rs1[r] = *reinterpret_cast<const f32x2*>(rp + a.Wp);
+      }
+    }
     float ow[16];
     float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;       // FUSE_OUTC: this lane's 16 channels of the 1x1 out-conv, per pixel
     if (FUSE_OUTC) {
@@ -414,13 +426,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
       y10 = y10 > 0.f ? y10 : y10 * a.slope;
       y11 = y11 > 0.f ? y11 : y11 * a.slope;
       float* o = ob + (size_t)co * HpWp;
-      if (a.res && !(WINO_ABL & 128)) {
-        const float* rp = a.res + (o - a.out);
-        const f32x2 r0 = *reinterpret_cast<const f32x2*>(rp), r1 = *reinterpret_cast<const f32x2*>(rp + a.Wp);
-        y00 += r0[0];
-        y01 += r0[1];
-        y10 += r1[0];
-        y11 += r1[1];
+      if (RES && !(WINO_ABL & 128)) {
+        y00 += rs0[RES ? R : 0][0];
+        y01 += rs0[RES ? R : 0][1];
+        y10 += rs1[RES ? R : 0][0];
+        y11 += rs1[RES ? R : 0][1];
       }
       if (FUSE_OUTC) {
         s00 = fmaf(ow[R], y00, s00);
@@ -548,7 +558,7 @@ void pack_conv_weights_wino(const float* w, int cout, int cin, float* dst) {
             }
 }
 
-template <int CT, bool FUSE_OUTC>
+template <int CT, bool FUSE_OUTC, bool RES>
 static int launch_wino(WinoArgs a, hipStream_t s) {
   using C = Cfg<CT>;
   a.nct = a.Cout / CT;
@@ -559,14 +569,14 @@ static int launch_wino(WinoArgs a, hipStream_t s) {
   int dev = 0;
   PNPX_HIP(hipGetDevice(&dev));
   if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-    PNPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<CT, FUSE_OUTC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ));
+    PNPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<CT, FUSE_OUTC, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ));
     attr_done[dev] = true;
   }
   const long long ntiles = (long long)a.rx * a.ry * a.B * a.nct;
   long long grid = 256;
   if (grid >= ntiles) grid = ntiles;
   else if ((grid / 8) % a.nct != 0 && grid >= 8LL * a.nct) grid -= grid % (8 * a.nct);
-  hipLaunchKernelGGL((conv3x3_wino_f32_kernel<CT, FUSE_OUTC>), dim3((unsigned)grid), dim3(256), LDS_REQ, s, a);
+  hipLaunchKernelGGL((conv3x3_wino_f32_kernel<CT, FUSE_OUTC, RES>), dim3((unsigned)grid), dim3(256), LDS_REQ, s, a);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
@@ -600,7 +610,7 @@ int launch_conv3x3_wino_outc(const float* u, const float* bias, const float* in0
   a.C1 = 0;
   a.Cout = 32;
   a.slope = 0.2f;
-  return launch_wino<32, true>(a, s);
+  return launch_wino<32, true, false>(a, s);
 }
 
 int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
@@ -627,7 +637,8 @@ int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float
   a.C1 = C1;
   a.Cout = cout;
   a.slope = slope;
-  return ct == 64 ? launch_wino<64, false>(a, s) : launch_wino<32, false>(a, s);
+  if (res) return ct == 64 ? launch_wino<64, false, true>(a, s) : launch_wino<32, false, true>(a, s);
+  return ct == 64 ? launch_wino<64, false, false>(a, s) : launch_wino<32, false, false>(a, s);
 }
 
 }  // namespace pnpx

@@ -6,9 +6,8 @@
 //   * 3x3 layers: Winograd F(2x2,3x3) on the fp32 MFMA (conv3x3_wino.hip) where the level's size is a multiple of 16, the direct
 //     fp32 MFMA kernel (conv3x3.hip) elsewhere; ReLU = negative slope 0, the ResBlock skip = the kernels' residual operand;
 //   * strided 2x2 conv = space-to-depth re-layout + 1x1 conv over 4*Cin phase-major channels, transposed 2x2 conv = 1x1 conv to
-//     4*Cout phase-major channels + depth-to-space; the 1x1 convolutions run on the direct kernel as centre-tap 3x3 layers (the
-//     same weight tensors drunet.hip builds; 8/9 of those launches' products are zeros -- 10 % of the network's time, accepted
-//     for a mode whose purpose is the arithmetic, not the speed);
+//     4*Cout phase-major channels + depth-to-space; the 1x1 convolutions run on the direct kernel's one-tap instance
+//     (conv3x3.hip: launch_conv1x1_act; as centre-tap 3x3 launches they took 23 of 89 ms);
 //   * head (2 -> 64) on the direct kernel's 2-channel path from a padded [x | sigma] tensor, tail (64 -> 1) as a 32-cout launch whose
 //     channel 0 is clamped into the output image.
 // Activations are padded planar fp32 tensors (common.h), one arena per context.  Weights are packed on the first conv_mode-0 call
@@ -194,8 +193,15 @@ int prepare_weights(pnpx_ctx* ctx) {
     const int cc = conv_pack_cc(cin), mt = (cc == 2) ? 32 : conv_pack_mt(cout);   // (the 2-channel path exists for 32-cout tiles)
     align();
     woff[i] = host.size();
-    host.resize(host.size() + (size_t)cout * cin * 9);
-    pack_conv_weights(w3.data(), cout, cin, mt, cc, host.data() + woff[i]);
+    if (d.kind == 3 || d.kind == 4) {       // 1x1 over phase-major channels: the centre taps of w3, packed for the one-tap instance
+      std::vector<float> w1((size_t)cout * cin);
+      for (size_t q = 0; q < w1.size(); ++q) w1[q] = w3[q * 9 + 4];
+      host.resize(host.size() + w1.size());
+      pack_conv_weights_1x1(w1.data(), cout, cin, host.data() + woff[i]);
+    } else {
+      host.resize(host.size() + (size_t)cout * cin * 9);
+      pack_conv_weights(w3.data(), cout, cin, mt, cc, host.data() + woff[i]);
+    }
     lay[i].cin = cin;
     lay[i].cout = cout;
     lay[i].mt = mt;
@@ -282,7 +288,9 @@ int drunet_denoise_f32(pnpx_ctx* ctx, const float* x, const float* sigma, int si
   auto conv = [&](const float* in, float* outp, int h, int w, float slope, const float* res) -> int {
     const ConvLayer& Lc = N.f32_layers[li];
     const float* u = N.f32_wino[li];
+    const int kind = L[li].kind;
     ++li;
+    if (kind == 3 || kind == 4) return launch_conv1x1_act(Lc, in, outp, B, h, w, slope, res, s);
     if (u && ctx->opt_fp32_winograd && conv3x3_wino_ok(Lc.cin, 0, Lc.cout, h, w))
       return launch_conv3x3_wino(u, Lc.b, Lc.cout, in, Lc.cin, nullptr, 0, outp, B, h, w, s, slope, res);
     return launch_conv3x3_act(Lc, in, Lc.cin, nullptr, 0, outp, B, h, w, slope, res, s);
