@@ -509,6 +509,18 @@ def conv_algorithmic_bytes(B, H, W, min_cin=16):
     return tot
 
 
+def cpu_quota():
+    """What this process may actually use of the host: scheduler affinity and the cgroup CPU bandwidth limit (a container that owns
+    8 of 256 cores gets slower, not faster, with more threads)."""
+    q = {"affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            q["cgroup:" + os.path.basename(path)] = open(path).read().strip()
+        except OSError:
+            pass
+    return q
+
+
 def cpu_baseline(params, solver, dev, args, gpu_value):
     """The CPU oracle (oracle/pnp_oracle.py, pinned to the reference by tests/golden) timed on the host cores on
     a bounded sample: cpu_batch items x cpu_iters inner iterations of the same workload.  Also the accuracy gate:
@@ -523,19 +535,19 @@ def cpu_baseline(params, solver, dev, args, gpu_value):
     oden = O.Denoiser(params)
     v0 = O.admm_reset(t(d["x0"]))
     with torch.no_grad():
-        # oneDNN convolutions do not scale to every core of a large host: calibrate the thread count on a small
-        # slice (4 items x 1 iteration per candidate) and time the sample with the fastest one.
+        # oneDNN convolutions do not scale to every core of a large host (and a container may own a fraction of them: the quota
+        # is reported below): calibrate the thread count ON THE BATCH THE SAMPLE USES (all Bc items x 1 iteration per candidate;
+        # r4 calibrated on 4 items, whose working set behaves differently from 24 items' -- VERDICT r4 weak #8) and time the
+        # sample with the fastest one.  The sample's rate and the calibration's best rate are both in the JSON.
         best, threads, calib = None, cores, []
-        for n in sorted({c for c in (8, 16, 32, 64, 128, cores) if c <= cores}):
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
+        for n in sorted({c for c in (8, 16, 32, 64, usable) if c <= usable}):
             torch.set_num_threads(n)
             O.csmri_admm(oden, v0[:1], t(d["y0"][:1]), t(d["mask"][:1]), sig[:1, :1], mu[:1, :1])   # warm up
-            dt = None
-            for _ in range(2):                                        # best of two: the slice is short, hosts are noisy
-                t0 = time.perf_counter()
-                O.csmri_admm(oden, v0[:4], t(d["y0"][:4]), t(d["mask"][:4]), sig[:4, :1], mu[:4, :1])
-                e = time.perf_counter() - t0
-                dt = e if dt is None else min(dt, e)
-            calib.append({"threads": n, "s_per_4_image_iters": dt})
+            t0 = time.perf_counter()
+            O.csmri_admm(oden, v0, t(d["y0"]), t(d["mask"]), sig[:, :1], mu[:, :1])
+            dt = time.perf_counter() - t0
+            calib.append({"threads": n, "s_per_iteration_of_the_sample_batch": dt, "image_iters_per_s": Bc / dt})
             if best is None or dt < best:
                 best, threads = dt, n
         torch.set_num_threads(threads)
@@ -591,7 +603,9 @@ def cpu_baseline(params, solver, dev, args, gpu_value):
         "unit": "iters/s",
         "cores": threads,
         "host_cores": cores,
+        "cpu_quota": cpu_quota(),
         "thread_calibration": calib,
+        "calibration_best_image_iters_per_s": Bc / best,
         "kind": "port",
         "sample": f"{Bc} items x {Tc} inner iterations of CS-MRI ADMM {H}x{W} ({dt:.1f} s of CPU wall), "
                   f"scaled to env_batch={args.batch}",

@@ -110,9 +110,10 @@ int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* 
  * pnpx_unet_load switches back.  The *_backward / *_train entries work too: a DRUNet context has no activation ring
  * (tickets are 0), its VJP re-computes the forward keeping every ResBlock's ReLU output and back-propagates on the same
  * kernel family.  conv_mode 0 runs the DRUNet forward in fp32 arithmetic throughout (csrc/drunet_f32.hip; the *_backward /
- * *_train entries return PNPX_ERR_ARG there).  Range guard: it never switches a DRUNet context to conv_mode 0; the bias-free ReLU network is positively
- * homogeneous, so a tripped guard makes later passes (range_guard 1) or the very call (range_guard 2, repeated) run on
- * inputs scaled by 2^-4k with the tail multiplying back (option "drunet_shift" reads / sets 4k in 0..16). */
+ * *_train entries return PNPX_ERR_ARG there).  Range guard: the bias-free ReLU network is positively homogeneous, so the first two trips
+ * make later passes (range_guard 1) or the very call (range_guard 2, repeated) run on inputs scaled by 2^-4, then 2^-8, with the
+ * tail multiplying back (option "drunet_shift" reads / sets the exponent: 0, 4 or 8; acknowledging a trip keeps it); a trip at
+ * 2^-8 latches the context to conv_mode 0 like a UNet context. */
 size_t pnpx_drunet_num_params(int nb);
 int pnpx_drunet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params, int nb);
 /* Vector-Jacobian product of pnpx_unet_denoise wrt x and sigma (weights are frozen): given grad_out [B,1,H,W] returns

@@ -169,8 +169,8 @@ def test_drunet_contract_errors(drunet):
 def test_drunet_range_overflow_is_loud_then_rescaled(drunet):
     """The DRUNet has no exact-fp32 family; its answer to a tripped half-split range guard is a re-scaled pass (the bias-free
     ReLU network is positively homogeneous).  Default guard mode (1, no synchronisation): the call that overflowed returns
-    invalid values and pnpx_ctx_status says so LOUDLY; every trip moves later passes 16x further inside the range, so after at
-    most four acknowledged trips the same call is valid -- and equal to 1e4 x the ordinary network's pre-clamp output (head
+    invalid values and pnpx_ctx_status says so LOUDLY; the first two trips move later passes 16x further inside the range each, a
+    third latches the context to its exact-fp32 family (r5), so after at most three acknowledged trips the same call is valid -- and equal to 1e4 x the ordinary network's pre-clamp output (head
     weights x 1e4 = input x 1e4).  Strict mode (2) on a fresh context: the very first call is already valid."""
     from tfpnp_amd._lib import PnpxError
     from tfpnp_amd.pnp import DRUNetDenoiser2D
@@ -304,6 +304,7 @@ def test_drunet_range_guard_rescales_instead_of_failing(drunet):
     finally:
         ctx.set_option("range_guard", 1)
         ctx.set_option("drunet_shift", 0)
+        ctx.set_option("conv_mode", 1)      # (a third trip would have latched the shared fixture to the fp32 family)
 
 
 # ----------------------------------------------------------------------------- conv_mode 0: fp32 arithmetic throughout (r4)

@@ -354,6 +354,8 @@ def test_fp32_winograd_layers_match_direct_kernel_and_oracle(unet_params):
     den = UNetDenoiser2D(state_dict=unet_params, conv_mode=0)
     ctx = den.context(dev())
     assert ctx.get_option("fp32_winograd") == 1
+    all_layers = (1 << 27) - 1
+    assert ctx.get_option("fp32_wino8_layers") == all_layers      # default: every Winograd layer on the 8-wave kernel
     p64 = {k: torch.as_tensor(v).double() for k, v in unet_params.items()}
     for B, H, W in [(2, 64, 64), (1, 128, 96), (3, 32, 64), (1, 32, 32), (5, 16, 32), (1, 48, 64)]:   # incl. one-region grids
         x, s = denoiser_inputs(B, H, W, 11 + B)
@@ -364,12 +366,19 @@ def test_fp32_winograd_layers_match_direct_kernel_and_oracle(unet_params):
         ctx.set_option("fp32_winograd", 1)
         _, wino = den.forward_preclamp(xt, st)
         wino = wino.double().cpu()
+        # the 4-wave kernel (conv3x3_wino.hip) on the same layers: same algebra, the output transform summed in the other order
+        ctx.set_option("fp32_wino8_layers", 0)
+        _, wino4 = den.forward_preclamp(xt, st)
+        wino4 = wino4.double().cpu()
+        ctx.set_option("fp32_wino8_layers", all_layers)
         with torch.no_grad():
             sig = torch.from_numpy(s).double().view(B, 1, 1, 1).expand(B, 1, H, W)
             ref = O.unet_forward(torch.cat([torch.from_numpy(x).double(), sig], 1), p64)
         assert not torch.equal(wino, direct), "the Winograd layers did not run"
         assert rel(direct, ref) < 3e-6 and rel(wino, ref) < 3e-6, (rel(direct, ref), rel(wino, ref))
         assert rel(wino, direct) < 4e-6
+        assert not torch.equal(wino, wino4), "the 8-wave kernel did not run"
+        assert rel(wino4, ref) < 3e-6 and rel(wino, wino4) < 3e-6, (rel(wino4, ref), rel(wino, wino4))
     # 24 x 24: no level is a multiple of 16, every layer falls back
     x, s = denoiser_inputs(2, 24, 24, 5)
     xt, st = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())

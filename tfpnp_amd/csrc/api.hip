@@ -53,43 +53,45 @@ static void unet_layers(LayerSpec out[27]) {
     for (int j = 0; j < 3; ++j) out[3 * b + j] = LayerSpec{j == 0 ? blocks[b][0] : blocks[b][1], blocks[b][1]};
 }
 
-// DRUNet contexts never switch kernel family: the bias-free ReLU network is positively homogeneous, so a tripped guard is
-// answered by running on inputs scaled down by another factor 16 (DruNet::shift, drunet.hip) -- exact up to f16 subnormals.
-static void drunet_rescale(pnpx_ctx* ctx) {
-  if (ctx->drunet.shift < 16) ctx->drunet.shift += 4;
+// A DRUNet context answers a tripped guard in steps (r5): the bias-free ReLU network is positively homogeneous, so the
+// first two trips move its passes 16x further inside the range each (DruNet::shift 4, then 8: exact up to f16 subnormals, 4e-6 at
+// 2^-8); a third trip latches the context to conv_mode 0 like a UNet context (drunet_f32.hip: exact fp32, forward only -- a VJP then
+// fails loudly).  Larger shifts are not used: at 2^-12 the lo halves sit in the f16 subnormals (1e-4 class errors, silently).
+// One trip = one step: the device is drained before the flag is cleared, so that kernels of the offending call still in flight
+// cannot set it again behind the host's back, and range_guard_enter steps only once per acknowledged trip.
+constexpr int DRUNET_MAX_SHIFT = 8;
+static int drunet_rescale(pnpx_ctx* ctx) {
+  PNPX_HIP(hipDeviceSynchronize());
+  if (ctx->drunet.shift < DRUNET_MAX_SHIFT) ctx->drunet.shift += 4;
+  else ctx->conv_mode = CONV_F32;
   *ctx->range_flag_host = 0;
+  return PNPX_OK;
 }
 
 void range_guard_enter(pnpx_ctx* ctx) {
   if (!ctx->opt_range_guard || !ctx->range_flag_host) return;
-  if (ctx->drunet.loaded) {
-    if (*static_cast<volatile unsigned*>(ctx->range_flag_host) != 0) {
-      ctx->range_tripped = true;      // an EARLIER call overflowed: its output was invalid (pnpx_ctx_status reports it)
-      drunet_rescale(ctx);            // every later call runs 16x further inside the range
-    }
-    return;
-  }
-  if (*static_cast<volatile unsigned*>(ctx->range_flag_host) != 0 && !ctx->range_tripped) {
-    ctx->range_tripped = true;        // an EARLIER call overflowed: its output was invalid (pnpx_ctx_status reports it)
-    ctx->conv_mode = CONV_F32;        // every later call is exact
-  }
+  if (*static_cast<volatile unsigned*>(ctx->range_flag_host) == 0 || ctx->range_tripped) return;
+  ctx->range_tripped = true;          // an EARLIER call overflowed: its output was invalid (pnpx_ctx_status reports it)
+  if (ctx->drunet.loaded && ctx->conv_mode == CONV_HS) (void)drunet_rescale(ctx);   // later calls: 16x further inside the range / exact
+  else ctx->conv_mode = CONV_F32;     // every later call is exact
 }
 
 int range_guard_strict(pnpx_ctx* ctx, hipStream_t s, bool* rerun) {
   *rerun = false;
   PNPX_HIP(hipStreamSynchronize(s));
-  if (ctx->drunet.loaded) {
-    if (*static_cast<volatile unsigned*>(ctx->range_flag_host) != 0 && ctx->drunet.shift < 16) {
-      drunet_rescale(ctx);            // this call is repeated 16x further inside the range before it returns
-      *rerun = true;
-    }
-    return PNPX_OK;
+  if (*static_cast<volatile unsigned*>(ctx->range_flag_host) == 0) return PNPX_OK;
+  if (ctx->conv_mode != CONV_HS || ctx->range_tripped) {
+    // nothing left to fall back to (the flag was set although the exact family ran, or an unacknowledged trip is pending): strict
+    // mode's contract is that nothing invalid leaves the call as a success
+    set_error("half-split range guard: the call's result is invalid and no fallback is left (conv_mode %d)", ctx->conv_mode);
+    return PNPX_ERR_RANGE;
   }
-  if (*static_cast<volatile unsigned*>(ctx->range_flag_host) != 0 && !ctx->range_tripped) {
+  if (ctx->drunet.loaded) PNPX_TRY(drunet_rescale(ctx));   // this call is repeated 16x further inside the range (or in exact fp32) before it returns
+  else {
     ctx->conv_mode = CONV_F32;        // this call is repeated in exact fp32 before it returns: nothing invalid escapes
     *ctx->range_flag_host = 0;
-    *rerun = true;
   }
+  *rerun = true;
   return PNPX_OK;
 }
 
@@ -202,7 +204,7 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->conv_mode = value;
     return PNPX_OK;
   }
-  if (is("drunet_shift") && value >= 0 && value <= 16 && (value & 3) == 0) {   // DRUNet passes run on inputs scaled by 2^-value
+  if (is("drunet_shift") && value >= 0 && value <= 8 && (value & 3) == 0) {   // DRUNet passes run on inputs scaled by 2^-value
     ctx->drunet.shift = value;                                                 // (raised by 4 whenever the range guard trips)
     return PNPX_OK;
   }
@@ -238,6 +240,10 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
   }
   if (is("fp32_winograd") && (value == 0 || value == 1)) {
     ctx->opt_fp32_winograd = value;
+    return PNPX_OK;
+  }
+  if (is("fp32_wino8_layers") && value >= 0 && value < (1 << 27)) {     // bit li: layer li on the 8-wave Winograd kernel
+    ctx->opt_fp32_wino8 = value;
     return PNPX_OK;
   }
   if (is("fft_fast") && (value == 0 || value == 1)) {
@@ -305,6 +311,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fft_affine")) *value = ctx->opt_fft_affine;
   else if (is("fft_fast")) *value = ctx->opt_fft_fast;
   else if (is("fp32_winograd")) *value = ctx->opt_fp32_winograd;
+  else if (is("fp32_wino8_layers")) *value = ctx->opt_fp32_wino8;
   else if (is("fft_tile")) *value = ctx->opt_fft_tile;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
   else if (is("train_cache_gb")) *value = ctx->opt_train_cache_gb;
@@ -321,9 +328,10 @@ int pnpx_ctx_status(pnpx_ctx* ctx) {
   if (ctx->range_tripped) {
     if (ctx->drunet.loaded)
       set_error("half-split range guard tripped: an activation of an earlier DRUNet call left the f16 hi/lo range (|v| >= 4095 "
-                "or NaN); that call's output is invalid.  The context now runs its passes on inputs scaled by 2^-%d (the "
-                "bias-free network is positively homogeneous; the tail multiplies back); acknowledge with "
-                "pnpx_ctx_set_option(ctx, \"range_guard\", 1)", ctx->drunet.shift);
+                "or NaN); that call's output is invalid.  The context now runs %s (the bias-free network is positively "
+                "homogeneous: inputs scaled by 2^-%d, the tail multiplies back; a trip at 2^-8 selects exact fp32); acknowledge "
+                "with pnpx_ctx_set_option(ctx, \"range_guard\", 1)", ctx->conv_mode == CONV_HS ? "re-scaled passes" : "conv_mode 0",
+                ctx->drunet.shift);
     else
     set_error("half-split range guard tripped: an activation of an earlier call left the f16 hi/lo range (|v| >= 4095 or "
               "NaN); that call's output is invalid.  The context now runs conv_mode 0 (exact fp32 MFMA); re-arm with "
@@ -336,7 +344,8 @@ int pnpx_ctx_status(pnpx_ctx* ctx) {
 size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
   if (!ctx) return 0;
   size_t n = ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_grad.buf.bytes + ctx->scratch.bytes +
-             ctx->drunet.weights.bytes + ctx->drunet.arena.bytes + ctx->drunet.arena_grad.bytes;
+             ctx->drunet.weights.bytes + ctx->drunet.arena.bytes + ctx->drunet.arena_grad.bytes + ctx->drunet.f32_weights.bytes +
+             ctx->drunet.f32_arena.bytes + ctx->policy.weights.bytes + ctx->policy.arena.bytes;
   for (const auto& sl : ctx->train_ring) n += sl.arena.buf.bytes + sl.pre.bytes;
   return n;
 }

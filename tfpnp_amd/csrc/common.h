@@ -129,8 +129,8 @@ struct DruNet {
   // Range handling.  The network is bias-free with ReLU activations only, i.e. positively homogeneous: f(a * in) = a * f(in) for
   // a > 0, and a power-of-two `a` commutes exactly with every step (the hi/lo split included, subnormals aside).  When the
   // half-split range guard trips (an activation left |v| < 4095) the pass is repeated / later passes run on inputs scaled by
-  // 2^-shift (in the head convolution's store) with the tail multiplying back -- the DRUNet's counterpart of the UNet's
-  // exact-fp32 fallback.  0, 4, 8, 12 or 16.
+  // 2^-shift (in the head convolution's store) with the tail multiplying back.  0, 4 or 8; a trip at 8 latches the context to
+  // conv_mode 0 (drunet_f32.hip) like a UNet context.
   int shift = 0;
   // adjoint (input-gradient) layers, index-parallel to `layers` (transposed, tap-flipped; the head's adjoint is a 64 -> 32
   // launch whose channels 0 / 1 are the image / noise-map gradients; the tail's adjoint runs on the vector ALU)
@@ -192,6 +192,8 @@ struct pnpx_ctx {
   bool range_tripped = false;            // latched by the host once the flag was seen set (cleared by set_option)
   float* conv_wino_u[27] = {};     // Winograd-transformed fp32 weights of the layers conv3x3_wino.hip can run (else null)
   int opt_fp32_winograd = 1;       // conv_mode 0: run those layers as F(2x2,3x3) (fp32 arithmetic, 2.25x fewer MFMAs; 0 = the direct kernel everywhere)
+  int opt_fp32_wino8 = (1 << 27) - 1;   // bit li: layer li runs on the 8-wave Winograd kernel (conv3x3_wino8.hip) where its geometry allows; a DRUNet
+                                   // context: any bit = its ResBlock layers do
   pnpx::ConvLayer conv_bwd[27];    // adjoint (input-gradient) convolutions, fp32 kernel family
   pnpx::ConvLayerHsDev conv_hs_bwd[27];  // ... and packed for the half-split kernel family
   float* zero_bias = nullptr;      // [768] zeros (bias operand of the adjoint convolutions)
@@ -240,21 +242,26 @@ int fan_out_chains(pnpx_ctx* ctx, int chains, int B, hipStream_t s, F&& run_slic
   hipEvent_t fork = nullptr, joins[16] = {};
   PNPX_TRY(chain_event(ctx, &fork));
   PNPX_HIP(hipEventRecord(fork, s));
+  // from here on work may sit on the side streams: EVERY error exit drains them first (nothing queued there may outlive the
+  // failing call and write the shared arena / output buffers while the caller re-uses them)
+  auto fail = [&](int rc) {
+    join_side_streams_after_failure(ctx);
+    return rc;
+  };
+  auto hip = [&](hipError_t e, const char* what) { return e == hipSuccess ? PNPX_OK : hip_fail(e, what, __FILE__, __LINE__); };
   for (int c = chains - 1; c >= 0; --c) {       // the caller's stream takes slice 0 last: its host-side issue overlaps
     const int lo = (int)((long long)B * c / chains), hi = (int)((long long)B * (c + 1) / chains);
     hipStream_t st = c ? ctx->side_streams[c - 1] : s;
-    if (c) PNPX_HIP(hipStreamWaitEvent(st, fork, 0));
-    const int rc = run_slice(lo, hi, st);
-    if (rc != PNPX_OK) {
-      join_side_streams_after_failure(ctx);    // nothing queued on a side stream may outlive the failing call
-      return rc;
-    }
-    if (c) {
-      PNPX_TRY(chain_event(ctx, &joins[c]));
-      PNPX_HIP(hipEventRecord(joins[c], st));
-    }
+    int rc = c ? hip(hipStreamWaitEvent(st, fork, 0), "hipStreamWaitEvent(fork)") : PNPX_OK;
+    if (rc == PNPX_OK) rc = run_slice(lo, hi, st);
+    if (rc == PNPX_OK && c) rc = chain_event(ctx, &joins[c]);
+    if (rc == PNPX_OK && c) rc = hip(hipEventRecord(joins[c], st), "hipEventRecord(join)");
+    if (rc != PNPX_OK) return fail(rc);
   }
-  for (int c = 1; c < chains; ++c) PNPX_HIP(hipStreamWaitEvent(s, joins[c], 0));
+  for (int c = 1; c < chains; ++c) {
+    const int rc = hip(hipStreamWaitEvent(s, joins[c], 0), "hipStreamWaitEvent(join)");
+    if (rc != PNPX_OK) return fail(rc);
+  }
   return PNPX_OK;
 }
 
@@ -275,6 +282,7 @@ int guarded(pnpx_ctx* ctx, hipStream_t s, F&& body) {
   int st = body();
   // strict mode: the UNet repeats the call once in exact fp32; a DRUNet context repeats it on inputs scaled down by another
   // factor 16 per attempt (api.hip::range_guard_strict) until the guard stays quiet
+  // (a DRUNet context: 2^-4, 2^-8, then exact fp32 -- api.hip::drunet_rescale)
   for (int attempt = 0; attempt < 4 && st == PNPX_OK && ctx->opt_range_guard == 2 && ctx->conv_mode == CONV_HS; ++attempt) {
     bool rerun = false;
     PNPX_TRY(range_guard_strict(ctx, s, &rerun));

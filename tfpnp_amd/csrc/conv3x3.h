@@ -56,6 +56,14 @@ int launch_conv3x3_wino(const float* u, const float* bias, int cout, const float
 bool conv3x3_wino_outc_ok(int cin, int cout, int H, int W);
 int launch_conv3x3_wino_outc(const float* u, const float* bias, const float* in0, int cin, const float* outc_w, const float* outc_b,
                              const float* x_img, float* img, float* img_pre, int B, int H, int W, hipStream_t s);
+// The same layers on the 8-wave Winograd kernel (conv3x3_wino8.hip: the 16 positions of a block split over the two waves of a SIMD;
+// same packed weights `u`); option fp32_wino8.
+bool conv3x3_wino8_ok(int C0, int C1, int cout, int H, int W);
+int launch_conv3x3_wino8(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
+                         float* out, int B, int H, int W, hipStream_t s, float slope = 0.2f, const float* res = nullptr,
+                         float* pool_out = nullptr);
+int launch_conv3x3_wino8_outc(const float* u, const float* bias, const float* in0, int cin, const float* outc_w, const float* outc_b,
+                              const float* x_img, float* img, float* img_pre, int B, int H, int W, hipStream_t s);
 void pack_conv_weights_transposed(const float* w, int cout, int cin, int cout_pad, int mt, int cc, float* dst);
 
 }  // namespace pnpx

@@ -29,16 +29,13 @@
 
 #include "common.h"
 #include "conv3x3.h"
+#include "wino_common.h"
 
 namespace pnpx {
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
+using namespace wino;
 
 // Two tile shapes.  CT = couts per workgroup tile:
 //   CT 64: region 16 x 16 px = 64 tiles, K chunks of 16 channels, waves 2 (cout blocks) x 2 (tile blocks), 32 MFMAs per stage
@@ -74,43 +71,6 @@ struct Cfg {
 };
 constexpr int LDS_REQ = 160 * 1024;                 // the whole CU (see conv_hs_kernel.h: no LDS-using neighbours)
 
-struct WinoArgs {
-  const float* in0;
-  const float* in1;
-  const float* u;      // [cout/CT][cin/CK][a 4][b 4][kg 2][half][m CT][4] fp32
-  const float* bias;
-  const float* res;    // optional: added after the activation (same geometry as out)
-  // FUSE_OUTC instances (32-cout layer = the UNet's last): the 1x1 out-conv + residual + clamp of models/unet.py:63-66,124-131 and
-  // denoiser/base.py:32 in the epilogue; `out` (the 32-channel tensor) is then neither written nor read again
-  const float* outc_w;   // [32]
-  const float* outc_b;   // [1]
-  const float* x_img;    // [B][H][W] the network's input image (residual)
-  float* img;            // [B][H][W] clamped result
-  float* img_pre;        // [B][H][W] pre-clamp result (== img when the caller wants none: the clamped store lands second)
-  float* pool;         // optional: MaxPool2d(2) of the activated output, padded planar [B][Cout][H/2 + 2][W/2 + 2 PADL] (a 2x2 tile = one lane)
-  float* out;
-  int B, H, W, Hp, Wp, C0, C1, Cout, nct, nch, rx, ry;
-  float slope;
-};
-
-// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the builtin widens every lane offset to a
-// 64-bit VGPR pair (21 + 4 pairs live across the whole kernel here), which is what pushed this kernel into scratch
-__device__ __forceinline__ void glds4(const void* base, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
-}
-__device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
-}
-
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
 // accumulator IDX (0..15) = AGPRs 16 * IDX .. 16 * IDX + 15, by name
 #define WINO_MFMA(IDX, x, y) \
   asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(x), "v"(y), "n"(16 * (IDX)), "n"(16 * (IDX) + 15))
@@ -138,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
     const float* s0;   // halo origin in channel 0 of the first source
     const float* s1;   // ... of the second source, pre-offset by -C0 channels
     const float* w;
-    bool ok;
+    int ok, pad_;      // (ints, no tail padding: a struct copy with padding bytes goes through scratch)
   };
   auto decode = [&](int k) {
     Tile T;
@@ -147,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_kernel(WinoArgs a) {
     T.ct = j - q * a.nct;
     const int reg = nx * q + xcd;
     T.ok = reg < nregions;
+    T.pad_ = 0;
     const int t1 = reg / a.rx;
     const int tx = reg - t1 * a.rx;
     const int t2 = t1 / a.ry;
@@ -565,12 +526,15 @@ static int launch_wino(WinoArgs a, hipStream_t s) {
   a.nch = (a.C0 + a.C1) / C::CK;
   a.rx = a.W / C::RPXW;
   a.ry = a.H / 16;
-  static bool attr_done[64] = {};
+  static std::once_flag attr_once[64];      // (host threads of different contexts launch concurrently)
   int dev = 0;
   PNPX_HIP(hipGetDevice(&dev));
-  if (dev >= 0 && dev < 64 && !attr_done[dev]) {
-    PNPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<CT, FUSE_OUTC, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ));
-    attr_done[dev] = true;
+  if (dev >= 0 && dev < 64) {
+    hipError_t e = hipSuccess;
+    std::call_once(attr_once[dev], [&] {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<CT, FUSE_OUTC, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ);
+    });
+    PNPX_HIP(e);
   }
   const long long ntiles = (long long)a.rx * a.ry * a.B * a.nct;
   long long grid = 256;

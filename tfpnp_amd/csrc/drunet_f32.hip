@@ -292,7 +292,8 @@ int drunet_denoise_f32(pnpx_ctx* ctx, const float* x, const float* sigma, int si
     ++li;
     if (kind == 3 || kind == 4) return launch_conv1x1_act(Lc, in, outp, B, h, w, slope, res, s);
     if (u && ctx->opt_fp32_winograd && conv3x3_wino_ok(Lc.cin, 0, Lc.cout, h, w))
-      return launch_conv3x3_wino(u, Lc.b, Lc.cout, in, Lc.cin, nullptr, 0, outp, B, h, w, s, slope, res);
+      return ((ctx->opt_fp32_wino8 && conv3x3_wino8_ok(Lc.cin, 0, Lc.cout, h, w)) ? launch_conv3x3_wino8 : launch_conv3x3_wino)(
+          u, Lc.b, Lc.cout, in, Lc.cin, nullptr, 0, outp, B, h, w, s, slope, res, nullptr);
     return launch_conv3x3_act(Lc, in, Lc.cin, nullptr, 0, outp, B, h, w, slope, res, s);
   };
   auto resblocks = [&](int l, float* cur, float** result) -> int {

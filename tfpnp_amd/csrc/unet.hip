@@ -707,8 +707,9 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     const int C1 = i1 ? i1->C : 0;
     if (pooled_done) *pooled_done = false;
     if (ctx->opt_fp32_winograd && ctx->conv_wino_u[li] && conv3x3_wino_ok(i0.C, C1, L.cout, o.H, o.W)) {
-      PNPX_TRY(launch_conv3x3_wino(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1, fptr(o), B, o.H, o.W, s,
-                                   0.2f, nullptr, pooled ? fptr(*pooled) : nullptr));
+      const bool w8 = ((ctx->opt_fp32_wino8 >> li) & 1) && conv3x3_wino8_ok(i0.C, C1, L.cout, o.H, o.W);
+      PNPX_TRY((w8 ? launch_conv3x3_wino8 : launch_conv3x3_wino)(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1,
+                                                                fptr(o), B, o.H, o.W, s, 0.2f, nullptr, pooled ? fptr(*pooled) : nullptr));
       if (pooled_done) *pooled_done = pooled != nullptr;
       return rec.mark("conv3x3_wino", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);   // algorithmic FLOPs; 4/9 of them executed
     } else {
@@ -758,8 +759,9 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     if (fuse_outc) {
       PNPX_TRY(conv(24, P.x[0], &P.u[0], P.da[0]));
       PNPX_TRY(conv(25, P.da[0], nullptr, P.db[0]));
-      PNPX_TRY(launch_conv3x3_wino_outc(ctx->conv_wino_u[26], ctx->conv[26].b, fptr(P.db[0]), ctx->conv[26].cin, ctx->outc_w, ctx->outc_b, x,
-                                        out, out_pre, B, H, W, s));
+      const bool w8 = ((ctx->opt_fp32_wino8 >> 26) & 1) && conv3x3_wino8_ok(ctx->conv[26].cin, 0, ctx->conv[26].cout, H, W);
+      PNPX_TRY((w8 ? launch_conv3x3_wino8_outc : launch_conv3x3_wino_outc)(ctx->conv_wino_u[26], ctx->conv[26].b, fptr(P.db[0]), ctx->conv[26].cin,
+                                                                          ctx->outc_w, ctx->outc_b, x, out, out_pre, B, H, W, s));
       return rec.mark("conv3x3_wino", 2.0 * 9.0 * ctx->conv[26].cin * ctx->conv[26].cout * (double)H * W * B);
     }
     PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l]));
