@@ -62,6 +62,9 @@ bool conv3x3_wino8_ok(int C0, int C1, int cout, int H, int W);
 int launch_conv3x3_wino8(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
                          float* out, int B, int H, int W, hipStream_t s, float slope = 0.2f, const float* res = nullptr,
                          float* pool_out = nullptr);
+bool conv3x3_wino8_ups_ok(int C0, int C1, int cout, int H, int W);
+int launch_conv3x3_wino8_ups(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1_lowres, int C1,
+                             float* out, int B, int H, int W, hipStream_t s, float slope = 0.2f);
 int launch_conv3x3_wino8_outc(const float* u, const float* bias, const float* in0, int cin, const float* outc_w, const float* outc_b,
                               const float* x_img, float* img, float* img_pre, int B, int H, int W, hipStream_t s);
 void pack_conv_weights_transposed(const float* w, int cout, int cin, int cout_pad, int mt, int cc, float* dst);

@@ -63,6 +63,17 @@ struct Cfg8 {
   static constexpr int OFF_U = 0, OFF_V = 4 * USTG, OFF_RAW = OFF_V + 2 * VSTG;   // U: ring of four stage slots
   static constexpr int LDS_USED = OFF_RAW + 2 * RAW_BYTES;   // 140288 / 137728
   static constexpr int BAR = 12;                          // MFMA slot the stage's barrier stands behind
+  // UPS instances: the low-resolution window of a chunk's halo (NR x NQP source pixels per channel, 16-byte granules of 4 channels:
+  // [quad][row][column][4]) is staged by LDS-DMA two (CT 32: three) chunks ahead and interpolated into the halo buffer one chunk ahead
+  static constexpr int NR = 11, NQP = (CT == 64) ? 12 : 20;     // 18 (34) output pixels span <= 10 (18) source pixels + 1
+  static constexpr int QPLANE = NR * NQP * 16;               // bytes per channel quad
+  static constexpr int ST_ELEMS = CK * NR * NQP;
+  static constexpr int ST_INSTR = (ST_ELEMS + 63) / 64;      // 33 / 28
+  static constexpr int ST_STRIDE = ST_INSTR * 256;           // bytes per staging buffer: 8448 / 7168
+  static constexpr int ST_PER_WAVE = (ST_INSTR + 7) / 8, NSW = ST_INSTR / 8;   // 5, >= 4 / 4, >= 3
+  static constexpr int OFF_ST = LDS_USED, OFF_TAB = OFF_ST + 2 * ST_STRIDE;     // tables: 18 row + RW column entries of 16 bytes
+  static constexpr int LDS_USED_UPS = OFF_TAB + (18 + RW) * 16;
+  static constexpr int NPOSI = 18 * RW;                      // halo pixels per channel: 324 / 612
 };
 constexpr int LDS_REQ8 = 160 * 1024;                // the whole CU (see conv_hs_kernel.h: no LDS-using neighbours)
 
@@ -106,6 +117,12 @@ __device__ __forceinline__ void wino8_stamp(int wave, int lane, int& n, int tag)
 #define WINO8_STAMP(tag)
 #endif
 
+template <bool RAWDMA_, bool STDMA_, int IQ_>
+struct StageKind {
+  static constexpr bool RAWDMA = RAWDMA_, STDMA = STDMA_;
+  static constexpr int IQ = IQ_;
+};
+
 using I0 = std::integral_constant<int, 0>;
 using I1 = std::integral_constant<int, 1>;
 using I2 = std::integral_constant<int, 2>;
@@ -113,9 +130,10 @@ using I3 = std::integral_constant<int, 3>;
 using Yes = std::true_type;
 using No = std::false_type;
 
-template <int CT, bool FUSE_OUTC, bool RES>
+template <int CT, bool FUSE_OUTC, bool RES, bool UPS>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
   static_assert(!FUSE_OUTC || CT == 32, "the fused out-conv needs all 32 couts of a pixel in one SIMD's wave pair");
+  static_assert(!UPS || (!FUSE_OUTC && !RES), "the up-sampling instances are the UNet's plain decoder entries");
   using C = Cfg8<CT>;
   constexpr int CK = C::CK, HALVES = C::HALVES, KS = C::KS, RS = C::RS, NSTG = C::NSTG, NPOS = C::NPOS;
   constexpr int TX = C::TX, NT = C::NT, RW = C::RW, RPX = C::RPX, RPXL = C::RPXL;
@@ -140,8 +158,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     const float* s0;   // halo origin in channel 0 of the first source
     const float* s1;   // ... of the second source, pre-offset by -C0 channels
     const float* w;
-    int ok, pad_;      // (ints, no tail padding: a struct copy with padding bytes goes through scratch)
+    const float* s1u;  // UPS: origin of the low-resolution window in the second source, pre-offset by -C0 channels
+    int ok, rlo;       // (ints, no tail padding: a struct copy with padding bytes goes through scratch)
+    int clo, pad_;
   };
+  const int hpwp_lo = UPS ? (a.ups_h + 2) * (a.ups_w + 2 * PADL) : 0;
   auto decode = [&](int k) {
     Tile T;
     const int j = slot + nslot * k;
@@ -150,6 +171,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     const int reg = nx * q + xcd;
     T.ok = reg < nregions;
     T.pad_ = 0;
+    T.rlo = T.clo = 0;
+    T.s1u = nullptr;
     const int t1 = reg / a.rx;
     const int tx = reg - t1 * a.rx;
     const int t2 = t1 / a.ry;
@@ -161,6 +184,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     T.s0 = a.in0 + (size_t)T.b * a.C0 * HpWp + pix;
     T.s1 = a.in1 + ((long long)T.b * a.C1 - a.C0) * (long long)HpWp + (long long)pix;
     T.w = a.u + (size_t)T.ct * a.nch * 4 * (UQ / 4);
+    if (UPS) {
+      // window of source pixels: anchored at the source pixel of the halo's first row / column, pulled back so that its NR rows and
+      // NQP columns stay inside the padded low-resolution tensor (whose padding is zero: the only out-of-image taps have weight 0)
+      const int ya = T.y0 > 0 ? T.y0 - 1 : 0, xa = T.x0 > 0 ? T.x0 - 1 : 0;
+      const int rl = (int)(a.ups_sy * (float)ya), cl = (int)(a.ups_sx * (float)xa);
+      const int rmax = a.ups_h + 1 - C::NR, cmax = a.ups_w + PADL - C::NQP;
+      T.rlo = rl < rmax ? rl : rmax;
+      T.clo = cl < cmax ? cl : cmax;
+      T.s1u = a.in1 + ((long long)T.b * a.C1 - a.C0) * (long long)hpwp_lo + (long long)(T.rlo + 1) * (a.ups_w + 2 * PADL) + T.clo + PADL;
+    }
     return T;
   };
   auto raw_of = [&](const Tile& X, int c) { return ((CK * c < a.C0) ? X.s0 : X.s1) + (size_t)CK * c * HpWp; };
@@ -209,6 +242,104 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
         if (k < RAW_PER_WAVE) {
           if (k < C::NRAW || wave + 8 * k < C::RAW_INSTR) glds4(src, roff[k], dst + k * 2048);
         }
+    };
+
+    // -- UPS: staging DMA of a chunk's low-resolution window, an eighth per wave (offsets are tile-independent: no clamping, see decode)
+    constexpr int NR = C::NR, NQP = C::NQP, QPLANE = C::QPLANE, ST_STRIDE = C::ST_STRIDE, SPW = C::ST_PER_WAVE;
+    constexpr int OFF_ST = C::OFF_ST, OFF_TAB = C::OFF_TAB, NPOSI = C::NPOSI;
+    unsigned soff[UPS ? SPW : 1];
+    if (UPS) {
+      const int wp_lo = a.ups_w + 2 * PADL;
+#pragma unroll
+      for (int k = 0; k < SPW; ++k) {
+        const int idx = (wave + 8 * k) * 64 + lane;
+        const int e = idx & 3, g = idx >> 2;
+        const int q = g % NQP, g2 = g / NQP;
+        const int rr = g2 % NR, Q = g2 / NR;
+        soff[k] = (Q < CK / 4) ? 4u * (unsigned)((4 * Q + e) * hpwp_lo + rr * wp_lo + q) : 0u;
+      }
+    }
+    auto dma_st = [&](const float* src, int sbuf) {
+      if (!UPS || (WINO8_ABL & 4)) return;
+      const unsigned dst = lds0 + OFF_ST + sbuf * ST_STRIDE + wave * 256;
+#pragma unroll
+      for (int k = 0; k < SPW; ++k)
+        if (k < C::NSW || wave + 8 * k < C::ST_INSTR) glds4(src, soff[UPS ? k : 0], dst + k * 2048);
+    };
+    // per-tile tables of the interpolation: entry = (byte offset into a staging plane, weight of the nearer tap h, of the farther tap l, 0);
+    // rows 0..17 of the halo, then its RW columns.  Same arithmetic as upsample2x_v4_kernel (unet.hip): f = s * index, i0 = (int) f, l = f - i0,
+    // h = 1 - l.  Pixels outside the image (the convolution's zero padding) get weights 0.
+    auto write_tables = [&](const Tile& X) {
+      if (!UPS) return;
+      if (tid < 18 + RW) {
+        const bool row = tid < 18;
+        const int i = row ? tid : tid - 18;
+        const int g = (row ? X.y0 : X.x0) - 1 + i;                      // image coordinate of the halo row / column
+        const bool valid = g >= 0 && g < (row ? a.H : a.W);
+        const float f = (row ? a.ups_sy : a.ups_sx) * (float)g;
+        const int i0 = (int)f;
+        const float l = f - (float)i0, h = 1.f - l;
+        const int off = row ? (i0 - X.rlo) * NQP * 16 : (i0 - X.clo) * 16;
+        f32x4 ent;
+        ent[0] = __int_as_float(valid ? off : 0);
+        ent[1] = valid ? h : 0.f;
+        ent[2] = valid ? l : 0.f;
+        ent[3] = 0.f;
+        *reinterpret_cast<f32x4*>(lds + OFF_TAB + tid * 16) = ent;
+      }
+    };
+    // interpolation of one channel quad of a staged chunk into a halo buffer: one halo pixel per thread and pass (CT 64: 324 pixels,
+    // threads beyond repeat the last one; CT 32: 612 pixels = a full pass + a second one of the p = 0 waves), 6 slices per pass:
+    // 0 table entries, 1 the four taps (16 bytes = 4 channels each), 2..5 one channel each: v = hy (hx v00 + lx v01) + ly (hx v10 + lx v11)
+    struct Ip {
+      float hy, ly, hx, lx;
+      int base;
+      f32x4 v00, v01, v10, v11;
+    };
+    const int ipos = tid < NPOSI ? tid : NPOSI - 1;                      // pass A: halo pixel `tid`, the quad's 4 channels
+    // pass B (CT 32: 612 pixels > 512 threads): the remaining 100 pixels x 4 channels, one output per thread
+    const int ipos_b = (512 + (tid >> 2) < NPOSI) ? 512 + (tid >> 2) : NPOSI - 1;
+    auto interp_tables = [&](int pp, Ip& ip) {
+      const int hyi = pp / RW, hxi = pp - hyi * RW;
+      const f32x4 rt = *reinterpret_cast<const f32x4*>(lds + OFF_TAB + hyi * 16);
+      const f32x4 ct = *reinterpret_cast<const f32x4*>(lds + OFF_TAB + (18 + hxi) * 16);
+      ip.hy = rt[1];
+      ip.ly = rt[2];
+      ip.hx = ct[1];
+      ip.lx = ct[2];
+      ip.base = __float_as_int(rt[0]) + __float_as_int(ct[0]);
+    };
+    auto interp_slice = [&](auto q_tag, int sl, Ip& ip, int sbuf, int rbuf) {
+      constexpr int Q = decltype(q_tag)::value;
+      if (sl == 0) {
+        interp_tables(ipos, ip);
+      } else if (sl == 1) {
+        const char* b = lds + OFF_ST + sbuf * ST_STRIDE + Q * QPLANE + ip.base;
+        ip.v00 = *reinterpret_cast<const f32x4*>(b);
+        ip.v01 = *reinterpret_cast<const f32x4*>(b + 16);
+        ip.v10 = *reinterpret_cast<const f32x4*>(b + NQP * 16);
+        ip.v11 = *reinterpret_cast<const f32x4*>(b + NQP * 16 + 16);
+      } else {
+        const int e = sl - 2;
+        const float o = ip.hy * (ip.hx * ip.v00[e] + ip.lx * ip.v01[e]) + ip.ly * (ip.hx * ip.v10[e] + ip.lx * ip.v11[e]);
+        *reinterpret_cast<float*>(lds + OFF_RAW + rbuf * RAW_BYTES + ((4 * Q + e) * RPXL + ipos) * 4) = o;
+      }
+    };
+    auto interp_mini = [&](auto q_tag, int sl, Ip& ip, int sbuf, int rbuf) {      // slices 0 tables, 1 taps, 2 output
+      constexpr int Q = decltype(q_tag)::value;
+      const int e4 = (tid & 3) * 4;
+      if (sl == 0) {
+        interp_tables(ipos_b, ip);
+      } else if (sl == 1) {
+        const char* b = lds + OFF_ST + sbuf * ST_STRIDE + Q * QPLANE + ip.base + e4;
+        ip.v00[0] = *reinterpret_cast<const float*>(b);
+        ip.v01[0] = *reinterpret_cast<const float*>(b + 16);
+        ip.v10[0] = *reinterpret_cast<const float*>(b + NQP * 16);
+        ip.v11[0] = *reinterpret_cast<const float*>(b + NQP * 16 + 16);
+      } else {
+        const float o = ip.hy * (ip.hx * ip.v00[0] + ip.lx * ip.v01[0]) + ip.ly * (ip.hx * ip.v10[0] + ip.lx * ip.v11[0]);
+        *reinterpret_cast<float*>(lds + OFF_RAW + rbuf * RAW_BYTES + (4 * Q * RPXL + ipos_b) * 4 + e4 * RPXL) = o;
+      }
     };
 
     // -- input transform, shared by all eight waves.  CT 32: one tile and 4 channels (one 16-byte V write per position) per thread:
@@ -295,17 +426,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
       int u_dst;
       const float* raw_src;  // DMA (halo stages): halo at raw_src -> halo buffer raw_buf
       int raw_buf;
+      const float* st_src;   // UPS: staging DMA of the window at st_src -> staging buffer st_buf
+      int st_buf;
+      int i_sbuf, i_rbuf;    // UPS: interpolation from staging buffer i_sbuf into halo buffer i_rbuf
     };
+    // what a stage does besides its MFMAs / transform / weight DMA: RAWDMA the halo gathers, STDMA the staging gathers, IQ >= 0 the
+    // interpolation of channel quad IQ
+    // (StageKind<RAWDMA, STDMA, IQ>, namespace scope)
     // One pipeline stage S: 16 MFMAs per wave, one at a time with a slice of the stage's side work behind each (conv3x3_wino.hip
     // explains why the order is pinned by fences and why a stage must stay one basic block).  Behind slot BAR: the counted wait
     // (DMA waves: N = VMEM operations issued after the ones the NEXT stage needs) + barrier, then the next stage's first operands.
-    auto stage = [&](auto s_tag, auto zero_tag, auto wait_tag, auto prefetch_tag, const Side& sd) {
+    auto stage = [&](auto s_tag, auto zero_tag, auto wait_tag, auto prefetch_tag, auto kind_tag, const Side& sd) {
+      using K = decltype(kind_tag);
       constexpr int S = decltype(s_tag)::value;
       constexpr bool PREFETCH = decltype(prefetch_tag)::value;   // false: the tile's last stage (the epilogue follows and wants the registers)
       constexpr int SN = (S + 1) % NSTG;
       constexpr bool ZERO = decltype(zero_tag)::value;
       constexpr int WAITN = decltype(wait_tag)::value;
-      constexpr bool RAWST = (CT == 64) ? (S == 0) : (S == 1);
+      constexpr bool HALOST = (CT == 64) ? (S == 0) : (S == 1);     // the stage of a chunk that fetches halos / staging windows
+      constexpr bool RAWST = HALOST && K::RAWDMA;
+      constexpr bool STST = UPS && HALOST && K::STDMA;
+      constexpr int IQ = UPS ? K::IQ : -1;
+      using IQt = std::integral_constant<int, IQ < 0 ? 0 : IQ>;
+      Ip ipa, ipb;
+      auto islice = [&](int q) {
+        if (IQ >= 0) interp_slice(IQt{}, q, ipa, sd.i_sbuf, sd.i_rbuf);
+      };
+      auto imini = [&](int q) {
+        if (IQ >= 0 && CT == 32) interp_mini(IQt{}, q, ipb, sd.i_sbuf, sd.i_rbuf);
+      };
       using TA = std::integral_constant<int, (CT == 64) ? SN : 2 * SN + P>;
       using SNt = std::integral_constant<int, SN>;
       Tr t;
@@ -315,30 +464,44 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
       };
       auto side = [&](int sl) {
         if (CT == 64) {
-          // slices 0, 1: halo reads of the two channels; 2, 3: row combinations; 4..11: four position columns (even = nothing, odd = combine + write)
+          // transform slices 0, 1: halo reads of the two channels; 2, 3: row combinations; 4..11: four position columns (even = nothing,
+          // odd = combine + write) -- done by slot 6; the interpolation of an up-sampled chunk (tables, taps, four channels) follows in
+          // slots 5..10, so that the two never hold their registers together
           if (sl == 0) operand(0, 1);
           else if (sl == 1) operand(1, 1);
           if (sl < 2) tslice(sl);
           if (sl == 2) dma_u(sd.u_src, sd.u_dst);
           if (RAWST && sl >= 3 && sl < 9) dma_raw(sd.raw_src, sd.raw_buf, 2 * (sl - 3), 2 * (sl - 3) + 2);
-          if (sl == 4) tslice(2);
-          if (sl == 5) tslice(3);
-          if (sl >= 6 && sl < 10) tslice(5 + 2 * (sl - 6));
+          if (STST && sl == 9) dma_st(sd.st_src, sd.st_buf);
+          if (IQ < 0) {
+            if (sl == 4) tslice(2);
+            if (sl == 5) tslice(3);
+            if (sl >= 6 && sl < 10) tslice(5 + 2 * (sl - 6));
+          } else {
+            if (sl == 3) tslice(2), tslice(3);
+            if (sl == 4) tslice(5), tslice(7);
+            if (sl == 5) tslice(9), tslice(11), islice(0);
+            if (sl == 6) islice(1);
+            if (sl >= 8 && sl < 12) islice(2 + (sl - 8));
+          }
         } else {
+          // transform slices 0-3: halo reads of the four channels; 4-7: row combinations (a channel's right behind the next one's reads,
+          // so that two channels' raw values are live at a time); 8-11: position columns + writes.  UPS: pass A of the interpolation in
+          // slots 7..10 (where the stage's first operands and the raw values are dead), the single-output pass B in 9..11
           if (sl == 0) tslice(0);
           else if (sl == 1) operand(2, 0);
           else if (sl == 2) tslice(1);
           else if (sl == 3) operand(3, 0);
-          else if (sl == 4) tslice(2);
-          else if (sl == 5) tslice(3);
-          else if (sl < 10) {
-            tslice(4 + 2 * (sl - 6));
-            tslice(5 + 2 * (sl - 6));
-            if (RAWST) dma_raw(sd.raw_src, sd.raw_buf, 2 * (sl - 6), 2 * (sl - 6) + 2);
-          } else if (sl == 10) {
-            dma_u(sd.u_src, sd.u_dst);
-            if (RAWST) dma_raw(sd.raw_src, sd.raw_buf, 8, RAW_PER_WAVE);
-          }
+          else if (sl == 4) tslice(4), tslice(2);
+          else if (sl == 5) tslice(5), tslice(3);
+          else if (sl == 6) tslice(6), tslice(7);
+          else if (sl == 7) tslice(8), tslice(9), islice(0);
+          else if (sl == 8) tslice(10), tslice(11), islice(1);
+          else if (sl == 9) islice(2), islice(3), imini(0);
+          else if (sl == 10) islice(4), islice(5), imini(1), dma_u(sd.u_src, sd.u_dst);
+          else if (sl == 11) imini(2);
+          if (RAWST && sl >= 6 && sl < 11) dma_raw(sd.raw_src, sd.raw_buf, 2 * (sl - 6), 2 * (sl - 6) + 2);
+          if (STST && sl == 9) dma_st(sd.st_src, sd.st_buf);
         }
         if (sl == BAR) {
           if (!(WINO8_ABL & 8)) {
@@ -547,20 +710,36 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     // next chunk, nraw = halo of the chunk the halo stage fetches (CT 64: the next one, CT 32: the one after) -- in the next tile(s)
     // at a tile's end; after the walk's last chunk they name this tile's first chunks again (surplus loads into buffers nobody reads,
     // so that no stage carries a condition).
-    auto chunk = [&](auto first_tag, auto last_tag, const float* w_c, const float* nu, const float* nraw, int cc) {
+    // K1 / K2 / K3: the chunk 1 / 2 / 3 after this one comes from the up-sampled source (UPS instances; same tile).  CT 64: stage 0
+    // fetches the next chunk's halo (or, K1, interpolates its quads 1-3 in stages 0-2) and stages the window of the chunk after (K2),
+    // whose quad 0 stage 3 interpolates.  CT 32: stage 0 interpolates quad 1 of the next chunk (K1); stage 1 fetches the halo of the
+    // chunk after (or, K2, interpolates its quad 0) and stages the window of the third (K3).
+    auto chunk = [&](auto first_tag, auto k1_tag, auto k2_tag, auto k3_tag, const float* w_c, const float* nu, const float* nraw,
+                     const float* nst, int cc) {
       constexpr int EPI = decltype(first_tag)::value ? NST : 0;
+      constexpr bool K1 = UPS && decltype(k1_tag)::value, K2 = UPS && decltype(k2_tag)::value, K3 = UPS && decltype(k3_tag)::value;
+      constexpr int NSW = C::NSW;
       using Pre = Yes;   // (a tile's last stage could leave its prefetch to the epilogue's registers: not needed, the epilogue fits)
-      (void)last_tag;
       const int rcur = cc & 1, rnext = rcur ^ 1;
       if constexpr (CT == 64) {
-        stage(I0{}, first_tag, std::integral_constant<int, NUW + EPI + NUW + NRAW>{}, Yes{}, Side{rcur, 0, 1, w_c + 3 * (UQ / 4), 3, nraw, rnext});
-        stage(I1{}, first_tag, std::integral_constant<int, EPI + NUW + NRAW + NUW>{}, Yes{}, Side{rcur, 1, 2, nu, 0, nullptr, 0});
-        stage(I2{}, first_tag, std::integral_constant<int, 2 * NUW>{}, Yes{}, Side{rcur, 2, 3, nu + (UQ / 4), 1, nullptr, 0});
-        stage(I3{}, first_tag, std::integral_constant<int, 2 * NUW>{}, Pre{}, Side{rnext, 3, 0, nu + 2 * (UQ / 4), 2, nullptr, 0});
+        using S0k = StageKind<!K1, K2, K1 ? 1 : -1>;
+        using S1k = StageKind<false, false, K1 ? 2 : -1>;
+        using S2k = StageKind<false, false, K1 ? 3 : -1>;
+        using S3k = StageKind<false, false, K2 ? 0 : -1>;
+        constexpr int HALO = (K1 ? 0 : NRAW) + (K2 ? NSW : 0);      // VMEM operations of stage 0 beyond its weight slice
+        stage(I0{}, first_tag, std::integral_constant<int, NUW + EPI + NUW + HALO>{}, Yes{}, S0k{},
+              Side{rcur, 0, 1, w_c + 3 * (UQ / 4), 3, nraw, rnext, nst, rcur, rnext, rnext});
+        stage(I1{}, first_tag, std::integral_constant<int, EPI + NUW + HALO + NUW>{}, Yes{}, S1k{},
+              Side{rcur, 1, 2, nu, 0, nullptr, 0, nullptr, 0, rnext, rnext});
+        stage(I2{}, first_tag, std::integral_constant<int, 2 * NUW>{}, Yes{}, S2k{}, Side{rcur, 2, 3, nu + (UQ / 4), 1, nullptr, 0, nullptr, 0, rnext, rnext});
+        stage(I3{}, first_tag, std::integral_constant<int, 2 * NUW>{}, Pre{}, S3k{}, Side{rnext, 3, 0, nu + 2 * (UQ / 4), 2, nullptr, 0, nullptr, 0, rcur, rcur});
       } else {
+        using S0k = StageKind<false, false, K1 ? 1 : -1>;
+        using S1k = StageKind<!K2, K3, K2 ? 0 : -1>;
         const int u0 = 2 * rcur, n0 = 2 * rnext;      // ring slots of this chunk's and the next chunk's stages
-        stage(I0{}, first_tag, std::integral_constant<int, NUW + EPI>{}, Yes{}, Side{rcur, u0, u0 + 1, nu, n0, nullptr, 0});
-        stage(I1{}, first_tag, std::integral_constant<int, NUW + NRAW>{}, Pre{}, Side{rnext, u0 + 1, n0, nu + (USTG / 4), n0 + 1, nraw, rcur});
+        stage(I0{}, first_tag, std::integral_constant<int, NUW + EPI>{}, Yes{}, S0k{}, Side{rcur, u0, u0 + 1, nu, n0, nullptr, 0, nullptr, 0, rnext, rnext});
+        stage(I1{}, first_tag, std::integral_constant<int, NUW + (K2 ? 0 : NRAW) + (K3 ? NSW : 0)>{}, Pre{}, S1k{},
+              Side{rnext, u0 + 1, n0, nu + (USTG / 4), n0 + 1, nraw, rcur, nst, rnext, rcur, rcur});
       }
     };
 
@@ -572,10 +751,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
       for (int c = 0; c < a.nch; ++c, ++cc) {
         const float* w_c = T.w + (size_t)c * 4 * (UQ / 4);
         const float* nu = (c + 1 < a.nch) ? w_c + 4 * (UQ / 4) : Tn.w;
-        constexpr int AH = (CT == 64) ? 1 : 2;
+        constexpr int AH = (CT == 64) ? 1 : 2;        // chunks ahead the halo stage fetches; the staging stage: one more
         const float* nraw = (c + AH < a.nch) ? raw_of(T, c + AH) : raw_of(Tn, c + AH - a.nch);
-        if (c == 0) chunk(Yes{}, No{}, w_c, nu, nraw, cc);
-        else chunk(No{}, No{}, w_c, nu, nraw, cc);
+        if constexpr (!UPS) {
+          if (c == 0) chunk(Yes{}, No{}, No{}, No{}, w_c, nu, nraw, nullptr, cc);
+          else chunk(No{}, No{}, No{}, No{}, w_c, nu, nraw, nullptr, cc);
+        } else {
+          const int cu = a.C0 / CK;                   // first chunk of the up-sampled source (host: >= 3 / 4, so chunk 0 is plain)
+          auto ups = [&](int j) { return c + j < a.nch && c + j >= cu; };
+          const bool k1 = ups(1), k2 = ups(2), k3 = (CT == 32) && ups(3);
+          const float* nst = T.s1u + (size_t)CK * (c + AH + 1) * hpwp_lo;      // window of chunk c + 2 (CT 32: c + 3)
+          if (c == 0) {
+            write_tables(T);                          // (read from the first interpolation on, several barriers later)
+            chunk(Yes{}, No{}, No{}, No{}, w_c, nu, nraw, nst, cc);
+          } else if constexpr (CT == 64) {
+            if (!k1 && !k2) chunk(No{}, No{}, No{}, No{}, w_c, nu, nraw, nst, cc);
+            else if (!k1 && k2) chunk(No{}, No{}, Yes{}, No{}, w_c, nu, nraw, nst, cc);
+            else if (k1 && k2) chunk(No{}, Yes{}, Yes{}, No{}, w_c, nu, nraw, nst, cc);
+            else chunk(No{}, Yes{}, No{}, No{}, w_c, nu, nraw, nst, cc);
+          } else {
+            if (!k1 && !k2 && !k3) chunk(No{}, No{}, No{}, No{}, w_c, nu, nraw, nst, cc);
+            else if (!k1 && !k2) chunk(No{}, No{}, No{}, Yes{}, w_c, nu, nraw, nst, cc);
+            else if (!k1 && k3) chunk(No{}, No{}, Yes{}, Yes{}, w_c, nu, nraw, nst, cc);
+            else if (k1 && k2 && k3) chunk(No{}, Yes{}, Yes{}, Yes{}, w_c, nu, nraw, nst, cc);
+            else if (k1 && k2) chunk(No{}, Yes{}, Yes{}, No{}, w_c, nu, nraw, nst, cc);
+            else if (k1) chunk(No{}, Yes{}, No{}, No{}, w_c, nu, nraw, nst, cc);
+            else chunk(No{}, No{}, Yes{}, No{}, w_c, nu, nraw, nst, cc);      // (k2 alone: two-chunk up-sampled sources)
+          }
+        }
       }
       // LDS free during the epilogue (nothing reads it, no DMA in flight targets it, the next stages refill it only behind the
       // epilogue's closing barrier): CT 64 -- weight slot 3 and V[1] (the last stage's), the halo buffer of the tile's last chunk, and
@@ -611,10 +814,10 @@ static int wino8_ct(int C0, int C1, int cout, int H, int W) {
 }
 bool conv3x3_wino8_ok(int C0, int C1, int cout, int H, int W) { return wino8_ct(C0, C1, cout, H, W) != 0; }
 
-template <int CT, bool FUSE_OUTC, bool RES>
+template <int CT, bool FUSE_OUTC, bool RES, bool UPS = false>
 static int launch_wino8(WinoArgs a, hipStream_t s) {
   using C = Cfg8<CT>;
-  static_assert(C::LDS_USED <= LDS_REQ8, "LDS budget");
+  static_assert(C::LDS_USED <= LDS_REQ8 && C::LDS_USED_UPS <= LDS_REQ8, "LDS budget");
   a.nct = a.Cout / CT;
   a.nch = (a.C0 + a.C1) / C::CK;
   a.rx = a.W / C::RPXW;
@@ -625,7 +828,7 @@ static int launch_wino8(WinoArgs a, hipStream_t s) {
   if (dev >= 0 && dev < 64) {
     hipError_t e = hipSuccess;
     std::call_once(attr_once[dev], [&] {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32_kernel<CT, FUSE_OUTC, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ8);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32_kernel<CT, FUSE_OUTC, RES, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ8);
     });
     PNPX_HIP(e);
   }
@@ -633,7 +836,7 @@ static int launch_wino8(WinoArgs a, hipStream_t s) {
   long long grid = 256;
   if (grid >= ntiles) grid = ntiles;
   else if ((grid / 8) % a.nct != 0 && grid >= 8LL * a.nct) grid -= grid % (8 * a.nct);
-  hipLaunchKernelGGL((conv3x3_wino8_f32_kernel<CT, FUSE_OUTC, RES>), dim3((unsigned)grid), dim3(512), LDS_REQ8, s, a);
+  hipLaunchKernelGGL((conv3x3_wino8_f32_kernel<CT, FUSE_OUTC, RES, UPS>), dim3((unsigned)grid), dim3(512), LDS_REQ8, s, a);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
@@ -665,6 +868,45 @@ int launch_conv3x3_wino8_outc(const float* u, const float* bias, const float* in
   a.Cout = 32;
   a.slope = 0.2f;
   return launch_wino8<32, true, false>(a, s);
+}
+
+// The decoder entries of the UNet with the bilinear x2 (align_corners) up-sampling of their second source inside the kernel: in1 is the
+// LOW-resolution tensor (C1 channels, H/2 x W/2, padded planar).  The first source must hold >= 3 (cout % 64 == 0) / 4 chunks.
+bool conv3x3_wino8_ups_ok(int C0, int C1, int cout, int H, int W) {
+  const int ct = wino8_ct(C0, C1, cout, H, W);
+  if (!ct || C1 <= 0 || H % 2 || W % 2) return false;
+  const int h = H / 2, w = W / 2;
+  if (ct == 64) return C0 / 16 >= 3 && h + 1 >= Cfg8<64>::NR && w + PADL >= Cfg8<64>::NQP;
+  return C0 / 8 >= 4 && h + 1 >= Cfg8<32>::NR && w + PADL >= Cfg8<32>::NQP;
+}
+
+int launch_conv3x3_wino8_ups(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1_lowres, int C1,
+                             float* out, int B, int H, int W, hipStream_t s, float slope) {
+  if (!conv3x3_wino8_ups_ok(C0, C1, cout, H, W)) {
+    set_error("conv3x3_wino8_ups: unsupported geometry (%d + up(%d) -> %d channels, %d x %d)", C0, C1, cout, H, W);
+    return PNPX_ERR_SHAPE;
+  }
+  WinoArgs a{};
+  a.in0 = in0;
+  a.in1 = in1_lowres;
+  a.u = u;
+  a.bias = bias;
+  a.out = out;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.Hp = padded_h(H);
+  a.Wp = padded_w(W);
+  a.C0 = C0;
+  a.C1 = C1;
+  a.Cout = cout;
+  a.slope = slope;
+  a.ups_h = H / 2;
+  a.ups_w = W / 2;
+  // models/unet.py:99 (align_corners = True): source = destination * (in - 1) / (out - 1); the same two floats as unet.hip hands upsample2x_v4_kernel
+  a.ups_sy = (H > 1) ? (float)(H / 2 - 1) / (float)(H - 1) : 0.f;
+  a.ups_sx = (W > 1) ? (float)(W / 2 - 1) / (float)(W - 1) : 0.f;
+  return wino8_ct(C0, C1, cout, H, W) == 64 ? launch_wino8<64, false, false, true>(a, s) : launch_wino8<32, false, false, true>(a, s);
 }
 
 int launch_conv3x3_wino8(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,

@@ -742,7 +742,13 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
     const size_t n_up = (size_t)B * below->C * (2 * h) * (2 * w);
-    if ((2 * w) % 4 == 0 && (size_t)B * below->C <= 65535) {
+    // r5: the decoder entry interpolates its second source itself (conv3x3_wino8.hip UPS instances: the low-resolution window of a
+    // chunk's halo staged in LDS, bilinear x2 into the halo buffer) -- no up-sampled tensor in HBM (models/unet.py:92-121)
+    const int li0 = 15 + 3 * (3 - l);
+    const bool ups_fused = !keep_all && ctx->opt_fp32_fuse_up && ctx->opt_fp32_winograd && ctx->conv_wino_u[li0] && ((ctx->opt_fp32_wino8 >> li0) & 1) &&
+                           P.x[l].H == 2 * h && P.x[l].W == 2 * w && conv3x3_wino8_ups_ok(P.x[l].C, below->C, ctx->conv[li0].cout, 2 * h, 2 * w);
+    if (ups_fused) {
+    } else if ((2 * w) % 4 == 0 && (size_t)B * below->C <= 65535) {
       const int quads = w / 2, bx = quads >= 64 ? 64 : quads, by = 256 / bx;
       hipLaunchKernelGGL(upsample2x_v4_kernel, dim3((quads + bx - 1) / bx, (2 * h + by * UPS_ROWS - 1) / (by * UPS_ROWS), B * below->C), dim3(bx, by), 0, s,
                          fptr(*below), fptr(P.u[l]), h, w, P.u[l].H, P.u[l].W, sy, sx);
@@ -751,20 +757,29 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
                          P.u[l].W, sy, sx);
     }
     PNPX_LAUNCH_CHECK();
-    PNPX_TRY(rec.mark("upsample2x", 0));
+    if (!ups_fused) PNPX_TRY(rec.mark("upsample2x", 0));
+    // first convolution of a decoder block: the fused instance reads the low-resolution tensor
+    auto entry = [&](const Act& ta) -> int {
+      if (!ups_fused) return conv(li0, P.x[l], &P.u[l], ta);
+      const ConvLayer& L = ctx->conv[li0];
+      PNPX_TRY(launch_conv3x3_wino8_ups(ctx->conv_wino_u[li0], L.b, L.cout, fptr(P.x[l]), P.x[l].C, fptr(*below), below->C, fptr(ta), B, 2 * h, 2 * w, s));
+      return rec.mark("conv3x3_wino", 2.0 * 9.0 * L.cin * L.cout * (double)(2 * h) * (2 * w) * B);
+    };
     // the network's last 3x3 layer takes the 1x1 out-conv + residual + clamp into its epilogue when the Winograd kernel runs it
     // (inference passes only: a training forward keeps the layer's output for the VJP)
     const bool fuse_outc = l == 0 && !keep_all && ctx->opt_fuse_outc && ctx->opt_fp32_winograd && ctx->conv_wino_u[26] &&
                            conv3x3_wino_outc_ok(ctx->conv[26].cin, ctx->conv[26].cout, H, W);
     if (fuse_outc) {
-      PNPX_TRY(conv(24, P.x[0], &P.u[0], P.da[0]));
+      PNPX_TRY(entry(P.da[0]));
       PNPX_TRY(conv(25, P.da[0], nullptr, P.db[0]));
       const bool w8 = ((ctx->opt_fp32_wino8 >> 26) & 1) && conv3x3_wino8_ok(ctx->conv[26].cin, 0, ctx->conv[26].cout, H, W);
       PNPX_TRY((w8 ? launch_conv3x3_wino8_outc : launch_conv3x3_wino_outc)(ctx->conv_wino_u[26], ctx->conv[26].b, fptr(P.db[0]), ctx->conv[26].cin,
                                                                           ctx->outc_w, ctx->outc_b, x, out, out_pre, B, H, W, s));
       return rec.mark("conv3x3_wino", 2.0 * 9.0 * ctx->conv[26].cin * ctx->conv[26].cout * (double)H * W * B);
     }
-    PNPX_TRY(block(15 + 3 * (3 - l), P.x[l], &P.u[l], l, P.y[l]));
+    PNPX_TRY(entry(P.da[l]));
+    PNPX_TRY(conv(li0 + 1, P.da[l], nullptr, P.db[l]));
+    PNPX_TRY(conv(li0 + 2, P.db[l], nullptr, P.y[l]));
     below = &P.y[l];
   }
   hipLaunchKernelGGL(outc_residual_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, fptr(P.y[0]), x, ctx->outc_w,

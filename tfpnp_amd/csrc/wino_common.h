@@ -31,6 +31,10 @@ struct WinoArgs {
   float* out;
   int B, H, W, Hp, Wp, C0, C1, Cout, nct, nch, rx, ry;
   float slope;
+  // UPS instances of the 8-wave kernel (the UNet's decoder entries): in1 is the LOW-resolution tensor [B][C1][ups_h + 2][ups_w + 2 PADL]
+  // and the kernel interpolates its bilinear x2 (align_corners) up-sampling into the halo buffer itself (models/unet.py:92-121)
+  int ups_h, ups_w;
+  float ups_sy, ups_sx;
 };
 
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the builtin widens every lane offset to a

@@ -24,9 +24,10 @@ for B, H, W in cases:
     s = torch.rand(B, generator=g) * 0.2 + 0.02
     xt, st = x.to(dev), s.to(dev)
     outs = {}
-    for name, (wg, w8) in {"direct": (0, 0), "wino4": (1, 0), "wino8": (1, ALL)}.items():
+    for name, (wg, w8, fu) in {"direct": (0, 0, 0), "wino4": (1, 0, 0), "wino8_nofuse": (1, ALL, 0), "wino8": (1, ALL, 1)}.items():
         ctx.set_option("fp32_winograd", wg)
         ctx.set_option("fp32_wino8_layers", w8)
+        ctx.set_option("fp32_fuse_up", fu)
         post, pre = den.forward_preclamp(xt, st)
         torch.cuda.synchronize()
         outs[name] = (pre.double().cpu(), post.double().cpu())
@@ -42,6 +43,8 @@ for B, H, W in cases:
         ok = e8 < 3e-6 and torch.equal(outs["wino8"][1], outs["wino8"][0].clamp(0, 1))
     else:
         ok = rel(outs["wino8"][0], outs["wino4"][0]) < 3e-6
+    fuse_same = torch.equal(outs["wino8"][0], outs["wino8_nofuse"][0])
+    line += f"  | fused up-sampling vs separate kernel: {'bit-identical' if fuse_same else '%.2e' % rel(outs['wino8'][0], outs['wino8_nofuse'][0])}"
     same = torch.equal(outs["wino8"][0], outs["wino4"][0])
     print(line, "OK" if ok else "FAIL", "(identical to wino4: kernel did not run?)" if same else "", flush=True)
     bad += not ok
