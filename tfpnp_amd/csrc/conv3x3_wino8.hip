@@ -694,6 +694,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
       dma_raw(raw_of(T, 1), 1, 0, RAW_PER_WAVE);
       dma_u(T.w, 0);
       dma_u(T.w + (USTG / 4), 1);
+      dma_u(T.w + 2 * (USTG / 4), 2);      // (nch >= 2: chunk 1 exists)
     }
     sync_all();
     {
@@ -714,8 +715,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     // fetches the next chunk's halo (or, K1, interpolates its quads 1-3 in stages 0-2) and stages the window of the chunk after (K2),
     // whose quad 0 stage 3 interpolates.  CT 32: stage 0 interpolates quad 1 of the next chunk (K1); stage 1 fetches the halo of the
     // chunk after (or, K2, interpolates its quad 0) and stages the window of the third (K3).
-    auto chunk = [&](auto first_tag, auto k1_tag, auto k2_tag, auto k3_tag, const float* w_c, const float* nu, const float* nraw,
-                     const float* nst, int cc) {
+    auto chunk = [&](auto first_tag, auto k1_tag, auto k2_tag, auto k3_tag, const float* w_c, const float* nu, const float* nu2,
+                     const float* nraw, const float* nst, int cc) {
       constexpr int EPI = decltype(first_tag)::value ? NST : 0;
       constexpr bool K1 = UPS && decltype(k1_tag)::value, K2 = UPS && decltype(k2_tag)::value, K3 = UPS && decltype(k3_tag)::value;
       constexpr int NSW = C::NSW;
@@ -736,10 +737,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
       } else {
         using S0k = StageKind<false, false, K1 ? 1 : -1>;
         using S1k = StageKind<!K2, K3, K2 ? 0 : -1>;
+        // weight ring: stage g = 2 cc + s reads slot g & 3 and fetches the weights of stage g + 3 (the slot the stage before just left):
+        // stage 0 those of the next chunk's stage 1, stage 1 those of the chunk after's stage 0 (nu2) -- 2.4 stages of lead (1.4 with a
+        // lead of two stages left the full-resolution layers waiting ~600 clocks per chunk for their weight slice behind the halo traffic)
         const int u0 = 2 * rcur, n0 = 2 * rnext;      // ring slots of this chunk's and the next chunk's stages
-        stage(I0{}, first_tag, std::integral_constant<int, NUW + EPI>{}, Yes{}, S0k{}, Side{rcur, u0, u0 + 1, nu, n0, nullptr, 0, nullptr, 0, rnext, rnext});
-        stage(I1{}, first_tag, std::integral_constant<int, NUW + (K2 ? 0 : NRAW) + (K3 ? NSW : 0)>{}, Pre{}, S1k{},
-              Side{rnext, u0 + 1, n0, nu + (USTG / 4), n0 + 1, nraw, rcur, nst, rnext, rcur, rcur});
+        stage(I0{}, first_tag, std::integral_constant<int, NUW + EPI>{}, Yes{}, S0k{},
+              Side{rcur, u0, u0 + 1, nu + (USTG / 4), n0 + 1, nullptr, 0, nullptr, 0, rnext, rnext});
+        stage(I1{}, first_tag, std::integral_constant<int, 2 * NUW + EPI + (K2 ? 0 : NRAW) + (K3 ? NSW : 0)>{}, Pre{}, S1k{},
+              Side{rnext, u0 + 1, n0, nu2, u0, nraw, rcur, nst, rnext, rcur, rcur});
       }
     };
 
@@ -751,11 +756,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
       for (int c = 0; c < a.nch; ++c, ++cc) {
         const float* w_c = T.w + (size_t)c * 4 * (UQ / 4);
         const float* nu = (c + 1 < a.nch) ? w_c + 4 * (UQ / 4) : Tn.w;
+        const float* nu2 = (c + 2 < a.nch) ? w_c + 8 * (UQ / 4) : Tn.w + (size_t)(c + 2 - a.nch) * 4 * (UQ / 4);      // (CT 32)
         constexpr int AH = (CT == 64) ? 1 : 2;        // chunks ahead the halo stage fetches; the staging stage: one more
         const float* nraw = (c + AH < a.nch) ? raw_of(T, c + AH) : raw_of(Tn, c + AH - a.nch);
         if constexpr (!UPS) {
-          if (c == 0) chunk(Yes{}, No{}, No{}, No{}, w_c, nu, nraw, nullptr, cc);
-          else chunk(No{}, No{}, No{}, No{}, w_c, nu, nraw, nullptr, cc);
+          if (c == 0) chunk(Yes{}, No{}, No{}, No{}, w_c, nu, nu2, nraw, nullptr, cc);
+          else chunk(No{}, No{}, No{}, No{}, w_c, nu, nu2, nraw, nullptr, cc);
         } else {
           const int cu = a.C0 / CK;                   // first chunk of the up-sampled source (host: >= 3 / 4, so chunk 0 is plain)
           auto ups = [&](int j) { return c + j < a.nch && c + j >= cu; };
@@ -763,20 +769,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
           const float* nst = T.s1u + (size_t)CK * (c + AH + 1) * hpwp_lo;      // window of chunk c + 2 (CT 32: c + 3)
           if (c == 0) {
             write_tables(T);                          // (read from the first interpolation on, several barriers later)
-            chunk(Yes{}, No{}, No{}, No{}, w_c, nu, nraw, nst, cc);
+            chunk(Yes{}, No{}, No{}, No{}, w_c, nu, nu2, nraw, nst, cc);
           } else if constexpr (CT == 64) {
-            if (!k1 && !k2) chunk(No{}, No{}, No{}, No{}, w_c, nu, nraw, nst, cc);
-            else if (!k1 && k2) chunk(No{}, No{}, Yes{}, No{}, w_c, nu, nraw, nst, cc);
-            else if (k1 && k2) chunk(No{}, Yes{}, Yes{}, No{}, w_c, nu, nraw, nst, cc);
-            else chunk(No{}, Yes{}, No{}, No{}, w_c, nu, nraw, nst, cc);
+            if (!k1 && !k2) chunk(No{}, No{}, No{}, No{}, w_c, nu, nu2, nraw, nst, cc);
+            else if (!k1 && k2) chunk(No{}, No{}, Yes{}, No{}, w_c, nu, nu2, nraw, nst, cc);
+            else if (k1 && k2) chunk(No{}, Yes{}, Yes{}, No{}, w_c, nu, nu2, nraw, nst, cc);
+            else chunk(No{}, Yes{}, No{}, No{}, w_c, nu, nu2, nraw, nst, cc);
           } else {
-            if (!k1 && !k2 && !k3) chunk(No{}, No{}, No{}, No{}, w_c, nu, nraw, nst, cc);
-            else if (!k1 && !k2) chunk(No{}, No{}, No{}, Yes{}, w_c, nu, nraw, nst, cc);
-            else if (!k1 && k3) chunk(No{}, No{}, Yes{}, Yes{}, w_c, nu, nraw, nst, cc);
-            else if (k1 && k2 && k3) chunk(No{}, Yes{}, Yes{}, Yes{}, w_c, nu, nraw, nst, cc);
-            else if (k1 && k2) chunk(No{}, Yes{}, Yes{}, No{}, w_c, nu, nraw, nst, cc);
-            else if (k1) chunk(No{}, Yes{}, No{}, No{}, w_c, nu, nraw, nst, cc);
-            else chunk(No{}, No{}, Yes{}, No{}, w_c, nu, nraw, nst, cc);      // (k2 alone: two-chunk up-sampled sources)
+            if (!k1 && !k2 && !k3) chunk(No{}, No{}, No{}, No{}, w_c, nu, nu2, nraw, nst, cc);
+            else if (!k1 && !k2) chunk(No{}, No{}, No{}, Yes{}, w_c, nu, nu2, nraw, nst, cc);
+            else if (!k1 && k3) chunk(No{}, No{}, Yes{}, Yes{}, w_c, nu, nu2, nraw, nst, cc);
+            else if (k1 && k2 && k3) chunk(No{}, Yes{}, Yes{}, Yes{}, w_c, nu, nu2, nraw, nst, cc);
+            else if (k1 && k2) chunk(No{}, Yes{}, Yes{}, No{}, w_c, nu, nu2, nraw, nst, cc);
+            else if (k1) chunk(No{}, Yes{}, No{}, No{}, w_c, nu, nu2, nraw, nst, cc);
+            else chunk(No{}, No{}, Yes{}, No{}, w_c, nu, nu2, nraw, nst, cc);      // (k2 alone: two-chunk up-sampled sources)
           }
         }
       }
