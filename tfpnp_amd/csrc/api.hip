@@ -451,7 +451,7 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
     ctx->conv_bwd[i].cc = 8;
   }
   // ... and the same adjoint convolutions for the half-split kernel family (backward pass of conv_mode 1)
-  size_t thoff[27];
+  size_t thoff[27], tuoff[27];      // tuoff: the same adjoint layers as Winograd weights of the fp32 family (conv3x3_wino8.hip, r5)
   float thscale[27];
   {
     std::vector<float> wt;
@@ -471,6 +471,13 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
       const size_t n16 = (size_t)cout_t * cin_t * 9 * 2;
       host.resize(host.size() + (n16 + 1) / 2, 0.f);
       thscale[i] = pack_conv_weights_hs(wt.data(), cout_t, cin_t, mt, reinterpret_cast<uint16_t*>(host.data() + thoff[i]));
+      tuoff[i] = 0;
+      if (conv3x3_wino_packs(cout_t, cin_t)) {
+        align();
+        tuoff[i] = host.size();
+        host.resize(host.size() + conv3x3_wino_floats(cout_t, cin_t));
+        pack_conv_weights_wino(wt.data(), cout_t, cin_t, host.data() + tuoff[i]);
+      }
       ctx->conv_hs_bwd[i].cin = cin_t;
       ctx->conv_hs_bwd[i].cout = cout_t;
       ctx->conv_hs_bwd[i].cin_pad = cin_t;
@@ -508,6 +515,7 @@ int pnpx_unet_load(pnpx_ctx* ctx, const float* params_host, size_t n_params) {
     ctx->conv[i].w = d + woff[i];
     ctx->conv[i].b = d + boff[i];
     ctx->conv_wino_u[i] = uoff[i] ? d + uoff[i] : nullptr;
+    ctx->conv_wino_u_bwd[i] = tuoff[i] ? d + tuoff[i] : nullptr;
     ctx->conv_hs[i].w = reinterpret_cast<char*>(d + hoff[i]);
     ctx->conv_bwd[i].w = d + toff[i];
     ctx->conv_bwd[i].b = nullptr;

@@ -191,6 +191,7 @@ struct pnpx_ctx {
   unsigned* range_flag_dev = nullptr;    // its device address
   bool range_tripped = false;            // latched by the host once the flag was seen set (cleared by set_option)
   float* conv_wino_u[27] = {};     // Winograd-transformed fp32 weights of the layers conv3x3_wino.hip can run (else null)
+  float* conv_wino_u_bwd[27] = {}; // ... of the adjoint (transposed, tap-flipped) convolutions of the fp32 backward pass (r5)
   int opt_fp32_winograd = 1;       // conv_mode 0: run those layers as F(2x2,3x3) (fp32 arithmetic, 2.25x fewer MFMAs; 0 = the direct kernel everywhere)
   int opt_fp32_wino8 = (1 << 27) - 1;   // bit li: layer li runs on the 8-wave Winograd kernel (conv3x3_wino8.hip) where its geometry allows; a DRUNet
                                    // context: any bit = its ResBlock layers do

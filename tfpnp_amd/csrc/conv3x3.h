@@ -62,6 +62,8 @@ bool conv3x3_wino8_ok(int C0, int C1, int cout, int H, int W);
 int launch_conv3x3_wino8(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
                          float* out, int B, int H, int W, hipStream_t s, float slope = 0.2f, const float* res = nullptr,
                          float* pool_out = nullptr);
+int launch_conv3x3_wino8_grad(const float* u, const float* zero_bias, int cout, const float* gin, int cin, float* gout, const float* dmask,
+                              float mask_slope, int B, int H, int W, hipStream_t s);
 bool conv3x3_wino8_ups_ok(int C0, int C1, int cout, int H, int W);
 int launch_conv3x3_wino8_ups(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1_lowres, int C1,
                              float* out, int B, int H, int W, hipStream_t s, float slope = 0.2f);

@@ -624,10 +624,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
         y10 = y10 > 0.f ? y10 : y10 * a.slope;
         y11 = y11 > 0.f ? y11 : y11 * a.slope;
         if (RES) {
-          y00 += rs0[RES ? (j & 3) : 0][0];
-          y01 += rs0[RES ? (j & 3) : 0][1];
-          y10 += rs1[RES ? (j & 3) : 0][0];
-          y11 += rs1[RES ? (j & 3) : 0][1];
+          const f32x2 r0 = rs0[RES ? (j & 3) : 0], r1 = rs1[RES ? (j & 3) : 0];
+          if (a.res_mask) {      // adjoint convolution: x LeakyReLU'(saved forward activation)
+            y00 *= r0[0] > 0.f ? 1.f : a.mask_slope;
+            y01 *= r0[1] > 0.f ? 1.f : a.mask_slope;
+            y10 *= r1[0] > 0.f ? 1.f : a.mask_slope;
+            y11 *= r1[1] > 0.f ? 1.f : a.mask_slope;
+          } else {
+            y00 += r0[0];
+            y01 += r0[1];
+            y10 += r1[0];
+            y11 += r1[1];
+          }
         }
         if (FUSE_OUTC) {
           s00 = fmaf(ow[j], y00, s00);
@@ -913,6 +921,38 @@ int launch_conv3x3_wino8_ups(const float* u, const float* bias, int cout, const 
   a.ups_sy = (H > 1) ? (float)(H / 2 - 1) / (float)(H - 1) : 0.f;
   a.ups_sx = (W > 1) ? (float)(W / 2 - 1) / (float)(W - 1) : 0.f;
   return wino8_ct(C0, C1, cout, H, W) == 64 ? launch_wino8<64, false, false, true>(a, s) : launch_wino8<32, false, false, true>(a, s);
+}
+
+// Input-gradient (adjoint) convolution of the backward pass on the same kernel: u = pack_conv_weights_wino of the transposed, tap-flipped
+// weights; no bias (zero_bias: >= cout zeros), linear, optionally x LeakyReLU'(dmask) with dmask = the saved forward activation the gradient
+// flows into (models/unet.py:8-18 backwards).
+int launch_conv3x3_wino8_grad(const float* u, const float* zero_bias, int cout, const float* gin, int cin, float* gout, const float* dmask,
+                              float mask_slope, int B, int H, int W, hipStream_t s) {
+  const int ct = wino8_ct(cin, 0, cout, H, W);
+  if (!ct) {
+    set_error("conv3x3_wino8_grad: unsupported geometry (%d -> %d channels, %d x %d)", cin, cout, H, W);
+    return PNPX_ERR_SHAPE;
+  }
+  WinoArgs a{};
+  a.in0 = gin;
+  a.in1 = gin;
+  a.u = u;
+  a.bias = zero_bias;
+  a.res = dmask;
+  a.res_mask = 1;
+  a.mask_slope = mask_slope;
+  a.out = gout;
+  a.B = B;
+  a.H = H;
+  a.W = W;
+  a.Hp = padded_h(H);
+  a.Wp = padded_w(W);
+  a.C0 = cin;
+  a.C1 = 0;
+  a.Cout = cout;
+  a.slope = 1.0f;
+  if (dmask) return ct == 64 ? launch_wino8<64, false, true>(a, s) : launch_wino8<32, false, true>(a, s);
+  return ct == 64 ? launch_wino8<64, false, false>(a, s) : launch_wino8<32, false, false>(a, s);
 }
 
 int launch_conv3x3_wino8(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,

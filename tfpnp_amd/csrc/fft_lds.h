@@ -372,6 +372,45 @@ __global__ __launch_bounds__(FFT_THREADS) void fft256_rows_kernel(PassGeom g, Lo
   }
 }
 
+// Row pass over GROUPS of images (r5; the PR solver's inverse row pass): a workgroup transforms the same 16 rows of the S images of one
+// group one after the other and hands every result to an accumulator functor -- acc.add(state, group, s, y, x, value) -- whose per-pixel
+// state stays in registers; acc.finish(state, group, y, x) stores once per pixel.  For the coded-diffraction adjoint (mean over the S
+// masks of conj(mask_s) F^-1, transforms.py:304-320) this removes the S image-space fields' round trip through memory: the row pass wrote
+// them (S x 8 N bytes) and the update kernel read them back.  g.n_img = number of groups.
+template <bool INV, class Load, class Acc>
+__global__ __launch_bounds__(FFT_THREADS) void fft256_rows_group_kernel(PassGeom g, int S, Load ld, Acc acc) {
+  __shared__ float2 ex[FFT256_LDS_F2];
+  const int i = threadIdx.x & 15, l = threadIdx.x >> 4;
+  int b, part;
+  xcd_affine_decode(blockIdx.x, g.H / FFT256_LINES, g.n_img, g.affine, &b, &part);
+  const int y = part * FFT256_LINES + l;
+  float2 tw[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) tw[m] = g.tw[(i * m) & 255];
+  const float sg = (g.centered && (i & 1)) ? -1.f : 1.f;
+  const float sc = g.scale * sg;
+  typename Acc::State st[16];
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) st[k1] = acc.init();
+  for (int s = 0; s < S; ++s) {
+    const int img = b * S + s;
+    float2 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float2 t = ld(img, y, i + 16 * j);
+      v[j] = make_float2(t.x * sg, t.y * sg);
+    }
+    typename Acc::Pre pf[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) pf[k1] = acc.fetch(img, y, 16 * k1 + i);
+    fft256_reg<INV, true>(v, ex, l, i, tw);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) acc.add(st[k1], pf[k1], make_float2(v[k1].x * sc, v[k1].y * sc));
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) acc.finish(st[k1], b, y, 16 * k1 + i);
+}
+
 // A k-space functor may split itself into fetch(b, ky, kx) -> Pre (its global reads: measurements, mask ...) and
 // apply(pre, v): the fused column kernel then issues those reads up front, beside the tile's own loads, instead of behind the
 // forward transform (a second exposed memory latency per workgroup: 31 -> 2x us on the CS-MRI blend pass).
@@ -459,6 +498,15 @@ int launch_rows(const FftPlan2D& P, Load ld, Store st, hipStream_t s) {
   }
   hipLaunchKernelGGL((fft_rows_kernel<INV, Load, Store>), P.grid_rows, dim3(FFT_THREADS), P.lds_rows, s, P.rows, ld,
                      st);
+  PNPX_LAUNCH_CHECK();
+  return PNPX_OK;
+}
+// (fast 256-point path only: the caller checks P.fast256_rows and P.rows.n_img == groups * S)
+template <bool INV, class Load, class Acc>
+int launch_rows_group(const FftPlan2D& P, int groups, int S, Load ld, Acc acc, hipStream_t s) {
+  PassGeom g = P.rows;
+  g.n_img = groups;
+  hipLaunchKernelGGL((fft256_rows_group_kernel<INV, Load, Acc>), dim3(groups * (g.H / FFT256_LINES)), dim3(FFT_THREADS), 0, s, g, S, ld, acc);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }

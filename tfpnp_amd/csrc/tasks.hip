@@ -82,6 +82,42 @@ __global__ void pr_update_kernel(const float2* __restrict__ I, const float2* __r
   d[i] = subr(zn.x, un.x);
   if (write_x) xout[(size_t)b * istride + r] = make_float2(xv, 0.f);
 }
+// The same update as the accumulator of the grouped inverse row pass (fft_lds.h fft256_rows_group_kernel): g is summed over the S masks
+// in registers, in the order and with the operations of cdp_adjoint_px, and the pixel is updated right there -- the S image-space
+// fields never reach memory.  Bit-identical to cdp rows pass + pr_update_kernel.
+struct PrUpdateAcc {
+  const float2* mask;     // [B*S][HW]
+  const float* xr;        // [B][HW]
+  const float2 *zin, *uin;
+  float2 *xout, *zout, *uout;
+  size_t istride;
+  float* d;
+  const float *mu, *tau;
+  int stride, S, W, HW, write_x;
+  typedef float2 State;
+  typedef float2 Pre;
+  __device__ float2 init() const { return make_float2(0.f, 0.f); }
+  __device__ float2 fetch(int img, int y, int x) const { return mask[(size_t)img * HW + (size_t)y * W + x]; }
+  __device__ void add(float2& acc, float2 m, float2 a) const {
+    const float my = -m.y;
+    acc.x = addr(acc.x, subr(mulr(a.x, m.x), mulr(a.y, my)));
+    acc.y = addr(acc.y, addr(mulr(a.x, my), mulr(a.y, m.x)));
+  }
+  __device__ void finish(float2 acc, int b, int y, int x) const {
+    const size_t r = (size_t)y * W + x, i = (size_t)b * HW + r;
+    const float2 g = make_float2(divr(acc.x, (float)S), divr(acc.y, (float)S));
+    const float m = mu[(size_t)b * stride], t = tau[(size_t)b * stride];
+    const float2 z = zin[(size_t)b * istride + r], u = uin[(size_t)b * istride + r];
+    const float xv = xr[i];
+    const float2 zn = make_float2(subr(z.x, mulr(t, addr(g.x, mulr(m, subr(z.x, addr(xv, u.x)))))),
+                                  subr(z.y, mulr(t, addr(g.y, mulr(m, subr(z.y, addr(0.f, u.y)))))));
+    const float2 un = make_float2(subr(addr(u.x, xv), zn.x), subr(addr(u.y, 0.f), zn.y));
+    zout[(size_t)b * istride + r] = zn;
+    uout[(size_t)b * istride + r] = un;
+    d[i] = subr(zn.x, un.x);
+    if (write_x) xout[(size_t)b * istride + r] = make_float2(xv, 0.f);
+  }
+};
 // ---- training path of IADMMSolver_PR (pnpx_pr_iadmm_train / _backward)
 struct MidPrResidualSave {  // MidPrResidual that also keeps w = F(mask_s z) of every (item, s)
   const float* y0;
@@ -238,7 +274,9 @@ __global__ void spi_inverse_kernel(const float* __restrict__ zt, const float* __
   out[i] = spi_inverse_px(zt[i], K1[i], K[b], mu[b]);
 }
 // z = spi_inverse(x+u, K1, K, mu); u = u + x - z; d = z - u                tasks/spi/solver.py:41-47
-__global__ void spi_step_kernel(const float* xin, const float* uin, size_t istride, const float* __restrict__ x0,
+// (x comes with its own item stride: the state's x slot on the first iteration, the denoiser's contiguous output afterwards -- r5: the
+//  per-iteration copy of that output into the slot, 29 % of the prox time at config #5, is gone; one copy per call remains)
+__global__ void spi_step_kernel(const float* xin, size_t xstride, const float* uin, size_t istride, const float* __restrict__ x0,
                                 const float* __restrict__ Kmap, float* zout, float* uout, float* __restrict__ d,
                                 const float* __restrict__ mu, int stride, int HW, int B) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,7 +284,7 @@ __global__ void spi_step_kernel(const float* xin, const float* uin, size_t istri
   const size_t b = i / HW, r = i - b * HW;
   const float K = mulr(Kmap[b * HW], 10.f);
   const float K1 = mulr(x0[i], mulr(K, K));
-  const float x = xin[b * istride + r], u = uin[b * istride + r];
+  const float x = xin[b * xstride + r], u = uin[b * istride + r];
   const float z = spi_inverse_px(addr(x, u), K1, K, mu[b * stride]);
   const float un = subr(addr(u, x), z);
   zout[b * istride + r] = z;
@@ -263,7 +301,7 @@ __global__ void copy_real_slot_kernel(const float* __restrict__ src, float* __re
 
 // ---- training paths of ADMMSolver_SPI / IADMMSolver_CT / PGSolver_CT (pnpx_{spi_admm,ct_iadmm,ct_pg}_train / _backward)
 // spi_step_kernel that also keeps zt = x + u (the argument of spi_inverse)
-__global__ void spi_step_save_kernel(const float* xin, const float* uin, size_t istride, const float* __restrict__ x0,
+__global__ void spi_step_save_kernel(const float* xin, size_t xstride, const float* uin, size_t istride, const float* __restrict__ x0,
                                      const float* __restrict__ Kmap, float* zout, float* uout, float* __restrict__ d,
                                      const float* __restrict__ mu, int stride, int HW, int B, float* __restrict__ zts) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,7 +309,7 @@ __global__ void spi_step_save_kernel(const float* xin, const float* uin, size_t 
   const size_t b = i / HW, r = i - b * HW;
   const float K = mulr(Kmap[b * HW], 10.f);
   const float K1 = mulr(x0[i], mulr(K, K));
-  const float x = xin[b * istride + r], u = uin[b * istride + r];
+  const float x = xin[b * xstride + r], u = uin[b * istride + r];
   const float zt = addr(x, u);
   const float z = spi_inverse_px(zt, K1, K, mu[b * stride]);
   const float un = subr(addr(u, x), z);
@@ -762,6 +800,12 @@ static int pr_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, cons
     } else {
       PNPX_TRY((launch_cols<false, true>(P, kld, MidPrResidual{y0, W, HW}, kst, s)));
     }
+    if (!saved && P.fast256_rows) {
+      // inverse row pass + coded-diffraction adjoint + z / u update in one kernel (the S fields stay in registers)
+      PNPX_TRY((launch_rows_group<true>(P, B, S, kld, PrUpdateAcc{reinterpret_cast<const float2*>(mask), xr, zi, ui, vout, vout + HW, vout + 2 * HW,
+                                                                   is, d, mu + i, tau + i, param_stride, S, W, HW, i == T - 1}, s)));
+      continue;
+    }
     PNPX_TRY((launch_rows<true>(P, kld, kst, s)));
     if (saved) {
       hipLaunchKernelGGL(pr_update_save_kernel, g1(n), dim3(256), 0, s, k, reinterpret_cast<const float2*>(mask), xr, zi, ui,
@@ -881,26 +925,28 @@ static int spi_forward(pnpx_ctx* ctx, const float* vars_in, float* vars_out, con
   float* dscr = cv.take<float>(n);
   float* xr = cv.take<float>(n);
   for (int i = 0; i < T; ++i) {
-    // x of iteration i: state x on the first pass, the previous denoiser output (already in the x slot) later
-    const float* xin = (i == 0) ? vars_in : vars_out;
+    // x of iteration i: the state's x slot on the first pass, the previous denoiser output (contiguous, in xr) later
+    const float* xin = (i == 0) ? vars_in : xr;
+    const size_t xs = (i == 0) ? is : (size_t)HW;
     const float* uin = ((i == 0) ? vars_in : vars_out) + 2 * HW;
     if (saved) {
       float* d = saved + ((size_t)T + i) * n;
-      hipLaunchKernelGGL(spi_step_save_kernel, g1(n), dim3(256), 0, s, xin, uin, is, x0, Kmap, vars_out + HW,
+      hipLaunchKernelGGL(spi_step_save_kernel, g1(n), dim3(256), 0, s, xin, xs, uin, is, x0, Kmap, vars_out + HW,
                          vars_out + 2 * HW, d, mu + i, param_stride, HW, B, saved + (size_t)i * n);
       PNPX_LAUNCH_CHECK();
       unsigned long long tk = 0;
       PNPX_TRY(unet_denoise_train(ctx, d, sigma_d + i, param_stride, xr, B, H, W, s, &tk));
       if (i == 0 && ticket_out) *ticket_out = tk;
     } else {
-      hipLaunchKernelGGL(spi_step_kernel, g1(n), dim3(256), 0, s, xin, uin, is, x0, Kmap, vars_out + HW,
+      hipLaunchKernelGGL(spi_step_kernel, g1(n), dim3(256), 0, s, xin, xs, uin, is, x0, Kmap, vars_out + HW,
                          vars_out + 2 * HW, dscr, mu + i, param_stride, HW, B);
       PNPX_LAUNCH_CHECK();
       PNPX_TRY(unet_denoise(ctx, dscr, sigma_d + i, param_stride, xr, nullptr, B, H, W, s, nullptr));
     }
-    hipLaunchKernelGGL(copy_real_slot_kernel, g1(n), dim3(256), 0, s, xr, vars_out, is, HW, B);
-    PNPX_LAUNCH_CHECK();
   }
+  // the last denoiser output becomes the state's x (the only copy of the call)
+  hipLaunchKernelGGL(copy_real_slot_kernel, g1(n), dim3(256), 0, s, xr, vars_out, is, HW, B);
+  PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
 

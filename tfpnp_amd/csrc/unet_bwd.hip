@@ -525,6 +525,10 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
   auto convT = [&](int li, const Act& gin, const Act& gout, const Act* saved) -> int {
     const float* dm = (saved && !hs) ? reinterpret_cast<const float*>(FA + saved->off) : nullptr;
     const char* dmh = (saved && hs) ? FA + saved->off : nullptr;
+    // r5: Winograd F(2x2,3x3) for the adjoint convolutions too (8-wave kernel, LeakyReLU' mask in its epilogue)
+    if (!hs && ctx->opt_fp32_winograd && ((ctx->opt_fp32_wino8 >> li) & 1) && ctx->conv_wino_u_bwd[li] && gout.C == ctx->conv_bwd[li].cout &&
+        conv3x3_wino8_ok(gin.C, 0, gout.C, gout.H, gout.W))
+      return launch_conv3x3_wino8_grad(ctx->conv_wino_u_bwd[li], ctx->zero_bias, gout.C, gptr(gin), gin.C, gptr(gout), dm, 0.2f, B, gout.H, gout.W, s);
     return launch_conv3x3_grad(ctx->conv_bwd[li], gptr(gin), gptr(gout), dm, B, gout.H, gout.W, s, dmh);
   };
 

@@ -19,7 +19,8 @@ struct WinoArgs {
   const float* in1;
   const float* u;      // [cout/CT][cin/CK][a 4][b 4][kg 2][half][m CT][4] fp32
   const float* bias;
-  const float* res;    // optional: added after the activation (same geometry as out)
+  const float* res;    // optional: added after the activation (same geometry as out); res_mask != 0 (8-wave kernel, adjoint convolutions):
+                       // the saved forward activation instead -- the result is multiplied by LeakyReLU'(res) = res > 0 ? 1 : mask_slope
   // FUSE_OUTC instances (32-cout layer = the UNet's last): the 1x1 out-conv + residual + clamp of models/unet.py:63-66,124-131 and
   // denoiser/base.py:32 in the epilogue; `out` (the 32-channel tensor) is then neither written nor read again
   const float* outc_w;   // [32]
@@ -35,6 +36,8 @@ struct WinoArgs {
   // and the kernel interpolates its bilinear x2 (align_corners) up-sampling into the halo buffer itself (models/unet.py:92-121)
   int ups_h, ups_w;
   float ups_sy, ups_sx;
+  int res_mask;
+  float mask_slope;
 };
 
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the builtin widens every lane offset to a
