@@ -738,9 +738,9 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
   // ---- plain-fp32 path (conv_mode 0): padded planar fp32 activations, whole batch per launch
   char* A = static_cast<char*>(ar.buf.p);
   auto fptr = [&](const Act& d) { return reinterpret_cast<float*>(A + d.off); };
-  // the first convolution (2 -> 32 channels) straight from the fp32 image on the vector ALU (inference passes; a training forward keeps
-  // the padded 2-channel input tensor for the VJP)
-  const bool first_valu = !keep_all && ctx->opt_fuse_first && W % 4 == 0 && ctx->conv[0].cout == 32;
+  // the first convolution (2 -> 32 channels) straight from the fp32 image on the vector ALU (training forwards too: the VJP needs the
+  // layer's output, not its padded input tensor)
+  const bool first_valu = ctx->opt_fuse_first && W % 4 == 0 && ctx->conv[0].cout == 32;
   if (!first_valu) {
     hipLaunchKernelGGL(prep_input_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, x, sigma, sigma_stride, fptr(P.in0), H,
                        W, padded_h(H), padded_w(W));
@@ -798,7 +798,8 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     // r5: the decoder entry interpolates its second source itself (conv3x3_wino8.hip UPS instances: the low-resolution window of a
     // chunk's halo staged in LDS, bilinear x2 into the halo buffer) -- no up-sampled tensor in HBM (models/unet.py:92-121)
     const int li0 = 15 + 3 * (3 - l);
-    const bool ups_fused = !keep_all && ctx->opt_fp32_fuse_up && ctx->opt_fp32_winograd && ctx->conv_wino_u[li0] && ((ctx->opt_fp32_wino8 >> li0) & 1) &&
+    // (training forwards too: the VJP of the up-sampling is linear in the gradient and reads no up-sampled activation)
+    const bool ups_fused = ctx->opt_fp32_fuse_up && ctx->opt_fp32_winograd && ctx->conv_wino_u[li0] && ((ctx->opt_fp32_wino8 >> li0) & 1) &&
                            P.x[l].H == 2 * h && P.x[l].W == 2 * w && conv3x3_wino8_ups_ok(P.x[l].C, below->C, ctx->conv[li0].cout, 2 * h, 2 * w);
     if (ups_fused) {
     } else if ((2 * w) % 4 == 0 && (size_t)B * below->C <= 65535) {

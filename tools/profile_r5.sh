@@ -54,6 +54,9 @@ if [ $WHAT = tasks ] || [ $WHAT = all ]; then
   cp $O/task_sq.log $O/r5_tasks_times.txt
   $R --stats -d $O/train -o t -- python tools/time_train.py 48 256 5 > $O/r5_train_times.txt 2>&1
   python tools/rocpd_stats.py $O/train/t_results.db > $O/r5_train_kernel_stats.md
+  # the same training step in the fp32 family (r5: adjoint convolutions on the 8-wave Winograd kernel) and the DRUNet's two families
+  python tools/time_train.py 48 256 5 0 --fused-only >> $O/r5_train_times.txt 2>&1
+  python tools/time_drunet_modes.py > $O/r5_drunet_times.txt 2>&1
 fi
 find $O -name "*.db" -delete
 ls $O

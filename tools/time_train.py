@@ -1,6 +1,6 @@
 """Training-path timing of ADMMSolver_CSMRI (forward + backward of T inner iterations under autograd): the fused native
 VJP (pnpx_csmri_admm_train / _backward) vs the same loop composed from differentiable building blocks.  GPU box only.
-usage: time_train.py [B] [H] [T]"""
+usage: time_train.py [B] [H] [T] [conv_mode] [--fused-only] [--set=option:value ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,9 +13,17 @@ composed_solvers.install()      # the composed (step-by-step autograd) loops liv
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+args = [v for v in sys.argv[1:] if not v.startswith("--")]
+B = int(args[0]) if len(args) > 0 else 48
+H = int(args[1]) if len(args) > 1 else 256
+T = int(args[2]) if len(args) > 2 else 5
+MODE = int(args[3]) if len(args) > 3 else 1
 dev = torch.device("cuda:0")
 t = lambda a: torch.from_numpy(a).to(dev)
-den = UNetDenoiser2D(state_dict=synth.make_unet_params(0))
+den = UNetDenoiser2D(state_dict=synth.make_unet_params(0), conv_mode=MODE)
+for kv in [v.split("=", 1)[1] for v in sys.argv[1:] if v.startswith("--set=")]:
+    den.context(dev).set_option(kv.split(":")[0], int(kv.split(":")[1]))
+print(f"conv_mode {MODE}" + ("" if MODE else " (fp32 arithmetic: Winograd / direct fp32 MFMA kernels)"))
 sol = csmri.ADMMSolver_CSMRI(den)
 d = synth.make_csmri_batch(B, H, H, seed=1)
 a = synth.make_actions(B, 1, T)[0]
@@ -35,10 +43,11 @@ def step(fn):
 
 
 ctx = den.context(dev)
-for name, gb, fn in (("fused, ring", 96, lambda v, s, mu: sol((v, (y0, m)), (s, mu))),
-                     ("fused, recompute", 0, lambda v, s, mu: sol((v, (y0, m)), (s, mu))),
-                     ("composed, ring", 96, lambda v, s, mu: sol._forward_autograd(v, y0, m, s, mu, None)),
-                     ("composed, recompute", 0, lambda v, s, mu: sol._forward_autograd(v, y0, m, s, mu, None))):
+cases = (("fused, ring", 96, lambda v, s, mu: sol((v, (y0, m)), (s, mu))),
+         ("fused, recompute", 0, lambda v, s, mu: sol((v, (y0, m)), (s, mu))),
+         ("composed, ring", 96, lambda v, s, mu: sol._forward_autograd(v, y0, m, s, mu, None)),
+         ("composed, recompute", 0, lambda v, s, mu: sol._forward_autograd(v, y0, m, s, mu, None)))
+for name, gb, fn in (cases[:2] if "--fused-only" in sys.argv else cases):
     ctx.set_option("train_cache_gb", gb)
     step(fn)
     print(f"  context holds {ctx.bytes() / 2**30:.1f} GiB")
