@@ -428,9 +428,10 @@ def batch_table(solver, dev, H, W, ratio, sizes=(6, 12, 24, 48), T=ACTION_PACK, 
 
 
 def fp32_mode(params, data, actions, dev, B, H, W, steps, warmup):
-    """The fp32 MFMA convolution family (conv_mode 0: csrc/conv3x3_wino.hip on the >= 64-channel layers, csrc/conv3x3.hip on
-    the rest; fp32 arithmetic throughout, like the reference's) on the same episode with the same --steps / --warmup as the headline, and its own roofline against
-    the 157.3 TF/s fp32-MFMA peak (profiles/r3_bench_kernel_stats_fp32.md is the rocprofv3 summary of this leg)."""
+    """The fp32 convolution family (conv_mode 0; r5: csrc/conv3x3_wino8.hip = Winograd F(2x2,3x3) on the fp32 MFMA for the 26 layers
+    with cout % 32 == 0, the decoder entries up-sampling their second source in the kernel, the first convolution on the vector ALU;
+    fp32 arithmetic throughout, like the reference's) on the same episode with the same --steps / --warmup as the headline, and its own
+    roofline against the 157.3 TF/s fp32-MFMA peak (profiles/r5_bench_kernel_stats_fp32.md is the rocprofv3 summary of this leg)."""
     den = UNetDenoiser2D(state_dict=params, conv_mode=0)
     env = CSMRIEnv(None, ADMMSolver_CSMRI(den), max_episode_step=N_POLICY_STEPS)
 
@@ -464,9 +465,13 @@ def roofline_fp32(den, dev, x, sigma, n_fwd=12):
     conv_ms = whole_ms * (shares.get("conv3x3", 0.0) + shares.get("conv3x3_wino", 0.0))
     tf = conv_fl / (conv_ms * 1e-3) / 1e12
     wino_fl = sum(f for name, _, f in ops.unet_profile(den.context(dev), x, sigma) if name == "conv3x3_wino")
-    executed = conv_fl - wino_fl * (1.0 - 16.0 / 36.0)
+    # the matrix pipe executes 16/36 of the Winograd launches' algorithmic FLOPs and none of the first convolution's (vector ALU, r5)
+    B, _, H, W = x.shape
+    first_fl = 2.0 * 9 * 2 * 32 * H * W * B if W % 4 == 0 else 0.0
+    executed = conv_fl - wino_fl * (1.0 - 16.0 / 36.0) - first_fl
     tf_exec = executed / (conv_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv3x3_wino_f32_kernel<64|32> + conv3x3_mfma_kernel (27 launches per denoiser forward)",
+    return {"bound": "mfma", "kernel": "conv3x3_wino8_f32_kernel<64|32> (26 launches per denoiser forward, 4 of them with the bilinear x2 "
+                                       "up-sampling inside) + conv_first_f32_kernel",
             "achieved": tf_exec, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf_exec / PEAK_FP32_MFMA_TFLOPS,
             "achieved_note": "EXECUTED MFMA FLOPs / time (the honest utilisation of the fp32 matrix pipe); the algorithmic rate "
                              "of the same launches is `algorithmic_tflops`",

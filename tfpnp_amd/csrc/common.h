@@ -177,7 +177,7 @@ struct pnpx_ctx {
   // fork / join events of the launch chains: a ROTATING pool.  An event must not be re-recorded while a hipStreamWaitEvent on
   // its previous record may still sit un-submitted in another stream's host-side queue: with one fork event and one join event
   // per side stream re-recorded every call, two host threads driving two contexts on one GPU lost joins (a slice's output read
-  // before it was written: one item of a batch wrong, 15 of 25 stress runs; r4, tools/stress_threads.py).
+  // before it was written: one item of a batch wrong, 15 of 25 stress runs; r4, tools/attic/stress_threads.py).
   std::vector<hipEvent_t> ev_pool;
   size_t ev_next = 0;
   int opt_wreg = 2;                // weights-in-registers instances for the 32 -> 32 channel layers (0 off, 1 / 2 = shape)

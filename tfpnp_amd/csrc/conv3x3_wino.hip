@@ -41,7 +41,7 @@ using namespace wino;
 //   CT 64: region 16 x 16 px = 64 tiles, K chunks of 16 channels, waves 2 (cout blocks) x 2 (tile blocks), 32 MFMAs per stage
 //   CT 32: region 16 x 32 px = 128 tiles, K chunks of  8 channels, waves 1 x 4 (tile blocks),             16 MFMAs per stage
 // (a 32-cout tile with 16-channel chunks would need 174 KB of LDS for its 128-tile halo and V buffers).  V is 16 KiB per stage in both.
-// Diagnostic builds (tools/wino_ablate.sh): -DWINO_ABL=bits removes parts of a stage (results are then wrong; timing only):
+// Diagnostic builds (tools/attic/wino_ablate.sh): -DWINO_ABL=bits removes parts of a stage (results are then wrong; timing only):
 // 1 the closing wait + barrier, 2 the transform, 4 the operand reads, 8 the LDS-DMA issue, 16 the MFMAs, 32 the epilogue's stores,
 // 64 its bias loads, 128 its residual loads.
 #ifndef WINO_ABL

@@ -91,7 +91,7 @@ struct HsGeom {
   // One workgroup per CU BY CONSTRUCTION, and NO other workgroup that needs LDS beside it: every instance requests the CU's whole
   // 160 KiB.  (r1-r3 padded the request past 80 KiB, which kept a second conv_hs workgroup out but let small-LDS kernels of other
   // streams in.  On this pool's MI355X boxes a wave executing packed-fp32 VALU instructions on a CU that hosts another kernel's
-  // dense f16 MFMA wave computes wrong values in lanes 48-63 -- tools/stress_aggressor.py, DESIGN.md appendix r4 -- so conv_hs
+  // dense f16 MFMA wave computes wrong values in lanes 48-63 -- tools/attic/stress_aggressor.py, DESIGN.md appendix r4 -- so conv_hs
   // keeps LDS-using neighbours off its CUs; kernels without LDS can still share the CU's free registers.)
   static constexpr int LDS_BYTES = 160 * 1024;
   static constexpr int MTB = MT / 32;

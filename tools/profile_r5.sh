@@ -56,7 +56,7 @@ if [ $WHAT = tasks ] || [ $WHAT = all ]; then
   python tools/rocpd_stats.py $O/train/t_results.db > $O/r5_train_kernel_stats.md
   # the same training step in the fp32 family (r5: adjoint convolutions on the 8-wave Winograd kernel) and the DRUNet's two families
   python tools/time_train.py 48 256 5 0 --fused-only >> $O/r5_train_times.txt 2>&1
-  python tools/time_drunet_modes.py > $O/r5_drunet_times.txt 2>&1
+  python tools/time_drunet_modes.py 48 256 > $O/r5_drunet_times.txt 2>&1
 fi
 find $O -name "*.db" -delete
 ls $O
