@@ -80,14 +80,30 @@ def test_winograd_kernels_keep_their_named_accumulators(code_objects):
             agpr = int(blk.split()[0])
             spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
             scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
-            res_instance = re.search(r"Lb[01]ELb1E", name) is not None      # <.., .., RES = true>: the DRUNet skip instances
+            flags = [int(v) for v in re.findall(r"Lb([01])E", name)]      # <CT, FUSE_OUTC, RES[, UPS]>
+            special = any(flags[1:])       # RES (DRUNet skip / adjoint mask) and UPS (in-kernel up-sampling) instances
             seen += 1
             if "conv3x3_wino8_f32_kernel" in name:
                 assert agpr == 128, (name, agpr)
-                assert (spill, scratch) == (0, 0) or (res_instance and spill <= 4), (name, spill, scratch)
+                # the plain instances fit their 128 VGPRs; the RES / UPS ones may spill a few values AROUND a tile's epilogue / first
+                # stage -- never inside the steady-state stages (test_wino8_stage_loops_are_spill_free)
+                assert (spill, scratch) == (0, 0) or (special and spill <= 32), (name, spill, scratch)
             else:
                 assert agpr == 256 and spill == 0 and scratch == 0, (name, agpr, spill, scratch)
     assert seen >= 8, seen
+
+
+def test_wino8_stage_loops_are_spill_free(disassembly):
+    """A pipeline stage of the 8-wave kernel = the code between two s_barriers that holds exactly 16 MFMAs; a scratch access in
+    there would put a vmcnt wait (behind the LDS-DMA in flight) into every stage."""
+    stages = 0
+    for text in disassembly:
+        for m in re.finditer(r"<(_ZN4pnpx\S*conv3x3_wino8_f32_kernel\S*)>:\n(.*?)s_endpgm", text, re.S):
+            for seg in m.group(2).split("s_barrier"):
+                if seg.count("v_mfma_f32_32x32x2_f32") == 16:
+                    stages += 1
+                    assert "scratch_" not in seg, m.group(1)
+    assert stages >= 100, stages
 
 
 def test_wino8_compiler_never_writes_accumulator_registers(disassembly):
