@@ -453,7 +453,16 @@ def fp32_mode(params, data, actions, dev, B, H, W, steps, warmup):
     sigma = actions[-1]["sigma_d"][:, -1].contiguous()
     rl = roofline_fp32(den, dev, x, sigma)
     rl["power"] = power
-    return {"value": N_POLICY_STEPS * ACTION_PACK / dt, "unit": "iters/s", "steps": steps, "warmup": max(1, warmup),
+    # accuracy gate of this leg (the headline's gate is the CPU oracle, cpu_baseline): one forward of both families on the episode's final
+    # images -- a timing of wrong results is not a measurement (r5: an LDS overlap in the 32-cout tile produced NaNs at full batch only)
+    with torch.no_grad():
+        sg = torch.as_tensor(sigma).to(dev)
+        y32 = den(x, sg)
+        yhs = UNetDenoiser2D(state_dict=params)(x, sg)
+    rel_hs = float((y32.double() - yhs.double()).norm() / yhs.double().norm())
+    if not (rel_hs < 1e-4):
+        raise RuntimeError(f"fp32_mode: denoiser forward differs from the half-split family by {rel_hs} (must be < 1e-4)")
+    return {"forward_rel_l2_vs_half_split": rel_hs,"value": N_POLICY_STEPS * ACTION_PACK / dt, "unit": "iters/s", "steps": steps, "warmup": max(1, warmup),
             "ms_per_step": 1e3 * dt, "dtype": "f32 (v_mfma_f32_32x32x2_f32; Winograd F(2x2,3x3) on the layers with cout % 32 == 0)",
             "iters_per_s": N_POLICY_STEPS * ACTION_PACK / dt, "roofline": rl}
 

@@ -663,8 +663,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
           wait_lds();
         }
         barrier();                                                   // #3
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
         if (P == 0) {
-          const f32x4 o = *reinterpret_cast<const f32x4*>(zb);
+          o = *reinterpret_cast<const f32x4*>(zb);
+          wait_lds();
+        }
+        barrier();                                                   // #4: the 1 KiB is read (it lies in LDS the next stages refill)
+        if (P == 0) {
           s00 += o[0];
           s01 += o[1];
           s10 += o[2];
@@ -797,14 +802,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
       }
       // LDS free during the epilogue (nothing reads it, no DMA in flight targets it, the next stages refill it only behind the
       // epilogue's closing barrier): CT 64 -- weight slot 3 and V[1] (the last stage's), the halo buffer of the tile's last chunk, and
-      // the bytes of the CU's 160 KiB beyond LDS_USED; CT 32 -- V[1], the two weight slots of the tile's last chunk, the bytes beyond.
-      // Buffer A carries p = 1 -> p = 0, buffer B p = 0 -> p = 1, 8 KiB per pair each.
+      // the bytes of the CU's 160 KiB beyond LDS_USED; CT 32 -- V[1], the weight slot of the tile's LAST stage (the slot of its last
+      // chunk's first stage is being refilled: the ring runs three stages ahead), the bytes beyond LDS_USED (UPS instances: their
+      // staging buffers and tables, dead at a tile's end).  Buffer A carries p = 1 -> p = 0, buffer B p = 0 -> p = 1, 8 KiB per pair
+      // each; the fused out-conv's 1 KiB per pair re-uses the pair's buffer B once its p = 1 wave has read it.
       const int rl = (cc - 1) & 1;
       const int bufA = (CT == 64) ? ((sw < 2) ? OFF_U + 3 * USTG + sw * 8192 : OFF_V + VSTG + (sw - 2) * 8192) : OFF_V + VSTG + sw * 8192;
       const int bufB = (CT == 64) ? ((sw < 2) ? OFF_RAW + rl * RAW_BYTES + sw * 8192 : C::LDS_USED + (sw - 2) * 8192)
-                                  : ((sw < 2) ? OFF_U + (2 * rl + sw) * USTG : C::LDS_USED + (sw - 2) * 8192);
-      static_assert(C::LDS_USED + 16384 + 4096 <= LDS_REQ8 && 2 * 8192 <= RAW_BYTES, "exchange buffers");
-      epilogue(T, P == 1 ? bufA : bufB, P == 1 ? bufB : bufA, C::LDS_USED + 16384 + sw * 1024);
+                                  : ((sw < 1) ? OFF_U + (2 * rl + 1) * USTG : C::LDS_USED + (sw - 1) * 8192);
+      static_assert(C::LDS_USED + (CT == 64 ? 2 : 3) * 8192 <= LDS_REQ8 && 2 * 8192 <= RAW_BYTES && USTG >= 8192, "exchange buffers");
+      epilogue(T, P == 1 ? bufA : bufB, P == 1 ? bufB : bufA, bufB);
       if (!more) break;
       T = Tn;
       ++k;

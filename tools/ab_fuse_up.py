@@ -1,0 +1,22 @@
+import sys, os
+sys.path.insert(0, "/root/repo")
+import torch, numpy as np
+from tfpnp_amd import synth
+from tfpnp_amd.pnp import UNetDenoiser2D
+from oracle import pnp_oracle as O
+dev = torch.device("cuda:0")
+params = synth.make_unet_params(0)
+den = UNetDenoiser2D(state_dict=params)
+ctx = den.context(dev)
+p64 = {k: torch.as_tensor(v).double() for k, v in params.items()}
+rel = lambda a, b: float((a - b).norm() / b.norm())
+for B, H, W in [(2, 256, 256), (3, 64, 64), (1, 128, 96)]:
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, 1, H, W, generator=g); s = torch.rand(B, generator=g) * 0.2 + 0.02
+    xt, st = x.to(dev), s.to(dev)
+    ctx.set_option("fuse_up", 0); a = den.forward_preclamp(xt, st)[1].double().cpu()
+    ctx.set_option("fuse_up", 1); b = den.forward_preclamp(xt, st)[1].double().cpu()
+    with torch.no_grad():
+        sig = s.double().view(B, 1, 1, 1).expand(B, 1, H, W)
+        ref = O.unet_forward(torch.cat([x.double(), sig], 1), p64)
+    print(f"{B}x{H}x{W}: fuse_up 1 vs 0: {rel(b, a):.2e}; vs fp64: off {rel(a, ref):.2e} on {rel(b, ref):.2e}")
