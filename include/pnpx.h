@@ -73,10 +73,11 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *  "fft_affine" (default 1), "fft_tile" (default 0 = 1024 points): XCD-affine image mapping and tile size of the FFT passes.
  *  "fold_first" (default 0): 1 = the network's first convolution is evaluated inside the tile loader of the second one
  *      (its output tensor is neither written nor read; bit-identical, time-neutral).
- *  "fuse_up" (default 0): 1 = the full-resolution decoder entry (96 -> 32 channels) up-samples its low-resolution source
+ *  "fuse_up" (default 1 since r5): 1 = the full-resolution decoder entry (96 -> 32 channels) up-samples its low-resolution source
  *      inside the convolution kernel (four producer waves per workgroup interpolate each K-chunk's halo into LDS), so the
- *      largest up-sampled tensor never exists in HBM.  Same arithmetic (per-call difference 1.4e-7), +1.7 % iterations/s;
- *      off by default because it moves the up-sampling time into the convolution launches the roofline is quoted on.
+ *      largest up-sampled tensor never exists in HBM.  Same arithmetic (bit-identical on the r5 build at every size tried,
+ *      tools/ab_fuse_up.py; the test bound is 1e-6), forward 5.82 -> 5.76 ms at 48 x 256^2.  (conv_mode 0 has its own switch,
+ *      "fp32_fuse_up", default 1: all four decoder entries interpolate inside the 8-wave Winograd kernel.)
  *  "subbatch" (images per level-0 sub-batch, 0 = whole batch), "fuse_pool", "fuse_outc" (0/1): diagnostics. */
 int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value);
 int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value);

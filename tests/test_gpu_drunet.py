@@ -352,12 +352,35 @@ def test_drunet_fp32_mode_full_size_vs_oracle_and_half_split(drunet, drunet_f32)
     assert torch.equal(pre1.cpu(), pre32.cpu()[1:2])
 
 
-def test_drunet_fp32_mode_refuses_the_vjp_clearly(drunet_f32):
-    x, sigma = denoiser_inputs(1, 32, 32, 3)
-    xt = t(x).to(dev()).requires_grad_(True)
-    from tfpnp_amd._lib import PnpxError
-    with pytest.raises(PnpxError, match="half-split"):
-        drunet_f32(xt, t(sigma).to(dev())).sum().backward()
+def test_drunet_fp32_mode_vjp_vs_reference_autograd(drunet_f32, drunet):
+    """r5: the DRUNet VJP in fp32 arithmetic (csrc/drunet_f32.hip::drunet_denoise_backward_f32: forward re-computed keeping every
+    ResBlock's ReLU output, adjoint chain on the fp32 kernels -- Winograd adjoints with the ReLU' mask / the skip's add in their
+    epilogues where the level's size allows, the direct fp32 kernel elsewhere) against the reference's own autograd on the kink-free
+    case, against the half-split family's VJP on an arbitrary one, the adjoint identity against a finite difference, determinism."""
+    from tests.golden_inputs import kinkfree_case
+    gold = golden("solver_grads_kinkfree")
+    c = kinkfree_case("drunet")
+    x = t(c["v0"]).to(dev()).requires_grad_(True)
+    s = t(c["acts"][0]).to(dev()).requires_grad_(True)
+    out = drunet_f32(x, s)
+    assert rel(out, gold["drunet_out"]) < 1e-5
+    (out * t(c["wts"]).to(dev())).sum().backward()
+    ex, es = rel(x.grad, gold["drunet_grad_variables"]), rel(s.grad, gold["drunet_grad_sigma"])
+    print(f"DRUNet fp32 VJP (kink-free) vs reference autograd: d/dx {ex:.2e}  d/dsigma {es:.2e}")
+    assert ex < 1e-4 and es < 1e-4
+    # 64 x 64 (levels 64 / 32 / 16: Winograd adjoints; level 8: direct kernel) vs the half-split family's VJP of the same input
+    x2, s2 = denoiser_inputs(2, 64, 64, 1191)
+    x2 = 0.25 + 0.5 * x2
+    w = np.random.RandomState(1192).standard_normal(x2.shape).astype(np.float32)
+    grads = []
+    for den in (drunet_f32, drunet, drunet_f32):
+        lx, ls = t(x2).to(dev()).requires_grad_(True), t(s2).to(dev()).requires_grad_(True)
+        (den(lx, ls) * t(w).to(dev())).sum().backward()
+        grads.append((lx.grad.clone(), ls.grad.clone()))
+    ex, es = rel(grads[0][0], grads[1][0].cpu()), rel(grads[0][1], grads[1][1].cpu())
+    print(f"DRUNet fp32 VJP vs half-split VJP (2 x 64 x 64): d/dx {ex:.2e}  d/dsigma {es:.2e}")
+    assert ex < 2e-2 and es < 2e-2            # (kink flips between the two families' forwards move single gradients by per cents)
+    assert torch.equal(grads[0][0], grads[2][0]) and torch.equal(grads[0][1], grads[2][1])      # deterministic
 
 
 def test_drunet_fp32_mode_is_the_prox_of_the_native_solver_loops(drunet_f32):

@@ -151,7 +151,7 @@ def test_default_scale_weights_30_iterations_within_1e5(config):
 
 
 def test_fused_upsample_option_matches_separate_kernel(unet_params):
-    """Option fuse_up = 1 (producer waves of the conv kernel interpolate the full-resolution decoder entry's second source
+    """Option fuse_up = 1 (default since r5; producer waves of the conv kernel interpolate the full-resolution decoder entry's second source
     on the fly, conv_hs_kernel.h UPS): same arithmetic as the separate up-sampling kernel -- per call and over a
     5-iteration solver call -- at even sizes, silently the separate kernel at sizes the fused instance does not cover,
     deterministic, and within the golden tolerance of the oracle."""
@@ -181,7 +181,7 @@ def test_fused_upsample_option_matches_separate_kernel(unet_params):
                             torch.from_numpy(a["mu"]))
         assert rel(got.cpu(), want) < 1e-5
     finally:
-        ctx.set_option("fuse_up", 0)
+        ctx.set_option("fuse_up", 1)      # the default since r5
 
 
 def _hot_params(unet_params, scale=3e3):

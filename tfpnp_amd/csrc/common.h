@@ -144,6 +144,12 @@ struct DruNet {
   std::vector<const float*> f32_wino;      // Winograd weights of the 3x3 ResBlock layers (else null)
   DeviceBuf f32_weights, f32_arena;
   int f32_capB = 0, f32_capH = 0, f32_capW = 0;
+  bool f32_arena_keeps = false;            // ... with room for every ResBlock's middle activation (the fp32 VJP, r5)
+  bool f32_bwd_ready = false;              // adjoint packings of the fp32 family (made on the first fp32 VJP)
+  std::vector<ConvLayer> f32_layers_bwd;
+  std::vector<const float*> f32_wino_bwd;
+  DeviceBuf f32_weights_bwd, f32_arena_grad;
+  int f32_gcapB = 0, f32_gcapH = 0, f32_gcapW = 0;
   int capB = 0, capH = 0, capW = 0;
   bool arena_keeps = false;            // the arena has room for every ResBlock's middle activation (backward pass)
   int gcapB = 0, gcapH = 0, gcapW = 0;
@@ -164,8 +170,8 @@ struct pnpx_ctx {
   int opt_fuse_pool = 1;           // fused 2x2 max-pool epilogue
   int opt_fuse_outc = 1;           // fused 1x1 out-conv + residual + clamp epilogue
   int opt_fuse_first = 1;          // VALU first convolution straight from the fp32 image (no padded-input tensor)
-  int opt_fuse_up = 0;             // opt-in: bilinear x2 of the full-resolution decoder entry inside the conv kernel
-                                   // (producer waves; +1.7 % iterations/s)
+  int opt_fuse_up = 1;             // bilinear x2 of the full-resolution decoder entry inside the conv kernel (producer waves): r5 default --
+                                   // bit-identical to the separate kernel (tools/ab_fuse_up.py), forward 5.82 -> 5.76 ms at 48 x 256^2
   int opt_policy_s2_hs = 1;        // policy actor: the stride-2 stage entries on the sparse-tap half-split instances
   int opt_fold_first = 0;          // opt-in: first convolution folded into the loader of the second one (conv_hs WREG == 2;
                                    // bit-identical, 400 MB less HBM traffic per forward, time-neutral: 5.835 vs 5.841 ms)
@@ -333,7 +339,9 @@ int drunet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, i
                             float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s);
 void drunet_free(pnpx_ctx* ctx);
 int drunet_denoise_f32(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, float* out, float* out_pre, int B, int H,
-                       int W, hipStream_t s);
+                       int W, hipStream_t s, bool keep_mids = false);
+int drunet_denoise_backward_f32(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out, float* grad_x,
+                                float* grad_sigma, int B, int H, int W, hipStream_t s);
 void drunet_f32_free(pnpx_ctx* ctx);
 
 // Policy actor (policy.hip)

@@ -38,7 +38,7 @@ int launch_conv1x1_act(const ConvLayer& L, const float* in0, float* out, int B, 
 void pack_conv_weights_1x1(const float* w, int cout, int cin, float* dst);
 // Input-gradient convolution: L holds the transposed, tap-flipped weights (pack_conv_weights_transposed).
 int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const float* dmask, int B, int H, int W,
-                        hipStream_t s, const char* dmask_hs = nullptr);
+                        hipStream_t s, const char* dmask_hs = nullptr, float mask_slope = 0.2f);   // mask_slope: LeakyReLU' below zero (0 = ReLU)
 // w[cout][cin][3][3] -> packed weights of the adjoint convolution: wt[ci][co][tap] = w[co][ci][8 - tap], with the
 // adjoint's output channels (= cin) zero-padded to cout_pad.
 // Winograd F(2x2, 3x3) variant of the same layer on the fp32 MFMA (conv3x3_wino.hip; option fp32_winograd).  cout a multiple of 64:

@@ -316,7 +316,7 @@ int launch_conv3x3_act(const ConvLayer& L, const float* in0, int C0, const float
 }
 
 int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const float* dmask, int B, int H, int W,
-                        hipStream_t s, const char* dmask_hs) {
+                        hipStream_t s, const char* dmask_hs, float mask_slope) {
   ConvArgs a;
   a.in0 = gin;
   a.C0 = L.cin;
@@ -330,7 +330,7 @@ int launch_conv3x3_grad(const ConvLayer& L, const float* gin, float* gout, const
   a.Hp = padded_h(H);
   a.Wp = padded_w(W);
   a.nct = L.cout / L.mt;
-  a.slope = 0.2f;
+  a.slope = mask_slope;
   a.mode = dmask_hs ? 4 : (dmask ? 2 : 1);
   a.dmask = dmask;
   a.dmask_hs = dmask_hs;

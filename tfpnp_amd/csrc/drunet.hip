@@ -287,11 +287,7 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
     return PNPX_ERR_NO_WEIGHTS;
   }
   if (ctx->conv_mode != CONV_HS) {
-    if (keep_mids) {
-      set_error("DRUNet: the training forward / VJP run on the half-split convolutions only (conv_mode 1)");
-      return PNPX_ERR_ARG;
-    }
-    return drunet_denoise_f32(ctx, x, sigma, sigma_stride, out, out_pre, B, H, W, s);   // fp32 arithmetic throughout (drunet_f32.hip)
+    return drunet_denoise_f32(ctx, x, sigma, sigma_stride, out, out_pre, B, H, W, s, keep_mids);   // fp32 arithmetic throughout (drunet_f32.hip)
   }
   if (B <= 0 || H < 8 || W < 8 || (H & 7) || (W & 7)) {
     set_error("DRUNet: need B > 0 and H, W positive multiples of 8 (three 2x2 strided convolutions; got B=%d H=%d W=%d)", B, H, W);
@@ -470,6 +466,8 @@ __global__ __launch_bounds__(256) void dru_tail_mask_kernel(const float* __restr
 int drunet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_stride, const float* grad_out,
                             float* grad_x, float* grad_sigma, int B, int H, int W, hipStream_t s) {
   DruNet& N = ctx->drunet;
+  if (ctx->conv_mode != CONV_HS)      // fp32 arithmetic throughout (drunet_f32.hip, r5)
+    return drunet_denoise_backward_f32(ctx, x, sigma, sigma_stride, grad_out, grad_x, grad_sigma, B, H, W, s);
   const size_t npix = (size_t)B * H * W;
   void* sp;
   PNPX_TRY(ctx_scratch(ctx, (3 * npix + (size_t)B * SIG_CHUNKS) * sizeof(float) + 8192, &sp));
