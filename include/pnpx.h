@@ -110,8 +110,8 @@ int pnpx_unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, float* 
  * inside every solver entry below -- runs the DRUNet (out = clamp(net(cat[x, sigma*1]), 0, 1), H and W multiples of 8);
  * pnpx_unet_load switches back.  The *_backward / *_train entries work too: a DRUNet context has no activation ring
  * (tickets are 0), its VJP re-computes the forward keeping every ResBlock's ReLU output and back-propagates on the same
- * kernel family.  conv_mode 0 runs the DRUNet forward in fp32 arithmetic throughout (csrc/drunet_f32.hip; the *_backward /
- * *_train entries return PNPX_ERR_ARG there).  Range guard: the bias-free ReLU network is positively homogeneous, so the first two trips
+ * kernel family.  conv_mode 0 runs the DRUNet in fp32 arithmetic throughout (csrc/drunet_f32.hip; forward and, since r5,
+ * the *_backward / *_train entries).  Range guard: the bias-free ReLU network is positively homogeneous, so the first two trips
  * make later passes (range_guard 1) or the very call (range_guard 2, repeated) run on inputs scaled by 2^-4, then 2^-8, with the
  * tail multiplying back (option "drunet_shift" reads / sets the exponent: 0, 4 or 8; acknowledging a trip keeps it); a trip at
  * 2^-8 latches the context to conv_mode 0 like a UNet context. */

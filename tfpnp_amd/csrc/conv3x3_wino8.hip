@@ -90,10 +90,19 @@ constexpr int LDS_REQ8 = 160 * 1024;                // the whole CU (see conv_hs
   "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", \
   "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
 // accumulator IDX (0..7) = AGPRs 16 * IDX .. 16 * IDX + 15, by name (see conv3x3_wino.hip)
+// -DWINO8_PRIO=n (experiment): the wave raises its issue priority around every MFMA, so that the SIMD's arbiter prefers a ready MFMA over
+// the other wave's VALU / LDS instruction
+#ifdef WINO8_PRIO
+#define WINO8_PRIO_UP "s_setprio 3\n\t"
+#define WINO8_PRIO_DOWN "\n\ts_setprio 0"
+#else
+#define WINO8_PRIO_UP
+#define WINO8_PRIO_DOWN
+#endif
 #define WINO8_MFMA(IDX, x, y) \
-  asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(x), "v"(y), "n"(16 * (IDX)), "n"(16 * (IDX) + 15) : WINO8_ACC)
+  asm volatile(WINO8_PRIO_UP "v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, a[%2:%3]" WINO8_PRIO_DOWN ::"v"(x), "v"(y), "n"(16 * (IDX)), "n"(16 * (IDX) + 15) : WINO8_ACC)
 #define WINO8_MFMA_FROM_ZERO(IDX, x, y) \
-  asm volatile("v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, 0" ::"v"(x), "v"(y), "n"(16 * (IDX)), "n"(16 * (IDX) + 15) : WINO8_ACC)
+  asm volatile(WINO8_PRIO_UP "v_mfma_f32_32x32x2_f32 a[%2:%3], %0, %1, 0" WINO8_PRIO_DOWN ::"v"(x), "v"(y), "n"(16 * (IDX)), "n"(16 * (IDX) + 15) : WINO8_ACC)
 
 // Diagnostic builds (-DWINO8_TRACE, tools/trace_wino8.py): waves 0 and 4 of workgroup 0 stamp s_memtime behind every stage's barrier and
 // at the epilogue's phases into a device array the tool reads back through pnpx_debug_wino8_trace.
