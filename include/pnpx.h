@@ -54,6 +54,12 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *  "fp32_winograd" (default 1): in conv_mode 0, layers with cout % 64 == 0 (sources % 16, H and W % 16) or cout % 32 == 0
  *      (sources % 8, H % 16, W % 32) run as Winograd F(2x2,3x3) in fp32 (1.3-1.8x per layer; 7e-7 from the fp64 oracle where
  *      the direct kernel is 1.1e-6 -- same accuracy class, different summation order).  0 = the direct kernel on every layer.
+ *  "fp32_wino8_layers" (default: all 27 bits set): bit i = layer i of the UNet (state_dict order) runs on the 8-wave Winograd kernel
+ *      (csrc/conv3x3_wino8.hip: the 16 positions of a block split over the two waves of a SIMD; forward and adjoint convolutions) where
+ *      its geometry allows; 0 = the round-4 4-wave kernel (csrc/conv3x3_wino.hip) everywhere.  A DRUNet context: any bit.
+ *  "fp32_fuse_up" (default 1): in conv_mode 0 the decoder-entry convolutions interpolate the bilinear x2 up-sampling of their second
+ *      source inside the 8-wave kernel (tfpnp/pnp/denoiser/models/unet.py:92-121; no up-sampled tensor); 0 = the separate kernel
+ *      (results agree to 5e-7).
  *  "range_guard": the half-split kernels carry activations as f16 hi+lo pairs of 16*v, i.e. |v| < 4095.  Their
  *      epilogues set a sticky flag when a stored value leaves that range or is NaN.
  *      1 (default): the flag is looked at (no synchronisation) at the top of the next call; once seen, the context

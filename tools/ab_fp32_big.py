@@ -1,5 +1,6 @@
-import sys
-sys.path.insert(0, "/root/repo")
+"""fp32 family at full batch against the half-split family, per layer class of the 8-wave Winograd kernel (GPU box).  usage: ab_fp32_big.py [B]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tfpnp_amd import synth
 from tfpnp_amd.pnp import UNetDenoiser2D

@@ -1,5 +1,6 @@
+"""Half-split fuse_up 0 / 1: output difference and distance to the fp64 oracle (GPU box)."""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from tfpnp_amd import synth
 from tfpnp_amd.pnp import UNetDenoiser2D
