@@ -57,6 +57,9 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *  "fp32_wino8_layers" (default: all 27 bits set): bit i = layer i of the UNet (state_dict order) runs on the 8-wave Winograd kernel
  *      (csrc/conv3x3_wino8.hip: the 16 positions of a block split over the two waves of a SIMD; forward and adjoint convolutions) where
  *      its geometry allows; 0 = the round-4 4-wave kernel (csrc/conv3x3_wino.hip) everywhere.  A DRUNet context: any bit.
+ *  "fp32_chains" (default 2): in conv_mode 0 the denoiser forward runs as n independent launch chains over contiguous slices of the batch
+ *      (caller's stream + side streams, joined before the entry returns; bit-identical per image): 2 measured best (-3.6 % at 48 x 256^2,
+ *      -7 % at B = 24); 1 = only the bottom level's three launches fork two chains; 0 = one chain.
  *  "fp32_fuse_up" (default 1): in conv_mode 0 the decoder-entry convolutions interpolate the bilinear x2 up-sampling of their second
  *      source inside the 8-wave kernel (tfpnp/pnp/denoiser/models/unet.py:92-121; no up-sampled tensor); 0 = the separate kernel
  *      (results agree to 5e-7).

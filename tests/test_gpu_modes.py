@@ -424,3 +424,35 @@ def test_fp32_decoder_entries_upsample_inside_the_kernel(unet_params):
             assert rel(fused, plain) < 1e-6 and rel(fused, ref) < 3e-6
     finally:
         ctx.set_option("fp32_fuse_up", 1)
+
+
+def test_fp32_launch_chains_are_bit_identical(unet_params):
+    """r5: the fp32 family's forward as launch chains over slices of the batch (option fp32_chains: 0 one chain, 1 only the bottom level
+    forks, n >= 2 whole-forward chains; default 2).  Per-image results must not depend on the slicing, for odd batch sizes, batches
+    smaller than the chain count, sizes where only some layers run on the Winograd kernels, and inside a solver call."""
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
+    den = UNetDenoiser2D(state_dict=unet_params, conv_mode=0)
+    ctx = den.context(dev())
+    assert ctx.get_option("fp32_chains") == 2
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    try:
+        for (B, H, W) in [(5, 64, 64), (1, 128, 96), (9, 32, 48), (7, 256, 256), (3, 50, 39)]:
+            x, s = denoiser_inputs(B, H, W, 500 + B)
+            x, s = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
+            ctx.set_option("fp32_chains", 0)
+            ref = den.forward_preclamp(x, s)[1].clone()
+            for c in (1, 2, 3):
+                ctx.set_option("fp32_chains", c)
+                assert torch.equal(den.forward_preclamp(x, s)[1], ref), (B, H, W, c)
+        d = synth.make_csmri_batch(5, 64, 64, ratio=4, seed=43)
+        a = synth.make_actions(5)[0]
+        sol = ADMMSolver_CSMRI(den)
+        v0 = sol.reset({"x0": t(d["x0"])})
+        outs = []
+        for c in (0, 2):
+            ctx.set_option("fp32_chains", c)
+            outs.append(sol((v0, (t(d["y0"]), t(d["mask"]))), (t(a["sigma_d"]), t(a["mu"]))).clone())
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        ctx.set_option("fp32_chains", 2)

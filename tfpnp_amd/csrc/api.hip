@@ -242,6 +242,10 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_fp32_winograd = value;
     return PNPX_OK;
   }
+  if (is("fp32_chains") && value >= 0 && value <= 8) {
+    ctx->opt_fp32_chains = value;
+    return PNPX_OK;
+  }
   if (is("fp32_fuse_up") && (value == 0 || value == 1)) {
     ctx->opt_fp32_fuse_up = value;
     return PNPX_OK;
@@ -317,6 +321,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fp32_winograd")) *value = ctx->opt_fp32_winograd;
   else if (is("fp32_wino8_layers")) *value = ctx->opt_fp32_wino8;
   else if (is("fp32_fuse_up")) *value = ctx->opt_fp32_fuse_up;
+  else if (is("fp32_chains")) *value = ctx->opt_fp32_chains;
   else if (is("fft_tile")) *value = ctx->opt_fft_tile;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
   else if (is("train_cache_gb")) *value = ctx->opt_train_cache_gb;

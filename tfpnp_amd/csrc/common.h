@@ -201,6 +201,9 @@ struct pnpx_ctx {
   int opt_fp32_winograd = 1;       // conv_mode 0: run those layers as F(2x2,3x3) (fp32 arithmetic, 2.25x fewer MFMAs; 0 = the direct kernel everywhere)
   int opt_fp32_wino8 = (1 << 27) - 1;   // bit li: layer li runs on the 8-wave Winograd kernel (conv3x3_wino8.hip) where its geometry allows; a DRUNet
                                    // context: any bit = its ResBlock layers do
+  int opt_fp32_chains = 2;         // conv_mode 0: n >= 2 = the forward as n launch chains over slices of the batch (default 2: this family is not
+                                   // power-capped, a second chain fills the other's tails and partial rounds: 8.76 -> 8.44 ms at 48 x 256^2, -7 % at
+                                   // B = 24; 3 and 4 chains measured slower); 1 = only the bottom level forks two chains; 0 = one chain
   int opt_fp32_fuse_up = 1;        // conv_mode 0: the decoder entries up-sample their second source inside the 8-wave Winograd kernel (no up-sampled tensor)
   pnpx::ConvLayer conv_bwd[27];    // adjoint (input-gradient) convolutions, fp32 kernel family
   pnpx::ConvLayerHsDev conv_hs_bwd[27];  // ... and packed for the half-split kernel family

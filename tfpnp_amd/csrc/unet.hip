@@ -610,6 +610,143 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
   return PNPX_OK;
 }
 
+// fp32 forward pass (conv_mode 0) over B images that are images b_base .. b_base + B - 1 of the arena (x / sigma / out already point at the
+// first of them): the whole batch, or one of two launch chains (unet_denoise).  level_chains: the bottom level may fork two chains itself.
+static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, const float* x, const float* sigma, int sigma_stride, float* out,
+                            float* out_pre, int B, int H, int W, hipStream_t s, Recorder& rec, bool keep_all, bool level_chains, int b_base = 0) {
+  // ---- plain-fp32 path (conv_mode 0): padded planar fp32 activations, whole batch per launch
+  char* A = static_cast<char*>(ar.buf.p);
+  auto fptr = [&](const Act& d) { return reinterpret_cast<float*>(A + d.off + (size_t)b_base * act_bytes_per_image(CONV_F32, d.C, d.H, d.W)); };
+  // the first convolution (2 -> 32 channels) straight from the fp32 image on the vector ALU (training forwards too: the VJP needs the
+  // layer's output, not its padded input tensor)
+  const bool first_valu = ctx->opt_fuse_first && W % 4 == 0 && ctx->conv[0].cout == 32;
+  if (!first_valu) {
+    hipLaunchKernelGGL(prep_input_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, x, sigma, sigma_stride, fptr(P.in0), H,
+                       W, padded_h(H), padded_w(W));
+    PNPX_LAUNCH_CHECK();
+    PNPX_TRY(rec.mark("prep_input", 0));
+  }
+  // pooled: the encoder's MaxPool2d(2) of this layer's output, written by the same launch when the Winograd kernel runs the layer
+  // (one 2x2 output tile = one lane's four values); *pooled_done tells the caller whether the separate pooling kernel is still needed
+  auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o, const Act* pooled = nullptr, bool* pooled_done = nullptr) -> int {
+    const ConvLayer& L = ctx->conv[li];
+    const int C1 = i1 ? i1->C : 0;
+    if (pooled_done) *pooled_done = false;
+    if (ctx->opt_fp32_winograd && ctx->conv_wino_u[li] && conv3x3_wino_ok(i0.C, C1, L.cout, o.H, o.W)) {
+      const bool w8 = ((ctx->opt_fp32_wino8 >> li) & 1) && conv3x3_wino8_ok(i0.C, C1, L.cout, o.H, o.W);
+      PNPX_TRY((w8 ? launch_conv3x3_wino8 : launch_conv3x3_wino)(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1,
+                                                                fptr(o), B, o.H, o.W, s, 0.2f, nullptr, pooled ? fptr(*pooled) : nullptr));
+      if (pooled_done) *pooled_done = pooled != nullptr;
+      return rec.mark("conv3x3_wino", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);   // algorithmic FLOPs; 4/9 of them executed
+    } else {
+      PNPX_TRY(launch_conv3x3(L, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1, fptr(o), B, o.H, o.W, s));
+    }
+    return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);
+  };
+  auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o, const Act* pooled = nullptr, bool* pooled_done = nullptr) -> int {
+    const Act& ta = i1 ? P.da[lvl] : P.a[lvl];
+    const Act& tb = i1 ? P.db[lvl] : P.b[lvl];
+    if (li == 0 && first_valu) {
+      hipLaunchKernelGGL(conv_first_f32_kernel, dim3((H * (W / 4) + 255) / 256, 4, B), dim3(256), 0, s, x, sigma, sigma_stride, ctx->conv0_w,
+                         ctx->conv[0].b, fptr(ta), H, W, 0.2f);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(rec.mark("conv3x3", 2.0 * 9.0 * 2 * 32 * (double)H * W * B));
+    } else
+    PNPX_TRY(conv(li, i0, i1, ta));
+    PNPX_TRY(conv(li + 1, ta, nullptr, tb));
+    return conv(li + 2, tb, nullptr, o, pooled, pooled_done);
+  };
+  bool pooled = false;
+  PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0], &P.p[1], &pooled));
+  for (int l = 1; l < 5; ++l) {
+    const Act& src = P.x[l - 1];
+    if (!pooled) {
+      const size_t n_pool = (size_t)B * src.C * (src.H / 2) * (src.W / 2);
+      hipLaunchKernelGGL(maxpool2_kernel, g1d(n_pool), dim3(256), 0, s, fptr(src), fptr(P.p[l]), n_pool, src.H, src.W);
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(rec.mark("maxpool2", 0));
+    }
+    // r5: the bottom level's three launches as TWO launch chains over halves of the batch when their tile count sits between round
+    // boundaries (B = 48 at 256^2: 384 tiles of 64 couts x 16 x 16 px on 256 one-per-CU workgroups = two rounds for 1.5 rounds of work):
+    // the second half's first layer fills the CUs the first half's leaves idle, and so on down the three layers.  Per-image results do
+    // not depend on the slicing (same kernel, independent tiles).
+    if (l == 4 && level_chains && B >= 2) {
+      const Act& o4 = P.x[4];
+      bool all8 = ctx->opt_fp32_winograd != 0;
+      for (int li = 12; li < 15; ++li)
+        all8 = all8 && ctx->conv_wino_u[li] && ((ctx->opt_fp32_wino8 >> li) & 1) && conv3x3_wino8_ok(ctx->conv[li].cin, 0, ctx->conv[li].cout, o4.H, o4.W);
+      const long long ntiles = (long long)(o4.H / 16) * (o4.W / 16) * B * (ctx->conv[13].cout / 64);
+      if (all8 && ntiles > 256 && ntiles < 768 && ntiles % 256 != 0) {
+        PNPX_TRY(fan_out_chains(ctx, 2, B, s, [&](int lo, int hi, hipStream_t st) -> int {
+          auto slice = [&](int li, const Act& i, const Act& o) -> int {
+            const ConvLayer& L = ctx->conv[li];
+            return launch_conv3x3_wino8(ctx->conv_wino_u[li], L.b, L.cout, fptr(i) + (size_t)lo * i.C * padded_h(i.H) * padded_w(i.W), i.C, nullptr, 0,
+                                        fptr(o) + (size_t)lo * o.C * padded_h(o.H) * padded_w(o.W), hi - lo, o.H, o.W, st, 0.2f, nullptr, nullptr);
+          };
+          PNPX_TRY(slice(12, P.p[4], P.a[4]));
+          PNPX_TRY(slice(13, P.a[4], P.b[4]));
+          return slice(14, P.b[4], P.x[4]);
+        }));
+        pooled = false;
+        continue;
+      }
+    }
+    PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l], l < 4 ? &P.p[l + 1] : nullptr, &pooled));
+  }
+  const Act* below = &P.x[4];
+  for (int l = 3; l >= 0; --l) {
+    const int h = below->H, w = below->W;
+    const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+    const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+    const size_t n_up = (size_t)B * below->C * (2 * h) * (2 * w);
+    // r5: the decoder entry interpolates its second source itself (conv3x3_wino8.hip UPS instances: the low-resolution window of a
+    // chunk's halo staged in LDS, bilinear x2 into the halo buffer) -- no up-sampled tensor in HBM (models/unet.py:92-121)
+    const int li0 = 15 + 3 * (3 - l);
+    // (training forwards too: the VJP of the up-sampling is linear in the gradient and reads no up-sampled activation)
+    const bool ups_fused = ctx->opt_fp32_fuse_up && ctx->opt_fp32_winograd && ctx->conv_wino_u[li0] && ((ctx->opt_fp32_wino8 >> li0) & 1) &&
+                           P.x[l].H == 2 * h && P.x[l].W == 2 * w && conv3x3_wino8_ups_ok(P.x[l].C, below->C, ctx->conv[li0].cout, 2 * h, 2 * w);
+    if (ups_fused) {
+    } else if ((2 * w) % 4 == 0 && (size_t)B * below->C <= 65535) {
+      const int quads = w / 2, bx = quads >= 64 ? 64 : quads, by = 256 / bx;
+      hipLaunchKernelGGL(upsample2x_v4_kernel, dim3((quads + bx - 1) / bx, (2 * h + by * UPS_ROWS - 1) / (by * UPS_ROWS), B * below->C), dim3(bx, by), 0, s,
+                         fptr(*below), fptr(P.u[l]), h, w, P.u[l].H, P.u[l].W, sy, sx);
+    } else {
+      hipLaunchKernelGGL(upsample2x_kernel, g1d(n_up), dim3(256), 0, s, fptr(*below), fptr(P.u[l]), n_up, h, w, P.u[l].H,
+                         P.u[l].W, sy, sx);
+    }
+    PNPX_LAUNCH_CHECK();
+    if (!ups_fused) PNPX_TRY(rec.mark("upsample2x", 0));
+    // first convolution of a decoder block: the fused instance reads the low-resolution tensor
+    auto entry = [&](const Act& ta) -> int {
+      if (!ups_fused) return conv(li0, P.x[l], &P.u[l], ta);
+      const ConvLayer& L = ctx->conv[li0];
+      PNPX_TRY(launch_conv3x3_wino8_ups(ctx->conv_wino_u[li0], L.b, L.cout, fptr(P.x[l]), P.x[l].C, fptr(*below), below->C, fptr(ta), B, 2 * h, 2 * w, s));
+      return rec.mark("conv3x3_wino", 2.0 * 9.0 * L.cin * L.cout * (double)(2 * h) * (2 * w) * B);
+    };
+    // the network's last 3x3 layer takes the 1x1 out-conv + residual + clamp into its epilogue when the Winograd kernel runs it
+    // (inference passes only: a training forward keeps the layer's output for the VJP)
+    const bool fuse_outc = l == 0 && !keep_all && ctx->opt_fuse_outc && ctx->opt_fp32_winograd && ctx->conv_wino_u[26] &&
+                           conv3x3_wino_outc_ok(ctx->conv[26].cin, ctx->conv[26].cout, H, W);
+    if (fuse_outc) {
+      PNPX_TRY(entry(P.da[0]));
+      PNPX_TRY(conv(25, P.da[0], nullptr, P.db[0]));
+      const bool w8 = ((ctx->opt_fp32_wino8 >> 26) & 1) && conv3x3_wino8_ok(ctx->conv[26].cin, 0, ctx->conv[26].cout, H, W);
+      PNPX_TRY((w8 ? launch_conv3x3_wino8_outc : launch_conv3x3_wino_outc)(ctx->conv_wino_u[26], ctx->conv[26].b, fptr(P.db[0]), ctx->conv[26].cin,
+                                                                          ctx->outc_w, ctx->outc_b, x, out, out_pre, B, H, W, s));
+      return rec.mark("conv3x3_wino", 2.0 * 9.0 * ctx->conv[26].cin * ctx->conv[26].cout * (double)H * W * B);
+    }
+    PNPX_TRY(entry(P.da[l]));
+    PNPX_TRY(conv(li0 + 1, P.da[l], nullptr, P.db[l]));
+    PNPX_TRY(conv(li0 + 2, P.db[l], nullptr, P.y[l]));
+    below = &P.y[l];
+  }
+  hipLaunchKernelGGL(outc_residual_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, fptr(P.y[0]), x, ctx->outc_w,
+                     ctx->outc_b, out, out_pre, H, W);
+  PNPX_LAUNCH_CHECK();
+  PNPX_TRY(rec.mark("outc_residual_clamp", 2.0 * 32 * (double)H * W * B));
+  return PNPX_OK;
+}
+
 // Number of independent launch chains for a B-image forward: option "chains" (0 = automatic, n = exactly n when B >= n).
 int launch_chains(const pnpx_ctx* ctx, int B, int H, int W) {
   int n = ctx->opt_chains;
@@ -694,112 +831,19 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
   }
   if (hs) return unet_forward_hs(ctx, ar, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec, keep_all);
 
-  // ---- plain-fp32 path (conv_mode 0): padded planar fp32 activations, whole batch per launch
-  char* A = static_cast<char*>(ar.buf.p);
-  auto fptr = [&](const Act& d) { return reinterpret_cast<float*>(A + d.off); };
-  // the first convolution (2 -> 32 channels) straight from the fp32 image on the vector ALU (training forwards too: the VJP needs the
-  // layer's output, not its padded input tensor)
-  const bool first_valu = ctx->opt_fuse_first && W % 4 == 0 && ctx->conv[0].cout == 32;
-  if (!first_valu) {
-    hipLaunchKernelGGL(prep_input_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, x, sigma, sigma_stride, fptr(P.in0), H,
-                       W, padded_h(H), padded_w(W));
-    PNPX_LAUNCH_CHECK();
-    PNPX_TRY(rec.mark("prep_input", 0));
+  // ---- plain-fp32 path (conv_mode 0): padded planar fp32 activations
+  // r5: two launch chains over halves of the batch (option fp32_chains = 2; bit-identical per image).  Unlike the half-split family this
+  // one is not power-capped, so what one chain's launch leaves idle at its tail / between round boundaries the other chain's launches
+  // fill.  fp32_chains = 1: only the bottom level (16 x 16 at 256^2: 384 tiles on 256 workgroups) forks two chains.
+  if (!prof && ctx->opt_fp32_chains >= 2 && B >= ctx->opt_fp32_chains) {
+    const size_t px = (size_t)H * W;
+    return fan_out_chains(ctx, ctx->opt_fp32_chains, B, s, [&](int lo, int hi, hipStream_t st) -> int {
+      Recorder none{nullptr, st};
+      return unet_forward_f32(ctx, ar, P, x + lo * px, sigma + (size_t)lo * sigma_stride, sigma_stride, out + lo * px,
+                              out_pre ? out_pre + lo * px : nullptr, hi - lo, H, W, st, none, keep_all, false, lo);
+    });
   }
-  // pooled: the encoder's MaxPool2d(2) of this layer's output, written by the same launch when the Winograd kernel runs the layer
-  // (one 2x2 output tile = one lane's four values); *pooled_done tells the caller whether the separate pooling kernel is still needed
-  auto conv = [&](int li, const Act& i0, const Act* i1, const Act& o, const Act* pooled = nullptr, bool* pooled_done = nullptr) -> int {
-    const ConvLayer& L = ctx->conv[li];
-    const int C1 = i1 ? i1->C : 0;
-    if (pooled_done) *pooled_done = false;
-    if (ctx->opt_fp32_winograd && ctx->conv_wino_u[li] && conv3x3_wino_ok(i0.C, C1, L.cout, o.H, o.W)) {
-      const bool w8 = ((ctx->opt_fp32_wino8 >> li) & 1) && conv3x3_wino8_ok(i0.C, C1, L.cout, o.H, o.W);
-      PNPX_TRY((w8 ? launch_conv3x3_wino8 : launch_conv3x3_wino)(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1,
-                                                                fptr(o), B, o.H, o.W, s, 0.2f, nullptr, pooled ? fptr(*pooled) : nullptr));
-      if (pooled_done) *pooled_done = pooled != nullptr;
-      return rec.mark("conv3x3_wino", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);   // algorithmic FLOPs; 4/9 of them executed
-    } else {
-      PNPX_TRY(launch_conv3x3(L, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1, fptr(o), B, o.H, o.W, s));
-    }
-    return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);
-  };
-  auto block = [&](int li, const Act& i0, const Act* i1, int lvl, const Act& o, const Act* pooled = nullptr, bool* pooled_done = nullptr) -> int {
-    const Act& ta = i1 ? P.da[lvl] : P.a[lvl];
-    const Act& tb = i1 ? P.db[lvl] : P.b[lvl];
-    if (li == 0 && first_valu) {
-      hipLaunchKernelGGL(conv_first_f32_kernel, dim3((H * (W / 4) + 255) / 256, 4, B), dim3(256), 0, s, x, sigma, sigma_stride, ctx->conv0_w,
-                         ctx->conv[0].b, fptr(ta), H, W, 0.2f);
-      PNPX_LAUNCH_CHECK();
-      PNPX_TRY(rec.mark("conv3x3", 2.0 * 9.0 * 2 * 32 * (double)H * W * B));
-    } else
-    PNPX_TRY(conv(li, i0, i1, ta));
-    PNPX_TRY(conv(li + 1, ta, nullptr, tb));
-    return conv(li + 2, tb, nullptr, o, pooled, pooled_done);
-  };
-  bool pooled = false;
-  PNPX_TRY(block(0, P.in0, nullptr, 0, P.x[0], &P.p[1], &pooled));
-  for (int l = 1; l < 5; ++l) {
-    const Act& src = P.x[l - 1];
-    if (!pooled) {
-      const size_t n_pool = (size_t)B * src.C * (src.H / 2) * (src.W / 2);
-      hipLaunchKernelGGL(maxpool2_kernel, g1d(n_pool), dim3(256), 0, s, fptr(src), fptr(P.p[l]), n_pool, src.H, src.W);
-      PNPX_LAUNCH_CHECK();
-      PNPX_TRY(rec.mark("maxpool2", 0));
-    }
-    PNPX_TRY(block(3 * l, P.p[l], nullptr, l, P.x[l], l < 4 ? &P.p[l + 1] : nullptr, &pooled));
-  }
-  const Act* below = &P.x[4];
-  for (int l = 3; l >= 0; --l) {
-    const int h = below->H, w = below->W;
-    const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
-    const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
-    const size_t n_up = (size_t)B * below->C * (2 * h) * (2 * w);
-    // r5: the decoder entry interpolates its second source itself (conv3x3_wino8.hip UPS instances: the low-resolution window of a
-    // chunk's halo staged in LDS, bilinear x2 into the halo buffer) -- no up-sampled tensor in HBM (models/unet.py:92-121)
-    const int li0 = 15 + 3 * (3 - l);
-    // (training forwards too: the VJP of the up-sampling is linear in the gradient and reads no up-sampled activation)
-    const bool ups_fused = ctx->opt_fp32_fuse_up && ctx->opt_fp32_winograd && ctx->conv_wino_u[li0] && ((ctx->opt_fp32_wino8 >> li0) & 1) &&
-                           P.x[l].H == 2 * h && P.x[l].W == 2 * w && conv3x3_wino8_ups_ok(P.x[l].C, below->C, ctx->conv[li0].cout, 2 * h, 2 * w);
-    if (ups_fused) {
-    } else if ((2 * w) % 4 == 0 && (size_t)B * below->C <= 65535) {
-      const int quads = w / 2, bx = quads >= 64 ? 64 : quads, by = 256 / bx;
-      hipLaunchKernelGGL(upsample2x_v4_kernel, dim3((quads + bx - 1) / bx, (2 * h + by * UPS_ROWS - 1) / (by * UPS_ROWS), B * below->C), dim3(bx, by), 0, s,
-                         fptr(*below), fptr(P.u[l]), h, w, P.u[l].H, P.u[l].W, sy, sx);
-    } else {
-      hipLaunchKernelGGL(upsample2x_kernel, g1d(n_up), dim3(256), 0, s, fptr(*below), fptr(P.u[l]), n_up, h, w, P.u[l].H,
-                         P.u[l].W, sy, sx);
-    }
-    PNPX_LAUNCH_CHECK();
-    if (!ups_fused) PNPX_TRY(rec.mark("upsample2x", 0));
-    // first convolution of a decoder block: the fused instance reads the low-resolution tensor
-    auto entry = [&](const Act& ta) -> int {
-      if (!ups_fused) return conv(li0, P.x[l], &P.u[l], ta);
-      const ConvLayer& L = ctx->conv[li0];
-      PNPX_TRY(launch_conv3x3_wino8_ups(ctx->conv_wino_u[li0], L.b, L.cout, fptr(P.x[l]), P.x[l].C, fptr(*below), below->C, fptr(ta), B, 2 * h, 2 * w, s));
-      return rec.mark("conv3x3_wino", 2.0 * 9.0 * L.cin * L.cout * (double)(2 * h) * (2 * w) * B);
-    };
-    // the network's last 3x3 layer takes the 1x1 out-conv + residual + clamp into its epilogue when the Winograd kernel runs it
-    // (inference passes only: a training forward keeps the layer's output for the VJP)
-    const bool fuse_outc = l == 0 && !keep_all && ctx->opt_fuse_outc && ctx->opt_fp32_winograd && ctx->conv_wino_u[26] &&
-                           conv3x3_wino_outc_ok(ctx->conv[26].cin, ctx->conv[26].cout, H, W);
-    if (fuse_outc) {
-      PNPX_TRY(entry(P.da[0]));
-      PNPX_TRY(conv(25, P.da[0], nullptr, P.db[0]));
-      const bool w8 = ((ctx->opt_fp32_wino8 >> 26) & 1) && conv3x3_wino8_ok(ctx->conv[26].cin, 0, ctx->conv[26].cout, H, W);
-      PNPX_TRY((w8 ? launch_conv3x3_wino8_outc : launch_conv3x3_wino_outc)(ctx->conv_wino_u[26], ctx->conv[26].b, fptr(P.db[0]), ctx->conv[26].cin,
-                                                                          ctx->outc_w, ctx->outc_b, x, out, out_pre, B, H, W, s));
-      return rec.mark("conv3x3_wino", 2.0 * 9.0 * ctx->conv[26].cin * ctx->conv[26].cout * (double)H * W * B);
-    }
-    PNPX_TRY(entry(P.da[l]));
-    PNPX_TRY(conv(li0 + 1, P.da[l], nullptr, P.db[l]));
-    PNPX_TRY(conv(li0 + 2, P.db[l], nullptr, P.y[l]));
-    below = &P.y[l];
-  }
-  hipLaunchKernelGGL(outc_residual_kernel, dim3((W + 63) / 64, H, B), dim3(64), 0, s, fptr(P.y[0]), x, ctx->outc_w,
-                     ctx->outc_b, out, out_pre, H, W);
-  PNPX_LAUNCH_CHECK();
-  PNPX_TRY(rec.mark("outc_residual_clamp", 2.0 * 32 * (double)H * W * B));
-  return PNPX_OK;
+  return unet_forward_f32(ctx, ar, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec, keep_all, !prof && ctx->opt_fp32_chains == 1);
 }
 
 }  // namespace pnpx
