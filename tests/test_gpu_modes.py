@@ -427,7 +427,7 @@ def test_fp32_decoder_entries_upsample_inside_the_kernel(unet_params):
 
 
 def test_fp32_launch_chains_are_bit_identical(unet_params):
-    """r5: the fp32 family's forward as launch chains over slices of the batch (option fp32_chains: 0 one chain, 1 only the bottom level
+    """r5: the fp32 family's forward (and the VJP's adjoint chain) as launch chains over slices of the batch (option fp32_chains: 0 one chain, 1 only the bottom level
     forks, n >= 2 whole-forward chains; default 2).  Per-image results must not depend on the slicing, for odd batch sizes, batches
     smaller than the chain count, sizes where only some layers run on the Winograd kernels, and inside a solver call."""
     from tfpnp_amd.pnp import UNetDenoiser2D
@@ -445,6 +445,14 @@ def test_fp32_launch_chains_are_bit_identical(unet_params):
             for c in (1, 2, 3):
                 ctx.set_option("fp32_chains", c)
                 assert torch.equal(den.forward_preclamp(x, s)[1], ref), (B, H, W, c)
+            # the VJP's adjoint chain is sliced the same way (two chains when fp32_chains >= 2)
+            from tfpnp_amd import ops
+            g = torch.from_numpy(np.random.default_rng(B).standard_normal((B, 1, H, W)).astype(np.float32)).to(dev())
+            ctx.set_option("fp32_chains", 0)
+            gx0, gs0 = [v.clone() for v in ops.unet_denoise_backward(ctx, x, s.reshape(-1), g)]
+            ctx.set_option("fp32_chains", 2)
+            gx2, gs2 = ops.unet_denoise_backward(ctx, x, s.reshape(-1), g)
+            assert torch.equal(gx0, gx2) and torch.equal(gs0, gs2), (B, H, W)
         d = synth.make_csmri_batch(5, 64, 64, ratio=4, seed=43)
         a = synth.make_actions(5)[0]
         sol = ADMMSolver_CSMRI(den)

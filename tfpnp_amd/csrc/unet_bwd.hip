@@ -418,7 +418,6 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
   }
   const UNetPlan F = make_plan(fmode, fa.capB, H, W);
   char* FA = static_cast<char*>(fa.buf.p);
-  auto sact = [&](const Act& d) { return SavedAct{FA + d.off, hs ? 1 : 0}; };
 
   // 2. gradient arena (zero borders: gradients are convolution INPUTS of the adjoint convs)
   {
@@ -450,7 +449,6 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
   }
   const GradPlan G = make_grad_plan(fmode, ctx->arena_grad.capB, H, W);
   char* GA = static_cast<char*>(ctx->arena_grad.buf.p);
-  auto gptr = [&](const Act& d) { return reinterpret_cast<float*>(GA + d.off); };
 
   if (hs) {
     // ---- half-split backward: HS8 gradients, f16x3 MFMA adjoint convolutions
@@ -517,19 +515,31 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
     return PNPX_OK;
   }
 
+  // 3..6 over images lo .. lo + B - 1 on stream s: the whole batch, or one of two launch chains (r5, option fp32_chains; the fp32 family is
+  // not power-capped, a second chain fills the first one's tails and partial rounds; per-image results do not depend on the slicing)
+  auto run = [&](int lo, int B, hipStream_t s) -> int {
+  const size_t npix = (size_t)B * H * W, px0 = (size_t)lo * H * W;
+  const float* const grad_out_s = grad_out + px0;
+  const float* const pre_s = pre + px0;
+  float* const g_res_s = g_res + px0;
+  float* const grad_x_s = grad_x ? grad_x + px0 : nullptr;
+  float* const part_s = part + (size_t)lo * SIG_CHUNKS;
+  float* const grad_sigma_s = grad_sigma ? grad_sigma + lo : nullptr;
+  auto gp = [&](const Act& d) { return reinterpret_cast<float*>(GA + d.off + (size_t)lo * act_bytes_per_image(fmode, d.C, d.H, d.W)); };
+  auto sa = [&](const Act& d) { return SavedAct{FA + d.off + (size_t)lo * act_bytes_per_image(fmode, d.C, d.H, d.W), 0}; };
   // 3. tail: clamp + residual + 1x1 out-conv -> gradient wrt the pre-activation of the last conv (y[0])
-  hipLaunchKernelGGL(outc_bwd_kernel, g1(npix), dim3(256), 0, s, grad_out, pre, ctx->outc_w, sact(F.y[0]), gptr(G.y[0]),
-                     g_res, H, W, npix);
+  hipLaunchKernelGGL(outc_bwd_kernel, g1(npix), dim3(256), 0, s, grad_out_s, pre_s, ctx->outc_w, sa(F.y[0]), gp(G.y[0]),
+                     g_res_s, H, W, npix);
   PNPX_LAUNCH_CHECK();
 
   auto convT = [&](int li, const Act& gin, const Act& gout, const Act* saved) -> int {
-    const float* dm = (saved && !hs) ? reinterpret_cast<const float*>(FA + saved->off) : nullptr;
-    const char* dmh = (saved && hs) ? FA + saved->off : nullptr;
+    const float* dm = saved ? reinterpret_cast<const float*>(FA + saved->off + (size_t)lo * act_bytes_per_image(fmode, saved->C, saved->H, saved->W)) : nullptr;
+    const char* dmh = nullptr;
     // r5: Winograd F(2x2,3x3) for the adjoint convolutions too (8-wave kernel, LeakyReLU' mask in its epilogue)
     if (!hs && ctx->opt_fp32_winograd && ((ctx->opt_fp32_wino8 >> li) & 1) && ctx->conv_wino_u_bwd[li] && gout.C == ctx->conv_bwd[li].cout &&
         conv3x3_wino8_ok(gin.C, 0, gout.C, gout.H, gout.W))
-      return launch_conv3x3_wino8_grad(ctx->conv_wino_u_bwd[li], ctx->zero_bias, gout.C, gptr(gin), gin.C, gptr(gout), dm, 0.2f, B, gout.H, gout.W, s);
-    return launch_conv3x3_grad(ctx->conv_bwd[li], gptr(gin), gptr(gout), dm, B, gout.H, gout.W, s, dmh);
+      return launch_conv3x3_wino8_grad(ctx->conv_wino_u_bwd[li], ctx->zero_bias, gout.C, gp(gin), gin.C, gp(gout), dm, 0.2f, B, gout.H, gout.W, s);
+    return launch_conv3x3_grad(ctx->conv_bwd[li], gp(gin), gp(gout), dm, B, gout.H, gout.W, s, dmh);
   };
 
   // 4. decoder blocks, top (level 0) to bottom (level 3)
@@ -545,16 +555,16 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
     const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
     const size_t n = (size_t)B * Cb * h * w;
-    hipLaunchKernelGGL(upsample_bwd_kernel, g1(n), dim3(256), 0, s, gptr(G.cat[l]), G.cat[l].C, F.x[l].C, sact(below_f),
-                       gptr(below_g), Cb, h, w, G.cat[l].H, G.cat[l].W, sy, sx, n);
+    hipLaunchKernelGGL(upsample_bwd_kernel, g1(n), dim3(256), 0, s, gp(G.cat[l]), G.cat[l].C, F.x[l].C, sa(below_f),
+                       gp(below_g), Cb, h, w, G.cat[l].H, G.cat[l].W, sy, sx, n);
     PNPX_LAUNCH_CHECK();
   }
   // 5. encoder blocks, bottom (level 4) to top
   for (int l = 4; l >= 0; --l) {
     if (l < 4) {   // gradient reaching x[l]: skip part of the decoder concat + max-pool routing from level l+1
       const size_t n = (size_t)B * F.x[l].C * F.x[l].H * F.x[l].W;
-      hipLaunchKernelGGL(skip_pool_merge_kernel, g1(n), dim3(256), 0, s, gptr(G.cat[l]), G.cat[l].C, gptr(G.p[l + 1]),
-                         sact(F.x[l]), gptr(G.x[l]), F.x[l].C, F.x[l].H, F.x[l].W, n);
+      hipLaunchKernelGGL(skip_pool_merge_kernel, g1(n), dim3(256), 0, s, gp(G.cat[l]), G.cat[l].C, gp(G.p[l + 1]),
+                         sa(F.x[l]), gp(G.x[l]), F.x[l].C, F.x[l].H, F.x[l].W, n);
       PNPX_LAUNCH_CHECK();
     }
     PNPX_TRY(convT(3 * l + 2, G.x[l], G.b[l], &F.b[l]));
@@ -562,12 +572,16 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
     PNPX_TRY(convT(3 * l, G.a[l], l == 0 ? G.in0 : G.p[l], nullptr));
   }
   // 6. input gradients
-  hipLaunchKernelGGL(input_grad_kernel, dim3(SIG_CHUNKS, B), dim3(256), 0, s, gptr(G.in0), G.in0.C, g_res, grad_x, part, H,
+  hipLaunchKernelGGL(input_grad_kernel, dim3(SIG_CHUNKS, B), dim3(256), 0, s, gp(G.in0), G.in0.C, g_res_s, grad_x_s, part_s, H,
                      W);
   PNPX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sigma_grad_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, part, grad_sigma, B);
+  hipLaunchKernelGGL(sigma_grad_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, part_s, grad_sigma_s, B);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
+  };
+  if (ctx->opt_fp32_chains >= 2 && B >= 2)
+    return fan_out_chains(ctx, 2, B, s, [&](int lo, int hi, hipStream_t st) -> int { return run(lo, hi - lo, st); });
+  return run(0, B, s);
 }
 
 }  // namespace pnpx
