@@ -170,6 +170,10 @@ def test_fused_upsample_option_matches_separate_kernel(unet_params):
             ctx.set_option("fuse_up", 1)
             out = den(x, s).clone()
             assert rel(out, ref) < 1e-6 and torch.equal(out, den(x, s))
+            # opt-in value 2: every decoder entry whose geometry allows it (64-cout tiles: 8-row instance), measured slower than the
+            # separate kernel at those levels (profiles/r5_wino8.md's neighbour r5_hs_fuse_up.md) -- same bits
+            ctx.set_option("fuse_up", 2)
+            assert rel(den(x, s), ref) < 1e-6
         oden = O.Denoiser(unet_params)
         d = synth.make_csmri_batch(2, 64, 64, ratio=4, seed=41)
         a = synth.make_actions(2)[0]

@@ -270,7 +270,7 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_wreg = value;
     return PNPX_OK;
   }
-  if (is("fuse_up") && (value == 0 || value == 1)) {
+  if (is("fuse_up") && (value >= 0 && value <= 2)) {
     ctx->opt_fuse_up = value;
     return PNPX_OK;
   }

@@ -151,6 +151,8 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
     a.ups_w = fuse.ups_w;
     a.ups_sy = (H > 1) ? (float)(fuse.ups_h - 1) / (float)(H - 1) : 0.f;
     a.ups_sx = (W > 1) ? (float)(fuse.ups_w - 1) / (float)(W - 1) : 0.f;
+    // (64-cout layers: 8-row tiles -- the 16-row tile's two stages leave no LDS for the three low-resolution windows)
+    if (L.mt == 64) return launch_hs_cfg<64, 1, 32, 8, EPI_ACT, 1>(a, B, s);
     return launch_hs_cfg<32, 2, 32, 8, EPI_ACT, 1>(a, B, s);
   }
   if (L.mt != 64 && L.mt != 32) {
@@ -226,9 +228,11 @@ bool conv_hs_can_fold_first(const ConvLayerHs& L, int G0, int B, int H, int W, c
          !fuse.outc_w && !fuse.dmask && !fuse.res && !fuse.ups_h;
 }
 
-// The fused bilinear x2 instance: 32 output channels, 32-pixel-wide blocks, the first two K-chunks from the skip source.
+// The fused bilinear x2 instances: 32 output channels (16-row tiles) or 64-cout tiles (8-row tiles), 32-pixel-wide blocks, the first two
+// K-chunks from the skip source.
 bool conv_hs_can_fuse_upsample(const ConvLayerHs& L, int G0, int G1, int H, int W) {
-  return L.mt == 32 && L.cout == 32 && G0 >= 4 && !(G0 & 1) && G1 >= 2 && !(G1 & 1) && W >= 32 && !(H & 1) && !(W & 1);
+  return ((L.mt == 32 && L.cout == 32) || (L.mt == 64 && L.cout % 64 == 0)) && G0 >= 4 && !(G0 & 1) && G1 >= 2 && !(G1 & 1) && W >= 32 &&
+         !(H & 1) && !(W & 1);
 }
 
 // ---- host-side weight packing -------------------------------------------------------------------------

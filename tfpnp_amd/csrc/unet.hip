@@ -565,7 +565,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
       // kernel, conv_hs_kernel.h UPS): no up-sampled tensor in HBM
       ConvHsFuse f_first;
       bool ups_fused = false;
-      if (ctx->opt_fuse_up) {
+      if (ctx->opt_fuse_up >= (l == 0 ? 1 : 2)) {      // 1: the full-resolution entry only, 2: every decoder entry
         const ConvLayerHsDev& D0 = ctx->conv_hs[15 + 3 * (3 - l)];
         ConvLayerHs L0;
         L0.cout = D0.cout;
