@@ -87,6 +87,8 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *      largest up-sampled tensor never exists in HBM.  Same arithmetic (bit-identical on the r5 build at every size tried,
  *      tools/ab_fuse_up.py; the test bound is 1e-6), forward 5.82 -> 5.76 ms at 48 x 256^2.  (conv_mode 0 has its own switch,
  *      "fp32_fuse_up", default 1: all four decoder entries interpolate inside the 8-wave Winograd kernel.)
+ *      2 = opt-in: the 64-cout decoder entries too (8-row-tile instance; bit-identical, measured 3 % SLOWER than their separate
+ *      up-sampling launches: profiles/r5_hs_fuse_up.md).
  *  "subbatch" (images per level-0 sub-batch, 0 = whole batch), "fuse_pool", "fuse_outc" (0/1): diagnostics. */
 int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value);
 int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value);

@@ -468,3 +468,34 @@ def test_fp32_launch_chains_are_bit_identical(unet_params):
         assert torch.equal(outs[0], outs[1])
     finally:
         ctx.set_option("fp32_chains", 2)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_solver_call_replays_from_a_hip_graph(unet_params, mode):
+    """A solver call launches on the caller's stream (+ side streams forked and joined by events for the launch chains) and, once its
+    arenas exist, neither allocates nor synchronises: it can be captured into a HIP graph (torch.cuda.CUDAGraph) and replayed,
+    bit-identical to the eager call.  (No speed-up at the bench's batch sizes -- the iteration is GPU-bound down to B = 6,
+    tools/graph_probe.py -- but integrators that capture their whole episode need the property.)"""
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    sol = ADMMSolver_CSMRI(UNetDenoiser2D(state_dict=unet_params, conv_mode=mode))
+    d = synth.make_csmri_batch(5, 64, 64, ratio=4, seed=44)
+    a = synth.make_actions(5)[0]
+    v0 = sol.reset({"x0": t(d["x0"])})
+    aux, par = (t(d["y0"]), t(d["mask"])), (t(a["sigma_d"]), t(a["mu"]))
+    ref = sol((v0, aux), par).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):          # warm-up on the capture stream's pool, as torch.cuda.graph asks
+        sol((v0, aux), par)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = sol((v0, aux), par)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)

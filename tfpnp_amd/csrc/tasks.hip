@@ -449,10 +449,11 @@ __global__ void psnr_final_kernel(const float* __restrict__ part, float* __restr
 // image rows) instead of a 64-pixel line segment (up to 45 rows).  The image is read from two zero-bordered copies made per call
 // (radon_pad_kernel: plain and transposed, RADON_PAD pixels of border): with the border standing in for "outside the image"
 // a sample needs no validity masks or clamped addresses (an outside pixel contributes v * w = +0, exactly the oracle's skipped
-// term), and its two horizontally adjacent pixels come from ONE 8-byte load -- 2 gathers and ~32 vector instructions per sample
-// instead of 4 and ~60.  History at 32 x 256^2 x 30 views: one lane per ray 302 us (r2), eight lanes per ray 192 + 6 us (r3a),
+// term); r5: the copies hold row pairs, so all four taps of a sample come from ONE 16-byte gather (r3 / r4: two 8-byte ones; r2: four
+// dwords).  History at 32 x 256^2 x 30 views: one lane per ray 302 us (r2), eight lanes per ray 192 + 6 us (r3a),
 // an LDS-staged 48 x 48 bounding box per 32 x 32-sample patch 269 us (the box of a rotated square is twice its area and its
-// fill costs more instructions than it saves), this form: see DESIGN.md.  The eight partial sums are combined by a fixed
+// fill costs more instructions than it saves), two 8-byte gathers per sample from padded copies 99 us (r3b / r4), one 16-byte gather from
+// row-pair copies 71 + 12 us (r5; the sample loop is bound by the texture-address path: half the vector instructions alone bought 7 %).  The eight partial sums are combined by a fixed
 // xor-butterfly, so results are deterministic (summation order differs from the oracle's sequential one: ~1e-7).
 constexpr int RADON_LPR = 8;   // lanes per ray
 constexpr int RADON_PAD = 4;   // zero border of the padded copies: the k interval is computed loosely (widened by 2 steps)
@@ -474,7 +475,7 @@ __global__ void radon_forward_kernel(const float* __restrict__ imgP, const float
   // that direction is closer to the y axis, so a wave's loads stay within few cache lines.
   const bool tr = fabsf(sn) > fabsf(c);
   const int RP = R + 2 * RADON_PAD;
-  const float* im = (tr ? imgPT : imgP) + (size_t)b * RP * RP + (size_t)RADON_PAD * RP + RADON_PAD;
+  const float* im = (tr ? imgPT : imgP) + 2 * (size_t)b * RP * RP;      // this image's padded row-pair copy
   const float sc = mulr(sp, c), ss = mulr(sp, sn);
   // Only samples with px, py in [-1, R) touch the image.  Both coordinates are affine in k, so the contributing k
   // form one interval; it is computed loosely (widened by 2: still inside the zero border) and a coordinate that does not
@@ -486,7 +487,8 @@ __global__ void radon_forward_kernel(const float* __restrict__ imgP, const float
         if (!(base >= -1.f && base < (float)R)) k1 = 0;
         return;
       }
-      const float ka = (-1.f - base) / slope + half, kb = ((float)R - base) / slope + half;
+      const float rs = __builtin_amdgcn_rcpf(slope);      // (1 ulp: the interval is widened by two steps below)
+      const float ka = (-1.f - base) * rs + half, kb = ((float)R - base) * rs + half;
       const float lo = fminf(ka, kb), hi = fmaxf(ka, kb);
       k0 = max(k0, (int)floorf(lo) - 2);
       k1 = min(k1, (int)ceilf(hi) + 3);
@@ -494,63 +496,63 @@ __global__ void radon_forward_kernel(const float* __restrict__ imgP, const float
     clip(sc + off, -sn);
     clip(ss + off, c);
   }
-  typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+  // r5: ONE 16-byte gather per sample instead of two 8-byte ones.  The loop is bound by the texture-address path, not by its
+  // instruction count (halving the vector instructions -- fma coordinates, v_cvt_flr / v_fract, lerps -- moved it 99 -> 92 us;
+  // halving the gathers 92 -> 71 us at config #4): the padded copies hold ROW PAIRS, element (row, col) = (P[row][col], P[row + 1][col]),
+  // so the four taps of a bilinear sample are one aligned-to-8 load.  (a, b) = (column, row) in the copy this ray reads -- plain:
+  // (x, y), transposed: (y, x); both coordinates are computed with the oracle's own operation sequence (s c - t sn + off,
+  // s sn + t c + off: same floor decisions as the oracle at the loud borders of the shape-sweep test), per-ray operands selected once.
+  const float a1 = tr ? ss : sc, a2 = tr ? -c : sn;      // pa = (a1 - t a2) + off
+  const float b1 = tr ? sc : ss, b2 = tr ? sn : -c;      // pb = (b1 - t b2) + off
+  const float* imo = im + 2 * ((size_t)RADON_PAD * RP + RADON_PAD);
   float acc = 0.f;
-#ifndef RADON_UNROLL
-#define RADON_UNROLL 2
-#endif
-#pragma unroll RADON_UNROLL
+  float t = subr((float)(k0 + dk), half);
   for (int k = k0 + dk; k < k1; k += RADON_LPR) {
-    const float t = subr((float)k, half);
-    const float px = addr(subr(sc, mulr(t, sn)), off);
-    const float py = addr(addr(ss, mulr(t, c)), off);
-    const float fx0 = floorf(px), fy0 = floorf(py);
-    const int x0 = (int)fx0, y0 = (int)fy0;
-    const float fx = subr(px, fx0), fy = subr(py, fy0);
-    const float wx0 = subr(1.f, fx), wy0 = subr(1.f, fy);
-    // plain copy: row y0 holds (v00, v01), row y0 + 1 (v10, v11); transposed copy: row x0 holds (v00, v10), row x0 + 1 (v01, v11)
-    const float* p = tr ? im + x0 * RP + y0 : im + y0 * RP + x0;
-    const f32x2u r0 = *reinterpret_cast<const f32x2u*>(p);
-    const f32x2u r1 = *reinterpret_cast<const f32x2u*>(p + RP);
-    const float v00 = r0[0], v01 = tr ? r1[0] : r0[1], v10 = tr ? r0[1] : r1[0], v11 = r1[1];
-    float sm = 0.f;
-    sm = addr(sm, mulr(v00, mulr(wx0, wy0)));
-    sm = addr(sm, mulr(v01, mulr(fx, wy0)));
-    sm = addr(sm, mulr(v10, mulr(wx0, fy)));
-    sm = addr(sm, mulr(v11, mulr(fx, fy)));
-    acc = addr(acc, sm);
+    const float pa = addr(subr(a1, mulr(t, a2)), off), pb = addr(subr(b1, mulr(t, b2)), off);
+    t += (float)RADON_LPR;                       // exact: integers + 0.5
+    int a0, b0;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(a0) : "v"(pa));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(b0) : "v"(pb));
+    const float fa = subr(pa, floorf(pa)), fb = subr(pb, floorf(pb));
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
+    const f32x4u r = *reinterpret_cast<const f32x4u*>(imo + 2 * (ptrdiff_t)(__mul24(b0, RP) + a0));
+    const float top = __builtin_fmaf(fa, r[2] - r[0], r[0]);
+    const float bot = __builtin_fmaf(fa, r[3] - r[1], r[1]);
+    acc += __builtin_fmaf(fb, bot - top, top);
   }
   acc = addr(acc, __shfl_xor(acc, 1, 64));
   acc = addr(acc, __shfl_xor(acc, 2, 64));
   acc = addr(acc, __shfl_xor(acc, 4, 64));
   if (live && dk == 0) sino[i] = sub ? subr(acc, sub[i]) : acc;
 }
-// [B][R][R] -> zero-bordered plain and transposed copies [B][R + 2 PAD][R + 2 PAD] (32 x 32 LDS tiles over the padded grid).
+// [B][R][R] -> zero-bordered plain and transposed ROW-PAIR copies [B][R + 2 PAD][R + 2 PAD][2]: element (row, col) = (P[row][col],
+// P[row + 1][col]) of the padded image P resp. its transpose (32 x 32 LDS tiles over the padded grid, one row / column of overlap).
 __global__ __launch_bounds__(256) void radon_pad_kernel(const float* __restrict__ img, size_t istride,
                                                         float* __restrict__ outP, float* __restrict__ outPT, int R) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[33][34];
   const int RP = R + 2 * RADON_PAD;
   const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;   // padded coordinates
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float* im = img + (size_t)b * istride;
-  float* oP = outP + (size_t)b * RP * RP;
-  float* oT = outPT + (size_t)b * RP * RP;
-  for (int r = ty; r < 32; r += 8) {
-    const int y = y0 + r - RADON_PAD, x = x0 + tx - RADON_PAD;
-    const float val = (y >= 0 && y < R && x >= 0 && x < R) ? im[(size_t)y * R + x] : 0.f;
-    tile[r][tx] = val;
-    if (y0 + r < RP && x0 + tx < RP) oP[(size_t)(y0 + r) * RP + x0 + tx] = val;
+  float2* oP = reinterpret_cast<float2*>(outP) + (size_t)b * RP * RP;
+  float2* oT = reinterpret_cast<float2*>(outPT) + (size_t)b * RP * RP;
+  for (int e = threadIdx.x; e < 33 * 33; e += 256) {      // 33 x 33: every element's lower / right neighbour too
+    const int r = e / 33, c = e - r * 33;
+    const int y = y0 + r - RADON_PAD, x = x0 + c - RADON_PAD;
+    tile[r][c] = (y >= 0 && y < R && x >= 0 && x < R) ? im[(size_t)y * R + x] : 0.f;
   }
   __syncthreads();
-  for (int r = ty; r < 32; r += 8)
-    if (x0 + r < RP && y0 + tx < RP) oT[(size_t)(x0 + r) * RP + y0 + tx] = tile[tx][r];
+  for (int r = ty; r < 32; r += 8) {
+    if (y0 + r < RP && x0 + tx < RP) oP[(size_t)(y0 + r) * RP + x0 + tx] = make_float2(tile[r][tx], tile[r + 1][tx]);
+    if (x0 + r < RP && y0 + tx < RP) oT[(size_t)(x0 + r) * RP + y0 + tx] = make_float2(tile[tx][r], tile[tx][r + 1]);
+  }
 }
-// padded copies: 2 * B * (R + 2 PAD)^2 floats at `pad`
-static size_t radon_pad_floats(int B, int R) { return 2 * (size_t)B * (R + 2 * RADON_PAD) * (R + 2 * RADON_PAD); }
+// padded row-pair copies (plain + transposed): 4 * B * (R + 2 PAD)^2 floats at `pad`
+static size_t radon_pad_floats(int B, int R) { return 4 * (size_t)B * (R + 2 * RADON_PAD) * (R + 2 * RADON_PAD); }
 static void launch_radon_forward(const float* img, size_t istride, const float* sub, float* sino, const float2* cs,
                                  float* pad, int R, int V, int det, int B, hipStream_t s) {
   const int RP = R + 2 * RADON_PAD;
-  float* padT = pad + (size_t)B * RP * RP;
+  float* padT = pad + 2 * (size_t)B * RP * RP;
   hipLaunchKernelGGL(radon_pad_kernel, dim3((RP + 31) / 32, (RP + 31) / 32, B), dim3(256), 0, s, img, istride, pad, padT, R);
   hipLaunchKernelGGL(radon_forward_kernel, dim3((unsigned)(((size_t)B * V * det * RADON_LPR + 255) / 256)), dim3(256), 0, s, pad,
                      padT, sub, sino, cs, R, V, det, B);
