@@ -453,21 +453,29 @@ __global__ void psnr_final_kernel(const float* __restrict__ part, float* __restr
 // dwords).  History at 32 x 256^2 x 30 views: one lane per ray 302 us (r2), eight lanes per ray 192 + 6 us (r3a),
 // an LDS-staged 48 x 48 bounding box per 32 x 32-sample patch 269 us (the box of a rotated square is twice its area and its
 // fill costs more instructions than it saves), two 8-byte gathers per sample from padded copies 99 us (r3b / r4), one 16-byte gather from
-// row-pair copies 71 + 12 us (r5; the sample loop is bound by the texture-address path: half the vector instructions alone bought 7 %).  The eight partial sums are combined by a fixed
+// row-pair copies 71 + 12 us, images dealt to XCDs by b % 8: 67 + 12 us (r5; the sample loop is bound by the texture-address path: half the
+// vector instructions alone bought 7 %).  The eight partial sums are combined by a fixed
 // xor-butterfly, so results are deterministic (summation order differs from the oracle's sequential one: ~1e-7).
 constexpr int RADON_LPR = 8;   // lanes per ray
 constexpr int RADON_PAD = 4;   // zero border of the padded copies: the k interval is computed loosely (widened by 2 steps)
 __global__ void radon_forward_kernel(const float* __restrict__ imgP, const float* __restrict__ imgPT,
                                      const float* __restrict__ sub, float* __restrict__ sino,
                                      const float2* __restrict__ cs, int R, int V, int det, int B) {
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t n_rays = (size_t)B * V * det;
+  // XCD-affine image walk (r5): workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2.  Image b is projected by
+  // workgroups of XCD b % 8 only, so its two padded copies (1.1 MiB at 256^2) are fetched into ONE L2 and stay there for all its views
+  // (in ray order over the whole batch every XCD touched every image: 132 MB fetched per launch for 36 MB of copies at config #4).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bpi = (int)(((size_t)V * det * RADON_LPR + blockDim.x - 1) / blockDim.x);      // workgroups per image
+  const int b = (slot / bpi) * 8 + xcd;
+  if (b >= B) return;
+  const size_t tid = (size_t)(slot % bpi) * blockDim.x + threadIdx.x;      // within the image
+  const size_t n_rays = (size_t)V * det;
   const bool live = (tid / RADON_LPR) < n_rays;
-  const size_t i = live ? tid / RADON_LPR : n_rays - 1;      // dead tail lanes shadow the last ray (shuffles stay uniform)
+  const size_t ir = live ? tid / RADON_LPR : n_rays - 1;      // dead tail lanes shadow the image's last ray (shuffles stay uniform)
+  const size_t i = (size_t)b * n_rays + ir;
   const int dk = (int)(tid % RADON_LPR);
-  const int s = (int)(i % det);
-  const int v = (int)((i / det) % V);
-  const int b = (int)(i / ((size_t)det * V));
+  const int s = (int)(ir % det);
+  const int v = (int)(ir / det);
   const float c = cs[v].x, sn = cs[v].y;
   const float half = (float)det / 2.f - 0.5f, off = (float)R / 2.f - 0.5f;
   const float sp = subr((float)s, half);
@@ -554,8 +562,9 @@ static void launch_radon_forward(const float* img, size_t istride, const float* 
   const int RP = R + 2 * RADON_PAD;
   float* padT = pad + 2 * (size_t)B * RP * RP;
   hipLaunchKernelGGL(radon_pad_kernel, dim3((RP + 31) / 32, (RP + 31) / 32, B), dim3(256), 0, s, img, istride, pad, padT, R);
-  hipLaunchKernelGGL(radon_forward_kernel, dim3((unsigned)(((size_t)B * V * det * RADON_LPR + 255) / 256)), dim3(256), 0, s, pad,
-                     padT, sub, sino, cs, R, V, det, B);
+  const size_t bpi = ((size_t)V * det * RADON_LPR + 255) / 256;      // workgroups per image; images dealt to XCDs by b % 8
+  hipLaunchKernelGGL(radon_forward_kernel, dim3((unsigned)(8 * (((size_t)B + 7) / 8) * bpi)), dim3(256), 0, s, pad, padT, sub, sino, cs,
+                     R, V, det, B);
 }
 // Pixel-driven backprojection: one thread per pixel, linear interpolation along the detector.
 __global__ void radon_backproject_kernel(const float* __restrict__ sino, float* __restrict__ img,
