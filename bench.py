@@ -453,6 +453,10 @@ def fp32_mode(params, data, actions, dev, B, H, W, steps, warmup):
     sigma = actions[-1]["sigma_d"][:, -1].contiguous()
     rl = roofline_fp32(den, dev, x, sigma)
     rl["power"] = power
+    if power and power.get("gfx_clk_mhz_avg"):
+        # r5: as two launch chains this family reaches the package power limit too (1350 W, ~2.17 GHz): the fp32-MFMA peak at the clock the
+        # timed region actually held (nominal 2400 MHz), like the half-split roofline's field of the same name
+        rl["frac_of_peak_at_measured_clock"] = rl["achieved"] / (rl["peak"] * power["gfx_clk_mhz_avg"] / 2400.0)
     # accuracy gate of this leg (the headline's gate is the CPU oracle, cpu_baseline): one forward of both families on the episode's final
     # images -- a timing of wrong results is not a measurement (r5: an LDS overlap in the 32-cout tile produced NaNs at full batch only)
     with torch.no_grad():

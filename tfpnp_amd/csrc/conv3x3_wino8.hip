@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
   using C = Cfg8<CT>;
   constexpr int CK = C::CK, HALVES = C::HALVES, KS = C::KS, RS = C::RS, NSTG = C::NSTG, NPOS = C::NPOS;
   constexpr int TX = C::TX, NT = C::NT, RW = C::RW, RPX = C::RPX, RPXL = C::RPXL;
-  constexpr int RAW_ELEMS = C::RAW_ELEMS, RAW_BYTES = C::RAW_BYTES, RAW_PER_WAVE = C::RAW_PER_WAVE;
+  constexpr int RAW_BYTES = C::RAW_BYTES, RAW_PER_WAVE = C::RAW_PER_WAVE;
   constexpr int UQ = C::UQ, USTG = C::USTG, NUW = C::NUW, VROW = C::VROW, VSTG = C::VSTG;
   constexpr int OFF_U = C::OFF_U, OFF_V = C::OFF_V, OFF_RAW = C::OFF_RAW, BAR = C::BAR;
   extern __shared__ __attribute__((aligned(16))) char lds[];
