@@ -1,7 +1,7 @@
 """Stress of the threading / stream contract (tests/test_gpu_edge.py::test_two_contexts_from_two_threads_and_side_streams): two
 host threads drive two contexts on side streams; every result is compared with the serial one; prints mismatch statistics."""
 import os, sys, threading
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tfpnp_amd import synth
 from tfpnp_amd.pnp import UNetDenoiser2D
