@@ -475,7 +475,7 @@ def test_solver_call_replays_from_a_hip_graph(unet_params, mode):
     """A solver call launches on the caller's stream (+ side streams forked and joined by events for the launch chains) and, once its
     arenas exist, neither allocates nor synchronises: it can be captured into a HIP graph (torch.cuda.CUDAGraph) and replayed,
     bit-identical to the eager call.  (No speed-up at the bench's batch sizes -- the iteration is GPU-bound down to B = 6,
-    tools/graph_probe.py -- but integrators that capture their whole episode need the property.)"""
+    tools/graph_capture.py -- but integrators that capture their whole episode need the property.)"""
     from tfpnp_amd.pnp import UNetDenoiser2D
     from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
