@@ -430,7 +430,8 @@ def test_radon_forward_shape_sweep_vs_oracle():
     from oracle import pnp_oracle as O
     from tfpnp_amd.utils import transforms as T
     rs = np.random.RandomState(0)
-    for (R, V, B) in [(16, 1, 1), (17, 3, 2), (31, 7, 1), (33, 30, 2), (50, 11, 3), (97, 13, 1), (128, 60, 1), (200, 9, 1), (300, 5, 1)]:
+    for (R, V, B) in [(16, 1, 1), (17, 3, 2), (31, 7, 1), (33, 30, 2), (50, 11, 3), (97, 13, 1), (128, 60, 1), (200, 9, 1), (300, 5, 1),
+                      (40, 6, 11), (24, 4, 9)]:      # r5: images are dealt to XCDs by b % 8 -- batches that are no multiple of 8
         img = rs.rand(B, 1, R, R).astype(np.float32)
         img[:, :, :2, :], img[:, :, -2:, :], img[:, :, :, :2], img[:, :, :, -2:] = 5.0, -3.0, 7.0, -2.0
         angles, det = O.radon_geometry(R, V)
