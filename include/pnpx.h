@@ -80,6 +80,11 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *  "chains" (default 0 = automatic): run a denoiser forward as n independent launch chains over slices of the batch on
  *      side streams (pays for small batches whose launches cannot fill the chip; bit-identical per image).
  *  "fft_affine" (default 1), "fft_tile" (default 0 = 1024 points): XCD-affine image mapping and tile size of the FFT passes.
+ *  "fft_fast" (default 1): N = 256 lines on the register-radix-16 kernels (0 = the generic Stockham passes; same results to rounding).
+ *  "fuse_first" (default 1): the half-split family's first convolution reads the fp32 image and the noise level directly (no padded
+ *      two-channel input tensor); 0 = separate input preparation + the generic kernel (bit-identical).
+ *  "policy_s2_hs" (default 1): the policy actor's stem and stride-2 stage entries on the sparse-tap half-split instances over space-to-depth
+ *      tensors (0 = the fp32 space-to-depth convolution kernel of policy_conv.hip for those layers).
  *  "fold_first" (default 0): 1 = the network's first convolution is evaluated inside the tile loader of the second one
  *      (its output tensor is neither written nor read; bit-identical, time-neutral).
  *  "fuse_up" (default 1 since r5): 1 = the full-resolution decoder entry (96 -> 32 channels) up-samples its low-resolution source

@@ -142,3 +142,15 @@ def test_fused_solvers_refuse_foreign_denoisers_and_prox_overrides_clearly():
 
     with pytest.raises(NotImplementedError, match="overrides prox_mapping"):
         Mine(Plain())((v[:, :1], aux), par)
+
+
+def test_every_context_option_is_documented_in_the_header():
+    """pnpx_ctx_set_option's keys (csrc/api.hip) and the option list in include/pnpx.h must not drift apart."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api = open(os.path.join(root, "tfpnp_amd", "csrc", "api.hip")).read()
+    header = open(os.path.join(root, "include", "pnpx.h")).read()
+    keys = sorted(set(re.findall(r'is\("([a-z0-9_]+)"\)', api)))
+    assert len(keys) >= 20
+    missing = [k for k in keys if f'"{k}"' not in header]
+    assert not missing, f"options accepted by pnpx_ctx_set_option but not described in include/pnpx.h: {missing}"
