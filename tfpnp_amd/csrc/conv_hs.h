@@ -29,6 +29,7 @@ inline HsFastDiv hs_fastdiv(unsigned d) {
 
 struct ConvHsArgs {
   int plain_walk = 0;   // set by the launcher: one tile per workgroup, tile j = blockIdx.x (launches that fit one round)
+  int share = 1;        // launch chains running side by side (ConvHsFuse::share): the launch table plans for 256 / share workgroups
   const char* in0;   // HS8 tensor, G0 groups of 8 channels
   const char* in1;   // second source (channel concat), G1 groups
   const char* wpk;
@@ -106,6 +107,9 @@ struct ConvHsFuse {       // optional fused work
   const float* first_zero = nullptr;
   int first_sigma_stride = 0;
   float first_slope = 0.2f;
+  // r5: number of independent launch chains the caller runs side by side (unet.hip launch_chains): this launch shares the 256 CUs with
+  // share - 1 launches of the same shape, and the launch table picks the tile height for 256 / share workgroups (same bits either way)
+  int share = 1;
 };
 // true when launch_conv_hs will honour ConvHsFuse::first_x for this layer / geometry (else the caller runs conv_first)
 bool conv_hs_can_fold_first(const ConvLayerHs& L, int G0, int B, int H, int W, const ConvHsFuse& fuse);

@@ -59,22 +59,42 @@ HsChoice hs_choose(int mt, const ConvHsArgs& a, int B) {
     const int th = rows * (32 / mbw);
     return (long long)a.nct * ((a.W + mbw - 1) / mbw) * ((a.H + th - 1) / th) * B;
   };
+  // r5: beside `share - 1` other launch chains (small and medium batches, unet.hip launch_chains) the chains drift out of phase and their
+  // workgroups pack: a launch then costs its FRACTION of a round of 256 / share workgroups (at least one tile time), not a whole number
+  // of rounds of 256 -- and a tile's two waves per SIMD pay even in a one-tile workgroup (one wave's loads and epilogue hide behind the
+  // other's MFMAs while the other chain keeps the remaining CUs busy).  Measured against the lone-launch table (tools/_run_rule.sh, wall
+  // clock of whole forwards): B = 6 -1.7 %, 10 -4.0 %, 12 -4.7 %, 18 -6.1 %, 24 -6.3 %, 38 -8.3 %, 44 -6.1 %; whole rounds of 128
+  // workgroups instead (rule 1) lose 2.8 % at B = 10 / 12.  A lone launch (share = 1: B <= 4, full rounds, B >= 47) plans as before.
+  const int share = a.share > 1 ? a.share : 1;
+  int rule = 6;      // bit 1: two waves per SIMD beside another chain; bit 2: fractional rounds of 256 / share; bit 0 (experiment): whole rounds of 256 / share
+#ifdef PNPX_TUNING
+  if (const char* e = getenv("PNPX_HS_RULE")) rule = atoi(e);
+#endif
+  const long long budget = (rule & 1) ? 256 / share : 256;
+  const bool smooth = (rule & 4) != 0 && share > 1;
+  auto rounds = [&](long long nt) {
+    if (smooth) {
+      const double r = (double)nt * share / 256.0;
+      return r < 1.0 ? 1.0 : r;
+    }
+    return (double)((nt + budget - 1) / budget);
+  };
   HsChoice c{4, 4};
   double best = 1e30;
   for (int rows : {16, 8, 4}) {
-    const long long nt = blocks(rows);
-    const double cost = (double)((nt + 255) / 256) * (rows / 4 + 0.3);
+    const double cost = rounds(blocks(rows)) * (rows / 4 + 0.3);
     if (cost < best * 0.999) {
       best = cost;
       c.nbw = rows / 4;
     }
   }
   if (mt == 32 && a.w_mt == 32) {   // 32-cout layers: 16-row tiles unless a half-empty last round makes 8-row tiles cheaper
-    const double c16 = (double)((blocks(16) + 255) / 256) * 4.3, c8 = (double)((blocks(8) + 255) / 256) * 2.3;
+    const double c16 = rounds(blocks(16)) * 4.3, c8 = rounds(blocks(8)) * 2.3;
     c.nbw = (c8 < 0.9 * c16) ? 2 : 4;
   }
-  // two waves per SIMD (same tile, half the blocks per wave) once every workgroup has at least two tiles to walk
-  if (c.nbw >= 2 && blocks(4 * c.nbw) >= 512 && !(a.pool_out && c.nbw < 4)) c = HsChoice{c.nbw / 2, 8};
+  // two waves per SIMD (same tile, half the blocks per wave) once every workgroup has at least two tiles to walk -- or, beside another
+  // chain, always: one wave's loads and epilogue then hide behind the other's MFMAs even in a one-tile workgroup
+  if (c.nbw >= 2 && (blocks(4 * c.nbw) >= 512 || (share > 1 && (rule & 2))) && !(a.pool_out && c.nbw < 4)) c = HsChoice{c.nbw / 2, 8};
 #ifdef PNPX_TUNING
   tuning_override(mt, a.W, &c);
 #endif
@@ -130,6 +150,7 @@ int launch_conv_hs(const ConvLayerHs& L, const char* in0, int G0, const char* in
   a.trace = nullptr;
   a.wgt = nullptr;
   a.abl = 0;
+  a.share = fuse.share;
 #ifdef PNPX_TUNING
   if (const char* e = getenv("PNPX_HS_ABL")) a.abl = atoi(e);
 #endif

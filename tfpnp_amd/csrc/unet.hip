@@ -443,7 +443,8 @@ inline dim3 g1d(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 // around.  24 stays the default.  Deeper levels always run the whole batch.
 static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, const float* x, const float* sigma,
                            int sigma_stride, float* out, float* out_pre, int B, int H, int W, hipStream_t s,
-                           Recorder& rec, bool keep_all, int b_base = 0) {
+                           Recorder& rec, bool keep_all, int b_base = 0, int share = 1) {
+  // share: launch chains running side by side (this call is one of them): passed to the launch table.
   // b_base: the B images of this call are images b_base .. b_base + B - 1 of the arena (x / sigma / out already point at
   // the first of them): two halves of a batch can run as independent launch chains on two streams (dual_stream)
   char* A = static_cast<char*>(ar.buf.p);
@@ -486,6 +487,7 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
     ConvHsFuse fz = fuse;
     fz.range_flag = range_flag;
     fz.wreg = ctx->opt_wreg;
+    fz.share = share;
     PNPX_TRY(launch_conv_hs(Lh, at(i0, b0), i0.C / 8, i1 ? at(*i1, b0) : nullptr, i1 ? i1->C / 8 : 0, at(o, b0), nb, o.H,
                             o.W, fz, s));
     return rec.mark("conv3x3", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * nb);
@@ -826,7 +828,7 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     return fan_out_chains(ctx, chains, B, s, [&](int lo, int hi, hipStream_t st) -> int {
       Recorder none{nullptr, st};
       return unet_forward_hs(ctx, ar, P, x + lo * px, sigma + (size_t)lo * sigma_stride, sigma_stride, out + lo * px,
-                             out_pre ? out_pre + lo * px : nullptr, hi - lo, H, W, st, none, keep_all, lo);
+                             out_pre ? out_pre + lo * px : nullptr, hi - lo, H, W, st, none, keep_all, lo, chains);
     });
   }
   if (hs) return unet_forward_hs(ctx, ar, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec, keep_all);
