@@ -753,13 +753,13 @@ static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, con
 int launch_chains(const pnpx_ctx* ctx, int B, int H, int W) {
   int n = ctx->opt_chains;
   if (n == 0) {
-    // automatic: two chains where they were measured to pay (tools/chains_table.py, every batch size 1..48 at 256^2,
-    // profiles/r3_chains_table.txt): a second chain fills the drain of launches whose last round is partly empty -- up to -12 %
-    // (B = 17, 33), -7 % at B = 6 / 9 / 10, -2 % at B = 24; it costs 2..10 % where one chain already fills its rounds (B <= 4,
-    // B = 7, 8, 15, 16) and changes nothing from B = 47 up (power-limited).  q = batch in 256 x 256 images.
+    // automatic: two chains where they were measured to pay (tools/chains_table.py, every batch size 1..48 at 256^2).  r3 (lone-launch
+    // tile shapes, profiles/r3_chains_table.txt): only where a launch's last round was partly empty, and nothing from B = 47 up.  r5: the
+    // launch table plans for the chain running beside it (conv_hs.hip hs_choose, ConvHsFuse::share), and two chains pay from B = 5 up
+    // (profiles/r5_chains_table_hs.txt: -4 % at B = 6, -13 % at 9-11 / 17-19 / 33-35, -5.5 % at B = 48, -5 % at 64, -3 % at 96; B = 8
+    // +1 %, B <= 4 +2-3 % except 3).  q = batch in 256 x 256 images.
     const long long q = (long long)B * H * W / (256 * 256);
-    const bool full_rounds = q <= 16 && (q % 8 == 7 || q % 8 == 0);
-    n = (q >= 5 && q <= 46 && !full_rounds) ? 2 : 1;
+    n = (q >= 5 && q != 8) ? 2 : 1;
   }
   if (n > 8) n = 8;
   return n > B ? B : (n < 1 ? 1 : n);
