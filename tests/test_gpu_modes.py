@@ -457,6 +457,20 @@ def test_fp32_launch_chains_are_bit_identical(unet_params):
             ctx.set_option("fp32_chains", 2)
             gx2, gs2 = ops.unet_denoise_backward(ctx, x, s.reshape(-1), g)
             assert torch.equal(gx0, gx2) and torch.equal(gs0, gs2), (B, H, W)
+        # r5: the half-split family's VJP slices its adjoint chain the same way (option chains; the gradient scale is the whole batch's)
+        hden = UNetDenoiser2D(state_dict=unet_params, conv_mode=1)
+        hctx = hden.context(dev())
+        for (B, H, W) in [(5, 64, 64), (7, 128, 96), (3, 50, 39)]:
+            x, s = denoiser_inputs(B, H, W, 600 + B)
+            x, s = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
+            g = torch.from_numpy(np.random.default_rng(B).standard_normal((B, 1, H, W)).astype(np.float32)).to(dev())
+            res = []
+            for c in (1, 2, 3):
+                hctx.set_option("chains", c)
+                res.append([v.clone() for v in ops.unet_denoise_backward(hctx, x, s.reshape(-1), g)] + [hden(x, s).clone()])
+            hctx.set_option("chains", 0)
+            for r in res[1:]:
+                assert all(torch.equal(u, v) for u, v in zip(r, res[0])), (B, H, W)
         d = synth.make_csmri_batch(5, 64, 64, ratio=4, seed=43)
         a = synth.make_actions(5)[0]
         sol = ADMMSolver_CSMRI(den)

@@ -323,6 +323,7 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
   unsigned* const range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
   const std::vector<LayerDesc> L = dru_layers(N.nb);
 
+  const int chains = keep_mids ? 1 : launch_chains(ctx, B, H, W);      // (the launch table plans for the chains side by side: f.share)
   // The forward over images b0 .. b0 + B - 1 of the arena on stream s (x / sigma / out already point at the first of them): every
   // tensor is [image][group][h + 2][w + 2] records, so a slice of the batch is a contiguous piece of each -- independent launch
   // chains over slices run side by side on side streams exactly as for the UNet (unet.hip: launch_chains; bit-identical per image).
@@ -362,6 +363,7 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
     f.range_flag = range_flag;
     f.wreg = 0;
     f.taps = N.taps[li];
+    f.share = chains;
     if (tail) {
       f.outc_w = N.e0 + 32 * (sh / 4);   // selects channel 0 and multiplies the 2^-sh of the head back
       f.outc_b = N.e0 + 5 * 32;          // a zero
@@ -433,7 +435,6 @@ int drunet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_
   return PNPX_OK;
   };
 
-  const int chains = keep_mids ? 1 : launch_chains(ctx, B, H, W);
   if (chains <= 1) return run(0, B, x, sigma, out, out_pre, s);
   const size_t px = (size_t)H * W;
   return fan_out_chains(ctx, chains, B, s, [&](int lo, int hi, hipStream_t st) -> int {

@@ -452,13 +452,18 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
 
   if (hs) {
     // ---- half-split backward: HS8 gradients, f16x3 MFMA adjoint convolutions
-    auto grec = [&](const Act& d) { return reinterpret_cast<HsRec*>(GA + d.off); };
-    auto frec = [&](const Act& d) { return reinterpret_cast<const HsRec*>(FA + d.off); };
     PNPX_HIP(hipMemsetAsync(gmax_bits, 0, sizeof(unsigned), s));
     hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, s, grad_out, npix, gmax_bits);
     hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, s, gmax_bits, gscale);
-    hipLaunchKernelGGL(outc_bwd_hs_kernel, g1(npix * 4), dim3(256), 0, s, grad_out, pre, ctx->outc_w, frec(F.y[0]),
-                       grec(G.y[0]), g_res, gscale, H, W, npix * 4);
+    // the adjoint chain over images lo .. lo + B - 1 on stream s: the whole batch, or one of two launch chains (r5: like the forward's,
+    // unet.hip launch_chains; the launch table plans for the chain beside it: ConvHsFuse::share).  The gradient scale above is the whole
+    // batch's, so per-image results do not depend on the slicing.
+    auto run_hs = [&](int lo, int B, hipStream_t s, int share) -> int {
+    const size_t npix = (size_t)B * H * W, px0 = (size_t)lo * H * W;
+    auto grec = [&](const Act& d) { return reinterpret_cast<HsRec*>(GA + d.off + (size_t)lo * act_bytes_per_image(CONV_HS, d.C, d.H, d.W)); };
+    auto frec = [&](const Act& d) { return reinterpret_cast<const HsRec*>(FA + d.off + (size_t)lo * act_bytes_per_image(CONV_HS, d.C, d.H, d.W)); };
+    hipLaunchKernelGGL(outc_bwd_hs_kernel, g1(npix * 4), dim3(256), 0, s, grad_out + px0, pre + px0, ctx->outc_w, frec(F.y[0]),
+                       grec(G.y[0]), g_res + px0, gscale, H, W, npix * 4);
     PNPX_LAUNCH_CHECK();
     auto convH = [&](int li, const Act& gin, const Act& gout, const Act* saved) -> int {
       const ConvLayerHsDev& D = ctx->conv_hs_bwd[li];
@@ -476,10 +481,12 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
         return PNPX_ERR_SHAPE;
       }
       ConvHsFuse f;
-      f.dmask = saved ? FA + saved->off : nullptr;
+      f.dmask = saved ? FA + saved->off + (size_t)lo * act_bytes_per_image(CONV_HS, saved->C, saved->H, saved->W) : nullptr;
+      f.share = share;
       f.slope = saved ? 0.2f : 1.0f;
       f.range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
-      return launch_conv_hs(Lh, GA + gin.off, gin.C / 8, nullptr, 0, GA + gout.off, B, gout.H, gout.W, f, s);
+      return launch_conv_hs(Lh, reinterpret_cast<const char*>(grec(gin)), gin.C / 8, nullptr, 0, reinterpret_cast<char*>(grec(gout)), B, gout.H,
+                            gout.W, f, s);
     };
     for (int l = 0; l <= 3; ++l) {
       const int li = 15 + 3 * (3 - l);
@@ -507,12 +514,16 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
       PNPX_TRY(convH(3 * l + 1, G.b[l], G.a[l], &F.a[l]));
       PNPX_TRY(convH(3 * l, G.a[l], l == 0 ? G.in0 : G.p[l], nullptr));
     }
-    hipLaunchKernelGGL(input_grad_hs_kernel, dim3(SIG_CHUNKS, B), dim3(256), 0, s, grec(G.in0), g_res, grad_x, part,
-                       gscale, H, W);
+    hipLaunchKernelGGL(input_grad_hs_kernel, dim3(SIG_CHUNKS, B), dim3(256), 0, s, grec(G.in0), g_res + px0, grad_x + px0,
+                       part + (size_t)lo * SIG_CHUNKS, gscale, H, W);
     PNPX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sigma_grad_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, part, grad_sigma, B);
+    hipLaunchKernelGGL(sigma_grad_final_kernel, dim3((B + 63) / 64), dim3(64), 0, s, part + (size_t)lo * SIG_CHUNKS, grad_sigma + lo, B);
     PNPX_LAUNCH_CHECK();
     return PNPX_OK;
+    };
+    const int chains = launch_chains(ctx, B, H, W);
+    if (chains <= 1) return run_hs(0, B, s, 1);
+    return fan_out_chains(ctx, chains, B, s, [&](int lo, int hi, hipStream_t st) -> int { return run_hs(lo, hi - lo, st, chains); });
   }
 
   // 3..6 over images lo .. lo + B - 1 on stream s: the whole batch, or one of two launch chains (r5, option fp32_chains; the fp32 family is
