@@ -81,8 +81,12 @@ HsChoice hs_choose(int mt, const ConvHsArgs& a, int B) {
   };
   HsChoice c{4, 4};
   double best = 1e30;
+  // (half tiles -- 32 couts over a 64-cout packing, deep levels of small batches -- with one block per wave are bound by the LDS-DMA
+  // latency of a 27-MFMA step, not by its MFMAs: beside another chain a 4-row tile costs what an 8-row tile costs.  32-pixel-wide
+  // blocks only: at the 16-pixel level the 8-row tile measured slower.  tools/_run_tune_small.sh 6: -2.3 % per forward at B = 6.)
+  const bool latency_bound_rows4 = share > 1 && mt == 32 && a.w_mt == 64 && mbw == 32;
   for (int rows : {16, 8, 4}) {
-    const double cost = rounds(blocks(rows)) * (rows / 4 + 0.3);
+    const double cost = rounds(blocks(rows)) * ((rows == 4 && latency_bound_rows4 ? 2 : rows / 4) + 0.3);
     if (cost < best * 0.999) {
       best = cost;
       c.nbw = rows / 4;
