@@ -77,8 +77,10 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *      re-compute.  "train_cache_release" (any value): give the ring's memory back now, budget unchanged.
  *  "wreg" (default 2): weights-in-registers instances of the 32 -> 32 channel convolutions (0 = generic kernel, 1 = four
  *      waves x four pixel blocks, 2 = eight waves x two pixel blocks); bit-identical results.
- *  "chains" (default 0 = automatic): run a denoiser forward as n independent launch chains over slices of the batch on
- *      side streams (pays for small batches whose launches cannot fill the chip; bit-identical per image).
+ *  "chains" (default 0 = automatic): run a denoiser forward (and the half-split VJP's adjoint chain) as n independent launch chains over
+ *      slices of the batch on side streams; the convolution launch table picks its tile shapes for the chains running side by side.
+ *      Automatic (r5): two chains from 5 images of 256 x 256 up (-4 % at B = 6, -13 % at 9-11, -6 % at 48; profiles/r5_chains_table_hs.txt).
+ *      Bit-identical per image for every n.
  *  "fft_affine" (default 1), "fft_tile" (default 0 = 1024 points): XCD-affine image mapping and tile size of the FFT passes.
  *  "fft_fast" (default 1): N = 256 lines on the register-radix-16 kernels (0 = the generic Stockham passes; same results to rounding).
  *  "fuse_first" (default 1): the half-split family's first convolution reads the fp32 image and the noise level directly (no padded
