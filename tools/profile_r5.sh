@@ -27,6 +27,11 @@ PY
   $R --stats -d $O/bench -o bench -- python bench.py $BOPT > $O/bench.log 2>&1
   python tools/rocpd_stats.py $O/bench/bench_results.db > $O/r5_bench_kernel_stats.md
   grep '^{' $O/bench.log | tail -1 > $O/r5_bench_profiled.json
+  # the same half-split bench with ONE launch chain: with two (the default since r5) kernels of the two chains overlap pairwise and their
+  # durations sum to about twice the wall time; this trace is the serial per-kernel view
+  $R --stats -d $O/bench1 -o bench -- python bench.py $BOPT --ctx-option chains=1 > $O/bench1.log 2>&1
+  python tools/rocpd_stats.py $O/bench1/bench_results.db > $O/r5_bench_kernel_stats_chains1.md
+  grep '^{' $O/bench1.log | tail -1 > $O/r5_bench_profiled_chains1.json
   $R --stats -d $O/bench32 -o bench -- python bench.py $BOPT --ctx-option conv_mode=0 > $O/bench32.log 2>&1
   python tools/rocpd_stats.py $O/bench32/bench_results.db > $O/r5_bench_kernel_stats_fp32.md
   grep '^{' $O/bench32.log | tail -1 > $O/r5_bench_profiled_fp32.json
