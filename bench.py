@@ -376,7 +376,8 @@ def roofline(den, dev, x, sigma):
     return {
         "bound": "mfma",
         "kernel": "conv_hs_kernel: the 27 3x3 convolutions of one denoiser forward (half-split f16 MFMA, 3 MFMAs per fp32 "
-                  "product; 33 launches at B=48 with two level-0 sub-batches, the K=18 first layer on the vector ALU included)",
+                  "product; since r5 two launch chains of 30 launches each over halves of the batch at B=48, the K=18 first layer on the vector ALU "
+                  "included)",
         "achieved": achieved,
         "peak": PEAK_HS_TFLOPS,
         "unit": "TFLOP/s",
@@ -396,7 +397,7 @@ def roofline(den, dev, x, sigma):
         "denoiser_ms_per_forward": whole_ms,
         "timing": "one HIP-event pair around 12 back-to-back production forwards on the episode's final images; per-kernel "
                   "split = shares of a per-launch-event pass scaled to it (that pass alone sums to "
-                  f"{profiled_ms:.3f} ms: launch chains serialised)",
+                  f"{profiled_ms:.3f} ms: ONE chain, launches serialised; the production forward overlaps two chains)",
         "ms_by_kernel": {k: whole_ms * v for k, v in shares.items()},
     }
 
