@@ -62,7 +62,7 @@ HsChoice hs_choose(int mt, const ConvHsArgs& a, int B) {
   // r5: beside `share - 1` other launch chains (small and medium batches, unet.hip launch_chains) the chains drift out of phase and their
   // workgroups pack: a launch then costs its FRACTION of a round of 256 / share workgroups (at least one tile time), not a whole number
   // of rounds of 256 -- and a tile's two waves per SIMD pay even in a one-tile workgroup (one wave's loads and epilogue hide behind the
-  // other's MFMAs while the other chain keeps the remaining CUs busy).  Measured against the lone-launch table (tools/_run_rule.sh, wall
+  // other's MFMAs while the other chain keeps the remaining CUs busy).  Measured against the lone-launch table (tools/tune_rule.sh, wall
   // clock of whole forwards): B = 6 -1.7 %, 10 -4.0 %, 12 -4.7 %, 18 -6.1 %, 24 -6.3 %, 38 -8.3 %, 44 -6.1 %; whole rounds of 128
   // workgroups instead (rule 1) lose 2.8 % at B = 10 / 12.  A lone launch (share = 1: B <= 4, full rounds, B >= 47) plans as before.
   const int share = a.share > 1 ? a.share : 1;
@@ -83,7 +83,7 @@ HsChoice hs_choose(int mt, const ConvHsArgs& a, int B) {
   double best = 1e30;
   // (half tiles -- 32 couts over a 64-cout packing, deep levels of small batches -- with one block per wave are bound by the LDS-DMA
   // latency of a 27-MFMA step, not by its MFMAs: beside another chain a 4-row tile costs what an 8-row tile costs.  32-pixel-wide
-  // blocks only: at the 16-pixel level the 8-row tile measured slower.  tools/_run_tune_small.sh 6: -2.3 % per forward at B = 6.)
+  // blocks only: at the 16-pixel level the 8-row tile measured slower.  tools/tune_small.sh 6: -2.3 % per forward at B = 6.)
   const bool latency_bound_rows4 = share > 1 && mt == 32 && a.w_mt == 64 && mbw == 32;
   for (int rows : {16, 8, 4}) {
     const double cost = rounds(blocks(rows)) * ((rows == 4 && latency_bound_rows4 ? 2 : rows / 4) + 0.3);
