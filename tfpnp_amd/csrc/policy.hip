@@ -586,6 +586,19 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
   float* A = static_cast<float*>(N.arena.p);
   const bool all_hs = ctx->opt_policy_s2_hs && (N.stem_hs.cin_pad % 16 == 0);   // every activation is an HS8 tensor (the default)
 
+  // option "chains": n = exactly n chains (when B >= n); 0 = automatic, from the table of every batch size 1..48 at 256 x 256 with
+  // one and two chains (DESIGN.md section 9): two chains pay between the round boundaries of the 8 x 8 / 16 x 16 stages -- B = 9..15
+  // (-3..-6 %), 17..24 (-2..-7 %), 33..48 (-8..-15 %) -- and cost up to 12 % elsewhere (B = 32).  q = batch in 256 x 256 images.
+  int chains = 1;
+  if (all_hs) {
+    if (ctx->opt_chains != 0) {
+      chains = launch_chains(ctx, B, H, W);
+    } else {
+      const long long q = (long long)B * H * W / (256 * 256);
+      chains = ((q >= 9 && q <= 15) || (q >= 17 && q <= 24) || q >= 33) ? 2 : 1;
+    }
+    if (chains > B) chains = B;
+  }
   // The forward over observations b0 .. b0 + B - 1 (ob / probs / det already point at the first of them) on stream s.  With every
   // activation an HS8 tensor [image][group][h + 2][w + 2], a slice of the batch is a contiguous piece of each: slices run as
   // independent launch chains on side streams like the denoisers' (unet.hip: launch_chains; bit-identical per image) -- the deep
@@ -629,6 +642,7 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
     f.slope = 0.f;
     f.taps = 0x01B;
     f.wreg = 0;
+    f.share = chains;
     f.range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
     PNPX_TRY(launch_conv_hs(Lh, hsc0(P.ob_hs), N.stem_hs.cin_pad / 8, nullptr, 0, hsc0(P.stem_o), B, H / 2, W / 2, f, s));
     const size_t n2 = (size_t)B * 4 * 8 * (H / 4) * (W / 4) * 2;
@@ -659,6 +673,7 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
     Lh.inv_scale = D.inv_scale;
     ConvHsFuse f;
     f.slope = 0.f;                          // ReLU
+    f.share = chains;
     f.res = res ? hsc(*res) : nullptr;
     f.range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
     return launch_conv_hs(Lh, hsc(in), in.C / 8, nullptr, 0, hsc(out), B, h, w, f, s);
@@ -691,6 +706,7 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
         ConvHsFuse f;
         f.slope = k == 0 ? 0.f : 1.f;
         f.taps = k == 0 ? 0x01B : 0x010;
+        f.share = chains;
         f.in0_groups = s2in.C / 8;
         f.wreg = 0;
         f.range_flag = ctx->opt_range_guard ? ctx->range_flag_dev : nullptr;
@@ -720,19 +736,6 @@ int policy_forward(pnpx_ctx* ctx, const float* ob, float* probs, float* det, int
   return PNPX_OK;
   };
 
-  // option "chains": n = exactly n chains (when B >= n); 0 = automatic, from the table of every batch size 1..48 at 256 x 256 with
-  // one and two chains (DESIGN.md section 9): two chains pay between the round boundaries of the 8 x 8 / 16 x 16 stages -- B = 9..15
-  // (-3..-6 %), 17..24 (-2..-7 %), 33..48 (-8..-15 %) -- and cost up to 12 % elsewhere (B = 32).  q = batch in 256 x 256 images.
-  int chains = 1;
-  if (all_hs) {
-    if (ctx->opt_chains != 0) {
-      chains = launch_chains(ctx, B, H, W);
-    } else {
-      const long long q = (long long)B * H * W / (256 * 256);
-      chains = ((q >= 9 && q <= 15) || (q >= 17 && q <= 24) || q >= 33) ? 2 : 1;
-    }
-    if (chains > B) chains = B;
-  }
   if (chains <= 1) return run(0, B, ob, probs, det, s);
   return fan_out_chains(ctx, chains, B, s, [&](int lo, int hi, hipStream_t st) -> int {
     return run(lo, hi - lo, ob + (size_t)lo * N.num_inputs * H * W, probs + (size_t)lo * 2, det + (size_t)lo * N.n_det, st);
