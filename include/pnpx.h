@@ -48,9 +48,13 @@ int pnpx_ctx_destroy(pnpx_ctx* ctx);
  * grow on first use, which synchronises the device once). */
 int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
 /* Options (the library reads no environment variables).
- *  "conv_mode": 1 (default) = half-split f16 MFMA convolutions (fp32-class accuracy, 3 MFMAs per product,
- *      csrc/conv_hs.hip); 0 = plain fp32 MFMA convolutions (csrc/conv3x3.hip, and csrc/conv3x3_wino.hip for the layers
- *      "fp32_winograd" covers).  Both meet the 1e-4 bar.
+ *  "conv_mode": 0 (default since r6) = fp32 MFMA convolutions, the reference's own arithmetic (csrc/conv3x3_wino8.hip /
+ *      conv3x3_wino.hip for the layers "fp32_winograd" covers, csrc/conv3x3.hip otherwise): inside 1e-4 of the fp32 oracle over a
+ *      whole 30-iteration episode on every seed tested, also on expansive weights (profiles/r5_drift_seeds.md).
+ *      1 = the FAST mode: half-split f16 MFMA convolutions (every value an f16 hi + lo pair = 22-bit significand, 3 MFMAs per
+ *      product, csrc/conv_hs.hip): 1e-6-class per call and ~1.55x the episode rate, but narrower than fp32 -- on the chaotic
+ *      expansive-weight episode 2 of 12 seeds end at 1.0e-4 / 1.24e-4 from the fp32 oracle (default-scale weights: 1e-6 both
+ *      modes), and |v| < 4095 behind "range_guard".
  *  "fp32_winograd" (default 1): in conv_mode 0, layers with cout % 64 == 0 (sources % 16, H and W % 16) or cout % 32 == 0
  *      (sources % 8, H % 16, W % 32) run as Winograd F(2x2,3x3) in fp32 (1.3-1.8x per layer; 7e-7 from the fp64 oracle where
  *      the direct kernel is 1.1e-6 -- same accuracy class, different summation order).  0 = the direct kernel on every layer.
@@ -59,10 +63,16 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *      its geometry allows; 0 = the round-4 4-wave kernel (csrc/conv3x3_wino.hip) everywhere.  A DRUNet context: any bit.
  *  "fp32_chains" (default 2): in conv_mode 0 the denoiser forward runs as n independent launch chains over contiguous slices of the batch
  *      (caller's stream + side streams, joined before the entry returns; bit-identical per image): 2 measured best (-3.6 % at 48 x 256^2,
- *      -7 % at B = 24); 1 = only the bottom level's three launches fork two chains; 0 = one chain.
+ *      -7 % at B = 24); 1 = only the bottom level's three launches fork two chains; 0 = one chain.  The VJP's adjoint chain forks exactly
+ *      two chains for every n >= 2.
  *  "fp32_fuse_up" (default 1): in conv_mode 0 the decoder-entry convolutions interpolate the bilinear x2 up-sampling of their second
  *      source inside the 8-wave kernel (tfpnp/pnp/denoiser/models/unet.py:92-121; no up-sampled tensor); 0 = the separate kernel
  *      (results agree to 5e-7).
+ *  "fp32_ksplit" (default 1, r6): in conv_mode 0 the layers of the two deepest levels (<= 16 tiles of 64 couts x 16 x 16 px per image)
+ *      split their input-channel chunks over 2 or 4 workgroups of the 8-wave kernel; the pieces' partial sums meet in a scratch slab and
+ *      the last arriver adds them in piece order (a rule of the layer's geometry alone: per-image results are bit-identical across
+ *      batch sizes and launch chains).  Fills the chip at small batches and evens out the 16 x 16 level's rounds at B = 48.
+ *      0 = unsplit (a different summation order: 1e-7-class differences).
  *  "range_guard": the half-split kernels carry activations as f16 hi+lo pairs of 16*v, i.e. |v| < 4095.  Their
  *      epilogues set a sticky flag when a stored value leaves that range or is NaN.
  *      1 (default): the flag is looked at (no synchronisation) at the top of the next call; once seen, the context

@@ -56,7 +56,7 @@ def test_bench_two_ranks_share_the_gpu(scaling):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PNPX_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "6",
-           "--size", "64", "--scaling", scaling, "--no-cpu-baseline", "--no-batch-table", "--no-fp32-mode"]
+           "--size", "64", "--scaling", scaling, "--no-cpu-baseline", "--no-batch-table", "--no-fast-mode"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -29,8 +29,9 @@ def rel(a, b):
 
 @pytest.fixture(scope="module")
 def drunet():
+    """The fast mode (half-split f16 x 3 family); the default family is the `drunet_f32` fixture below."""
     from tfpnp_amd.pnp import DRUNetDenoiser2D
-    return DRUNetDenoiser2D(state_dict=synth.make_drunet_params(0))
+    return DRUNetDenoiser2D(state_dict=synth.make_drunet_params(0), conv_mode=1)
 
 
 @pytest.mark.parametrize("B,H,W,seed", DRUNET_CASES)
@@ -179,7 +180,7 @@ def test_drunet_range_overflow_is_loud_then_rescaled(drunet):
     x = torch.rand(2, 1, 64, 64, device=dev())
     s = torch.full((2,), 0.1, device=dev())
     _, want = drunet.forward_preclamp(x, s)
-    den = DRUNetDenoiser2D(state_dict=hot)
+    den = DRUNetDenoiser2D(state_dict=hot, conv_mode=1)
     ctx = den.context(dev())
     den(x, s)                                   # trips the guard (not visible yet: no synchronisation in the default mode)
     torch.cuda.synchronize()
@@ -195,7 +196,7 @@ def test_drunet_range_overflow_is_loud_then_rescaled(drunet):
     else:
         raise AssertionError("still out of range at the largest shift")
     assert torch.isfinite(pre).all() and rel(pre / 1e4, want.cpu()) < 1e-5
-    den2 = DRUNetDenoiser2D(state_dict=hot)
+    den2 = DRUNetDenoiser2D(state_dict=hot, conv_mode=1)
     den2.context(dev()).set_option("range_guard", 2)
     _, pre2 = den2.forward_preclamp(x, s)
     den2.context(dev()).status()
@@ -310,8 +311,12 @@ def test_drunet_range_guard_rescales_instead_of_failing(drunet):
 # ----------------------------------------------------------------------------- conv_mode 0: fp32 arithmetic throughout (r4)
 @pytest.fixture(scope="module")
 def drunet_f32():
+    """r6: a context's DEFAULT family (no conv_mode argument) is fp32 arithmetic."""
     from tfpnp_amd.pnp import DRUNetDenoiser2D
-    return DRUNetDenoiser2D(state_dict=synth.make_drunet_params(0), conv_mode=0)
+    d = DRUNetDenoiser2D(state_dict=synth.make_drunet_params(0))
+    if torch.cuda.is_available():
+        assert d.context(dev()).get_option("conv_mode") == 0
+    return d
 
 
 @pytest.mark.parametrize("B,H,W,seed", DRUNET_CASES)

@@ -38,7 +38,7 @@ def test_subbatching_is_bit_identical(unet_params):
     from tfpnp_amd.pnp import UNetDenoiser2D
     x, s = denoiser_inputs(20, 128, 128, 8)
     x, s = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
-    den = UNetDenoiser2D(state_dict=unet_params)
+    den = UNetDenoiser2D(state_dict=unet_params, conv_mode=1)      # `subbatch` is an option of the half-split (fast) family
     outs = []
     ctx = den.context(dev())
     for sb in [0, 1, 3, 24]:
@@ -56,12 +56,13 @@ def test_set_option_switches_layout_safely(unet_params):
     x, s = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
     den = UNetDenoiser2D(state_dict=unet_params)
     ctx = den.context(dev())
+    assert ctx.get_option("conv_mode") == 0        # r6: the fp32 family (the reference's arithmetic) is the default
     a = den(x, s)
-    ctx.set_option("conv_mode", 0)
+    ctx.set_option("conv_mode", 1)                 # the fast half-split mode is one option away ...
     b = den(x, s)
-    ctx.set_option("conv_mode", 1)
+    ctx.set_option("conv_mode", 0)                 # ... and back
     c = den(x, s)
-    assert torch.equal(a, c) and rel(b, a) < 1e-5
+    assert torch.equal(a, c) and rel(b, a) < 1e-5 and not torch.equal(a, b)
     from tfpnp_amd._lib import PnpxError
     with pytest.raises(PnpxError):
         ctx.set_option("no_such_option", 1)
@@ -69,23 +70,26 @@ def test_set_option_switches_layout_safely(unet_params):
 
 def test_csmri_episode_drift_not_worse_than_fp32(unet_params):
     """30 inner iterations (6 x 5) on the EXPANSIVE (He-scaled) synthetic UNet, which amplifies fp32 round-off chaotically (x1.5-2
-    per solver call): ANY two fp32-class implementations drift apart by ~1e-4 over an episode.  Three distances per seed and
-    convolution family (VERDICT r4 next #2; the full 12-seed table is profiles/r5_drift_seeds.md, tools/drift_seeds.py):
+    per solver call): ANY two fp32-class implementations drift apart by several 1e-5 over an episode.  Three distances per seed and
+    convolution family (the full 12-seed table is profiles/r5_drift_seeds.md, tools/drift_seeds.py):
       e64  = HIP vs the fp64 oracle            (the yardstick: distance to the true trajectory),
       e32  = HIP vs the fp32 CPU oracle        (the distance north_star's 1e-4 is stated on),
       ecpu = fp32 CPU oracle vs fp64           (what the reference's own arithmetic drifts by: 3.6e-5 .. 6.9e-5).
-    Bounds, per seed (no medians): e64 <= 1.5 ecpu + 3e-5, and hard caps chosen from the table with ~25 % head-room over its
-    worst seed: conv_mode 1 (half-split) e64 <= 1.3e-4 (table max 1.02e-4), e32 <= 1.6e-4 (table max 1.24e-4 -- 2 of 12 seeds
-    exceed 1e-4 against the fp32 oracle on this chaotic case, stated in DESIGN.md section 2); conv_mode 0 (fp32 arithmetic)
-    e64 <= 8e-5 (5.7e-5), e32 <= 1e-4 (7.8e-5).  The non-expansive weight set below holds 1e-5 over the same 30 iterations."""
+    r6: the DEFAULT family (conv_mode 0, fp32 arithmetic) must meet the stated tolerance on EVERY seed:
+    e32 <= 1e-4, and e64 <= 8e-5 (table max 5.7e-5).  The opt-in fast mode (conv_mode 1, half-split f16 x 3) is held to 1e-4 on every
+    seed except the two documented outliers of its table (seed 31: 1.003e-4, seed 36: 1.235e-4 -- INTEGRATION.md section 4 states this
+    drift beside the mode's speed), which are capped at 1.6e-4; e64 <= 1.3e-4; and both families to e64 <= 1.5 ecpu + 3e-5 per seed.
+    The non-expansive weight set below holds 1e-5 over the same 30 iterations in both."""
     from oracle import pnp_oracle as O
     from tfpnp_amd.pnp import UNetDenoiser2D
     from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
     B, H, W = 2, 64, 64
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     acts = synth.make_actions(B)
-    caps = {1: (1.3e-4, 1.6e-4), 0: (8e-5, 1e-4)}
-    sols = {m: ADMMSolver_CSMRI(UNetDenoiser2D(state_dict=unet_params, conv_mode=m)) for m in (1, 0)}
+    FAST_MODE_OUTLIERS = {31, 36}
+    sols = {0: ADMMSolver_CSMRI(UNetDenoiser2D(state_dict=unet_params)),                     # the default family
+            1: ADMMSolver_CSMRI(UNetDenoiser2D(state_dict=unet_params, conv_mode=1))}        # the fast mode
+    assert sols[0].denoiser.context(dev()).get_option("conv_mode") == 0
     for seed in (31, 32, 35, 36):      # incl. the table's worst seeds of both families
         d = synth.make_csmri_batch(B, H, W, ratio=4, seed=seed)
 
@@ -100,7 +104,7 @@ def test_csmri_episode_drift_not_worse_than_fp32(unet_params):
 
         ref64, ref32 = run_oracle(torch.float64), run_oracle(torch.float32)
         e_cpu32 = rel(ref32, ref64)
-        for mode in (1, 0):
+        for mode in (0, 1):
             sol = sols[mode]
             g = lambda a: t(a).to(dev())
             v = sol.reset({"x0": g(d["x0"])})
@@ -110,7 +114,10 @@ def test_csmri_episode_drift_not_worse_than_fp32(unet_params):
             e64, e32 = rel(out, ref64), rel(out, ref32)
             print(f"seed {seed} conv_mode {mode}: HIP vs fp64 {e64:.3e}  HIP vs fp32 CPU oracle {e32:.3e}  (CPU fp32 oracle vs fp64 {e_cpu32:.3e})")
             assert e64 <= 1.5 * e_cpu32 + 3e-5, (seed, mode, e64, e_cpu32)
-            assert e64 <= caps[mode][0] and e32 <= caps[mode][1], (seed, mode, e64, e32)
+            if mode == 0:
+                assert e32 <= 1e-4 and e64 <= 8e-5, (seed, mode, e64, e32)
+            else:
+                assert e32 <= (1.6e-4 if seed in FAST_MODE_OUTLIERS else 1e-4) and e64 <= 1.3e-4, (seed, mode, e64, e32)
 
 
 @pytest.mark.parametrize("config", ["#1: B=1 128x128", "#2: B=48 256x256 (4 items checked)"])
@@ -158,7 +165,7 @@ def test_fused_upsample_option_matches_separate_kernel(unet_params):
     from oracle import pnp_oracle as O
     from tfpnp_amd.pnp import UNetDenoiser2D
     from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
-    den = UNetDenoiser2D(state_dict=unet_params)
+    den = UNetDenoiser2D(state_dict=unet_params, conv_mode=1)
     ctx = den.context(dev())
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
     try:
@@ -298,7 +305,7 @@ def test_fold_first_option_is_bit_identical(unet_params):
     second one, its output tensor never written): same arithmetic in the same order -- bit-identical outputs at the bench
     geometry and on a ragged one; geometries the instance does not cover silently take the separate kernels."""
     from tfpnp_amd.pnp import UNetDenoiser2D
-    den = UNetDenoiser2D(state_dict=unet_params)
+    den = UNetDenoiser2D(state_dict=unet_params, conv_mode=1)
     ctx = den.context(dev())
     try:
         for (B, H, W) in [(24, 256, 256), (9, 160, 224), (2, 64, 64), (3, 50, 39)]:
@@ -317,7 +324,7 @@ def test_round3_execution_options_are_bit_identical(unet_params):
     fft_tile (FFT pass mapping and tile size) only change HOW the work is scheduled: outputs must not move by a bit."""
     from tfpnp_amd.pnp import UNetDenoiser2D
     from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
-    den = UNetDenoiser2D(state_dict=unet_params)
+    den = UNetDenoiser2D(state_dict=unet_params, conv_mode=1)
     ctx = den.context(dev())
     defaults = {k: ctx.get_option(k) for k in ("wreg", "chains", "fft_affine", "fft_tile")}
     try:

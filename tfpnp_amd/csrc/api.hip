@@ -55,8 +55,8 @@ static void unet_layers(LayerSpec out[27]) {
 
 // A DRUNet context answers a tripped guard in steps (r5): the bias-free ReLU network is positively homogeneous, so the
 // first two trips move its passes 16x further inside the range each (DruNet::shift 4, then 8: exact up to f16 subnormals, 4e-6 at
-// 2^-8); a third trip latches the context to conv_mode 0 like a UNet context (drunet_f32.hip: exact fp32, forward only -- a VJP then
-// fails loudly).  Larger shifts are not used: at 2^-12 the lo halves sit in the f16 subnormals (1e-4 class errors, silently).
+// 2^-8); a third trip latches the context to conv_mode 0 like a UNet context (drunet_f32.hip: exact fp32, forward and -- since r5 --
+// VJP).  Larger shifts are not used: at 2^-12 the lo halves sit in the f16 subnormals (1e-4 class errors, silently).
 // One trip = one step: the device is drained before the flag is cleared, so that kernels of the offending call still in flight
 // cannot set it again behind the host's back, and range_guard_enter steps only once per acknowledged trip.
 constexpr int DRUNET_MAX_SHIFT = 8;
@@ -72,8 +72,13 @@ void range_guard_enter(pnpx_ctx* ctx) {
   if (!ctx->opt_range_guard || !ctx->range_flag_host) return;
   if (*static_cast<volatile unsigned*>(ctx->range_flag_host) == 0 || ctx->range_tripped) return;
   ctx->range_tripped = true;          // an EARLIER call overflowed: its output was invalid (pnpx_ctx_status reports it)
-  if (ctx->drunet.loaded && ctx->conv_mode == CONV_HS) (void)drunet_rescale(ctx);   // later calls: 16x further inside the range / exact
-  else ctx->conv_mode = CONV_F32;     // every later call is exact
+  // later calls: 16x further inside the range / exact.  ADVICE r5: if the rescale step itself fails (its device synchronisation
+  // returned an error) neither the shift nor the flag clear happened and, the trip being latched, no later call would step either:
+  // fall back to the exact family right away so that nothing invalid is produced from here on (the HIP error resurfaces at the
+  // call's own first launch).
+  if (ctx->drunet.loaded && ctx->conv_mode == CONV_HS) {
+    if (drunet_rescale(ctx) != PNPX_OK) ctx->conv_mode = CONV_F32;
+  } else ctx->conv_mode = CONV_F32;     // every later call is exact
 }
 
 int range_guard_strict(pnpx_ctx* ctx, hipStream_t s, bool* rerun) {
@@ -250,6 +255,10 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_fp32_fuse_up = value;
     return PNPX_OK;
   }
+  if (is("fp32_ksplit") && (value == 0 || value == 1)) {
+    ctx->opt_fp32_ksplit = value;
+    return PNPX_OK;
+  }
   if (is("fp32_wino8_layers") && value >= 0 && value < (1 << 27)) {     // bit li: layer li on the 8-wave Winograd kernel
     ctx->opt_fp32_wino8 = value;
     return PNPX_OK;
@@ -321,6 +330,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fp32_winograd")) *value = ctx->opt_fp32_winograd;
   else if (is("fp32_wino8_layers")) *value = ctx->opt_fp32_wino8;
   else if (is("fp32_fuse_up")) *value = ctx->opt_fp32_fuse_up;
+  else if (is("fp32_ksplit")) *value = ctx->opt_fp32_ksplit;
   else if (is("fp32_chains")) *value = ctx->opt_fp32_chains;
   else if (is("fft_tile")) *value = ctx->opt_fft_tile;
   else if (is("range_guard")) *value = ctx->opt_range_guard;
@@ -355,7 +365,8 @@ size_t pnpx_ctx_bytes(const pnpx_ctx* ctx) {
   if (!ctx) return 0;
   size_t n = ctx->weights.bytes + ctx->arena.buf.bytes + ctx->arena_grad.buf.bytes + ctx->scratch.bytes +
              ctx->drunet.weights.bytes + ctx->drunet.arena.bytes + ctx->drunet.arena_grad.bytes + ctx->drunet.f32_weights.bytes +
-             ctx->drunet.f32_arena.bytes + ctx->policy.weights.bytes + ctx->policy.arena.bytes;
+             ctx->drunet.f32_arena.bytes + ctx->drunet.f32_weights_bwd.bytes + ctx->drunet.f32_arena_grad.bytes +
+             ctx->policy.weights.bytes + ctx->policy.arena.bytes;
   for (const auto& sl : ctx->train_ring) n += sl.arena.buf.bytes + sl.pre.bytes;
   return n;
 }

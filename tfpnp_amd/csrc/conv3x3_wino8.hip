@@ -139,10 +139,11 @@ using I3 = std::integral_constant<int, 3>;
 using Yes = std::true_type;
 using No = std::false_type;
 
-template <int CT, bool FUSE_OUTC, bool RES, bool UPS>
+template <int CT, bool FUSE_OUTC, bool RES, bool UPS, bool KSPLIT>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
   static_assert(!FUSE_OUTC || CT == 32, "the fused out-conv needs all 32 couts of a pixel in one SIMD's wave pair");
   static_assert(!UPS || (!FUSE_OUTC && !RES), "the up-sampling instances are the UNet's plain decoder entries");
+  static_assert(!KSPLIT || (CT == 64 && !FUSE_OUTC && !RES && !UPS), "K-split: the plain 64-cout instance (the deep levels' layers)");
   using C = Cfg8<CT>;
   constexpr int CK = C::CK, HALVES = C::HALVES, KS = C::KS, RS = C::RS, NSTG = C::NSTG, NPOS = C::NPOS;
   constexpr int TX = C::TX, NT = C::NT, RW = C::RW, RPX = C::RPX, RPXL = C::RPXL;
@@ -169,17 +170,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     const float* w;
     const float* s1u;  // UPS: origin of the low-resolution window in the second source, pre-offset by -C0 channels
     int ok, rlo;       // (ints, no tail padding: a struct copy with padding bytes goes through scratch)
-    int clo, pad_;
+    int clo, c0;       // c0 (KSPLIT): first channel chunk of this work item
+    int item, g;       // KSPLIT: tile number (scratch slab / arrival counters) and piece
   };
   const int hpwp_lo = UPS ? (a.ups_h + 2) * (a.ups_w + 2 * PADL) : 0;
   auto decode = [&](int k) {
     Tile T;
     const int j = slot + nslot * k;
-    const int q = j / a.nct;
-    T.ct = j - q * a.nct;
+    // KSPLIT: the pieces of a tile are `ksplit` consecutive groups of nct items (v = piece * nct + cout tile): they run side by side
+    // on one XCD, beside the sibling cout tiles that share their halo
+    const int vnct = KSPLIT ? a.nct * a.ksplit : a.nct;
+    const int q = j / vnct;
+    const int v = j - q * vnct;
+    T.g = KSPLIT ? v / a.nct : 0;
+    T.ct = KSPLIT ? v - T.g * a.nct : v;
+    T.c0 = KSPLIT ? T.g * a.nch : 0;
     const int reg = nx * q + xcd;
     T.ok = reg < nregions;
-    T.pad_ = 0;
+    T.item = reg * a.nct + T.ct;
     T.rlo = T.clo = 0;
     T.s1u = nullptr;
     const int t1 = reg / a.rx;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     const size_t pix = (size_t)T.y0 * a.Wp + T.x0 + (PADL - 1);
     T.s0 = a.in0 + (size_t)T.b * a.C0 * HpWp + pix;
     T.s1 = a.in1 + ((long long)T.b * a.C1 - a.C0) * (long long)HpWp + (long long)pix;
-    T.w = a.u + (size_t)T.ct * a.nch * 4 * (UQ / 4);
+    T.w = a.u + ((size_t)T.ct * (KSPLIT ? a.nch_all : a.nch) + T.c0) * 4 * (UQ / 4);
     if (UPS) {
       // window of source pixels: anchored at the source pixel of the halo's first row / column, pulled back so that its NR rows and
       // NQP columns stay inside the padded low-resolution tensor (whose padding is zero: the only out-of-image taps have weight 0)
@@ -205,7 +213,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     }
     return T;
   };
-  auto raw_of = [&](const Tile& X, int c) { return ((CK * c < a.C0) ? X.s0 : X.s1) + (size_t)CK * c * HpWp; };
+  auto raw_of = [&](const Tile& X, int c) {
+    const int ca = KSPLIT ? c + X.c0 : c;     // (a piece's prefetch beyond its last chunk names the next item's first chunks, as at a tile's end)
+    return ((CK * ca < a.C0) ? X.s0 : X.s1) + (size_t)CK * ca * HpWp;
+  };
 
   const int wm = (CT == 64) ? (sw & 1) : 0, wn = (CT == 64) ? (sw >> 1) : sw;
   const int l31 = lane & 31, kg = lane >> 5;
@@ -617,6 +628,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
         for (int j = 0; j < 8; ++j) ow[j] = a.outc_w[cbase + ((R0 + j) & 3) + 8 * ((R0 + j) >> 2)];
       }
       wait_lds();
+      // KSPLIT: [tile][piece][wave][row][lane] f32x4
+      float* const part_tile = KSPLIT ? a.part + ((size_t)T.item * a.ksplit * 8 + wave) * 2048 + lane * 4 : nullptr;
+      float* const part_mine = KSPLIT ? part_tile + (size_t)T.g * (8 * 2048) : nullptr;
       static_for<8>([&](auto j_tag) {
         constexpr int j = decltype(j_tag)::value;
         constexpr int R = R0 + j;
@@ -626,8 +640,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
         const f32x4 mine = column_sums(std::integral_constant<int, R>{});
         const f32x4 lo = (P == 0) ? mine : theirs[j], hi = (P == 0) ? theirs[j] : mine;
         const float bias = bias_r[j];
-        float y00 = ((lo[0] + lo[1]) + hi[0]) + bias, y01 = ((lo[1] - hi[0]) - hi[1]) + bias;
-        float y10 = ((lo[2] + lo[3]) + hi[2]) + bias, y11 = ((lo[3] - hi[2]) - hi[3]) + bias;
+        float y00 = (lo[0] + lo[1]) + hi[0], y01 = (lo[1] - hi[0]) - hi[1];
+        float y10 = (lo[2] + lo[3]) + hi[2], y11 = (lo[3] - hi[2]) - hi[3];
+        if (KSPLIT) {      // this piece's share of the sums over the input channels: finished below by the wave that arrives last
+          *reinterpret_cast<f32x4*>(part_mine + j * 256) = (f32x4){y00, y01, y10, y11};
+          return;
+        }
+        y00 += bias;
+        y01 += bias;
+        y10 += bias;
+        y11 += bias;
         // LeakyReLU with 0 <= slope <= 1 (0.2; 0 = ReLU; 1 = linear) as max(y, slope y): two instructions instead of three per value
         y00 = fmaxf(y00, y00 * a.slope);
         y01 = fmaxf(y01, y01 * a.slope);
@@ -659,6 +681,47 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
           if (a.pool) pb[(size_t)co * HpWp_pool] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));   // same association as maxpool2_kernel
         }
       });
+      if (KSPLIT) {
+        // Arrival: this wave's eight partial rows are in memory (vmcnt(0) + release fence), then one agent-scope counter per
+        // (tile, wave).  The wave that finds ksplit - 1 earlier arrivals reads all pieces back (its own included: one code path, one
+        // summation order -- piece 0 + piece 1 [+ piece 2 + piece 3], left to right, whoever arrives last) and finishes the rows.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        unsigned* const cnt = a.part_cnt + (size_t)T.item * 8 + wave;
+        unsigned seen = 0;
+        if (lane == 0) seen = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen = __builtin_amdgcn_readfirstlane(seen);
+        if (seen == (unsigned)(a.ksplit - 1)) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+          const int G = a.ksplit;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int R = R0 + j;
+            const int co = cbase + (R & 3) + 8 * (R >> 2);
+            f32x4 y = *reinterpret_cast<const f32x4*>(part_tile + j * 256);
+            for (int g = 1; g < G; ++g) {
+              const f32x4 pg = *reinterpret_cast<const f32x4*>(part_tile + (size_t)g * (8 * 2048) + j * 256);
+              y[0] += pg[0];
+              y[1] += pg[1];
+              y[2] += pg[2];
+              y[3] += pg[3];
+            }
+            const float bias = bias_r[j];
+            float y00 = y[0] + bias, y01 = y[1] + bias, y10 = y[2] + bias, y11 = y[3] + bias;
+            y00 = fmaxf(y00, y00 * a.slope);
+            y01 = fmaxf(y01, y01 * a.slope);
+            y10 = fmaxf(y10, y10 * a.slope);
+            y11 = fmaxf(y11, y11 * a.slope);
+            float* o = ob + (size_t)co * HpWp;
+            *reinterpret_cast<f32x2*>(o) = (f32x2){y00, y01};
+            *reinterpret_cast<f32x2*>(o + a.Wp) = (f32x2){y10, y11};
+            if (a.pool) pb[(size_t)co * HpWp_pool] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+          }
+        }
+        // the stage waits that follow count no epilogue stores for these instances (NST = 0): the queue is empty here
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       WINO8_STAMP(19);
       if (FUSE_OUTC) {
         // this wave holds couts 16 P .. 16 P + 15 (4 kg + (R & 3) + 8 (R >> 2)): the other lane half, then the other wave (through LDS)
@@ -699,7 +762,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     };
 
     // VMEM operations a DMA wave leaves in its queue across an epilogue (its stores); halo gathers per DMA wave (wave 0: one more)
-    constexpr int NST = FUSE_OUTC ? (P == 0 ? 4 : 0) : 16;
+    constexpr int NST = KSPLIT ? 0 : (FUSE_OUTC ? (P == 0 ? 4 : 0) : 16);
     constexpr int NRAW = C::NRAW;
 
     int k = 0;
@@ -708,7 +771,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     WINO8_STAMP(14);
     // prologue: first halo(s) and weight stages, first transform, first operands
     if (CT == 64) {
-      dma_raw(T.s0, 0, 0, RAW_PER_WAVE);
+      dma_raw(raw_of(T, 0), 0, 0, RAW_PER_WAVE);
       dma_u(T.w, 0);
       dma_u(T.w + (UQ / 4), 1);
       dma_u(T.w + 2 * (UQ / 4), 2);
@@ -845,12 +908,31 @@ static int wino8_ct(int C0, int C1, int cout, int H, int W) {
 }
 bool conv3x3_wino8_ok(int C0, int C1, int cout, int H, int W) { return wino8_ct(C0, C1, cout, H, W) != 0; }
 
-template <int CT, bool FUSE_OUTC, bool RES, bool UPS = false>
+// r6: which layers split their channel chunks over several work items, and into how many.  A rule of the LAYER'S geometry alone (never of
+// the batch): the summation tree of an output is then the same at every batch size, and per-image results stay bit-identical across
+// batch sizes, slices and launch chains.  t = tiles per image: <= 8 (the 16 x 16 level of a 256 x 256 input: one region x 8 cout tiles)
+// -> 4 pieces, <= 16 (32 x 32: four regions x 4) -> 2; every piece keeps >= 4 chunks.  At B = 48 this turns the 16 x 16 level's 384 tiles
+// on 256 workgroups (two rounds for 1.5 rounds of work) into 1536 quarter-tiles = 6 even rounds; at B = 6 it puts 192 instead of 48 / 96
+// workgroups on the chip.
+int conv3x3_wino8_ksplit(int C0, int C1, int cout, int H, int W) {
+  if (wino8_ct(C0, C1, cout, H, W) != 64) return 1;
+  const int t = (H / 16) * (W / 16) * (cout / 64), nch = (C0 + C1) / 16;
+  int g = t <= 8 ? 4 : (t <= 16 ? 2 : 1);
+  while (g > 1 && (nch % g != 0 || nch / g < 4)) g /= 2;
+  return g;
+}
+size_t conv3x3_wino8_ksplit_bytes_per_image() { return (size_t)32 * 8 * 2048 * sizeof(float); }     // <= 32 (tile, piece) slots of 64 KiB
+size_t conv3x3_wino8_ksplit_counters_per_image() { return 16 * 8; }                                  // <= 16 tiles x 8 waves
+
+template <int CT, bool FUSE_OUTC, bool RES, bool UPS = false, bool KSPLIT = false>
 static int launch_wino8(WinoArgs a, hipStream_t s) {
   using C = Cfg8<CT>;
   static_assert(C::LDS_USED <= LDS_REQ8 && C::LDS_USED_UPS <= LDS_REQ8, "LDS budget");
   a.nct = a.Cout / CT;
   a.nch = (a.C0 + a.C1) / C::CK;
+  a.nch_all = a.nch;
+  if (KSPLIT) a.nch /= a.ksplit;
+  else a.ksplit = 1;
   a.rx = a.W / C::RPXW;
   a.ry = a.H / 16;
   static std::once_flag attr_once[64];
@@ -859,15 +941,16 @@ static int launch_wino8(WinoArgs a, hipStream_t s) {
   if (dev >= 0 && dev < 64) {
     hipError_t e = hipSuccess;
     std::call_once(attr_once[dev], [&] {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32_kernel<CT, FUSE_OUTC, RES, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ8);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino8_f32_kernel<CT, FUSE_OUTC, RES, UPS, KSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_REQ8);
     });
     PNPX_HIP(e);
   }
-  const long long ntiles = (long long)a.rx * a.ry * a.B * a.nct;
+  const int vnct = a.nct * a.ksplit;                 // work items per region
+  const long long ntiles = (long long)a.rx * a.ry * a.B * vnct;
   long long grid = 256;
   if (grid >= ntiles) grid = ntiles;
-  else if ((grid / 8) % a.nct != 0 && grid >= 8LL * a.nct) grid -= grid % (8 * a.nct);
-  hipLaunchKernelGGL((conv3x3_wino8_f32_kernel<CT, FUSE_OUTC, RES, UPS>), dim3((unsigned)grid), dim3(512), LDS_REQ8, s, a);
+  else if ((grid / 8) % vnct != 0 && grid >= 8LL * vnct) grid -= grid % (8 * vnct);
+  hipLaunchKernelGGL((conv3x3_wino8_f32_kernel<CT, FUSE_OUTC, RES, UPS, KSPLIT>), dim3((unsigned)grid), dim3(512), LDS_REQ8, s, a);
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
 }
@@ -973,7 +1056,8 @@ int launch_conv3x3_wino8_grad(const float* u, const float* zero_bias, int cout, 
 }
 
 int launch_conv3x3_wino8(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
-                         float* out, int B, int H, int W, hipStream_t s, float slope, const float* res, float* pool_out) {
+                         float* out, int B, int H, int W, hipStream_t s, float slope, const float* res, float* pool_out, float* ks_part,
+                         unsigned* ks_cnt) {
   const int ct = wino8_ct(C0, C1, cout, H, W);
   if (!ct) {
     set_error("conv3x3_wino8: unsupported geometry (%d + %d -> %d channels, %d x %d)", C0, C1, cout, H, W);
@@ -997,6 +1081,15 @@ int launch_conv3x3_wino8(const float* u, const float* bias, int cout, const floa
   a.Cout = cout;
   a.slope = slope;
   if (res) return ct == 64 ? launch_wino8<64, false, true>(a, s) : launch_wino8<32, false, true>(a, s);
+  // K-split instances: when the caller hands over the scratch slab + arrival counters (>= conv3x3_wino8_ksplit_bytes_per_image() /
+  // _counters_per_image() per image of the batch, counters zero) and the layer's geometry calls for it
+  const int g = (ks_part && ks_cnt) ? conv3x3_wino8_ksplit(C0, C1, cout, H, W) : 1;
+  if (g > 1) {
+    a.ksplit = g;
+    a.part = ks_part;
+    a.part_cnt = ks_cnt;
+    return launch_wino8<64, false, false, false, true>(a, s);
+  }
   return ct == 64 ? launch_wino8<64, false, false>(a, s) : launch_wino8<32, false, false>(a, s);
 }
 

@@ -377,8 +377,11 @@ int drunet_denoise_f32(pnpx_ctx* ctx, const float* x, const float* sigma, int si
   }
   PNPX_TRY(prepare_weights(ctx));
   if (B > N.f32_capB || H != N.f32_capH || W != N.f32_capW || (keep_mids && !N.f32_arena_keeps)) {   // (re)lay the arena out; the zero borders are written here, once
-    const int nb_img = (H == N.f32_capH && W == N.f32_capW && N.f32_capB > B) ? N.f32_capB : B;
-    const bool keeps = keep_mids || (N.f32_arena_keeps && H == N.f32_capH && W == N.f32_capW);
+    // the keep planes (every ResBlock's middle activation: ~1 GB per 512 x 512 image at nb = 4) are sized for the batch of
+    // the call that NEEDS them, not for the largest inference batch the arena has seen; a re-layout for an inference call drops them
+    // (the next VJP lays them out again for its own batch).  Without keeps the arena keeps its largest batch, as before.
+    const bool keeps = keep_mids;
+    const int nb_img = (!keeps && H == N.f32_capH && W == N.f32_capW && N.f32_capB > B) ? N.f32_capB : B;
     const Plan Pl = plan_of(nb_img, H, W, keeps ? N.nb : 0);
     PNPX_HIP(hipDeviceSynchronize());
     if (N.f32_arena.bytes < Pl.total * sizeof(float)) {
@@ -413,8 +416,11 @@ int drunet_denoise_f32(pnpx_ctx* ctx, const float* x, const float* sigma, int si
     ++li;
     if (kind == 3 || kind == 4) return launch_conv1x1_act(Lc, in, outp, B, h, w, slope, res, s);
     if (u && ctx->opt_fp32_winograd && conv3x3_wino_ok(Lc.cin, 0, Lc.cout, h, w))
-      return ((ctx->opt_fp32_wino8 && conv3x3_wino8_ok(Lc.cin, 0, Lc.cout, h, w)) ? launch_conv3x3_wino8 : launch_conv3x3_wino)(
-          u, Lc.b, Lc.cout, in, Lc.cin, nullptr, 0, outp, B, h, w, s, slope, res, nullptr);
+    {
+      if (ctx->opt_fp32_wino8 && conv3x3_wino8_ok(Lc.cin, 0, Lc.cout, h, w))
+        return launch_conv3x3_wino8(u, Lc.b, Lc.cout, in, Lc.cin, nullptr, 0, outp, B, h, w, s, slope, res, nullptr);
+      return launch_conv3x3_wino(u, Lc.b, Lc.cout, in, Lc.cin, nullptr, 0, outp, B, h, w, s, slope, res, nullptr);
+    }
     return launch_conv3x3_act(Lc, in, Lc.cin, nullptr, 0, outp, B, h, w, slope, res, s);
   };
   auto resblocks = [&](int l, int dec, float* cur, float** result) -> int {

@@ -619,6 +619,9 @@ static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, con
   // ---- plain-fp32 path (conv_mode 0): padded planar fp32 activations, whole batch per launch
   char* A = static_cast<char*>(ar.buf.p);
   auto fptr = [&](const Act& d) { return reinterpret_cast<float*>(A + d.off + (size_t)b_base * act_bytes_per_image(CONV_F32, d.C, d.H, d.W)); };
+  // r6: scratch of the K-split launches (this slice's images; option fp32_ksplit = 0 hands none over: the layers then run unsplit)
+  float* const ks_part = ctx->opt_fp32_ksplit ? reinterpret_cast<float*>(A + P.ks_part + (size_t)b_base * P.ks_part_per_image) : nullptr;
+  unsigned* const ks_cnt = ctx->opt_fp32_ksplit ? reinterpret_cast<unsigned*>(A + P.ks_cnt + (size_t)b_base * P.ks_cnt_per_image) : nullptr;
   // the first convolution (2 -> 32 channels) straight from the fp32 image on the vector ALU (training forwards too: the VJP needs the
   // layer's output, not its padded input tensor)
   const bool first_valu = ctx->opt_fuse_first && W % 4 == 0 && ctx->conv[0].cout == 32;
@@ -636,8 +639,12 @@ static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, con
     if (pooled_done) *pooled_done = false;
     if (ctx->opt_fp32_winograd && ctx->conv_wino_u[li] && conv3x3_wino_ok(i0.C, C1, L.cout, o.H, o.W)) {
       const bool w8 = ((ctx->opt_fp32_wino8 >> li) & 1) && conv3x3_wino8_ok(i0.C, C1, L.cout, o.H, o.W);
-      PNPX_TRY((w8 ? launch_conv3x3_wino8 : launch_conv3x3_wino)(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1,
-                                                                fptr(o), B, o.H, o.W, s, 0.2f, nullptr, pooled ? fptr(*pooled) : nullptr));
+      if (w8)
+        PNPX_TRY(launch_conv3x3_wino8(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1, fptr(o), B, o.H, o.W, s, 0.2f,
+                                      nullptr, pooled ? fptr(*pooled) : nullptr, ks_part, ks_cnt));
+      else
+        PNPX_TRY(launch_conv3x3_wino(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1, fptr(o), B, o.H, o.W, s, 0.2f,
+                                     nullptr, pooled ? fptr(*pooled) : nullptr));
       if (pooled_done) *pooled_done = pooled != nullptr;
       return rec.mark("conv3x3_wino", 2.0 * 9.0 * L.cin * L.cout * (double)o.H * o.W * B);   // algorithmic FLOPs; 4/9 of them executed
     } else {
@@ -683,7 +690,9 @@ static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, con
           auto slice = [&](int li, const Act& i, const Act& o) -> int {
             const ConvLayer& L = ctx->conv[li];
             return launch_conv3x3_wino8(ctx->conv_wino_u[li], L.b, L.cout, fptr(i) + (size_t)lo * i.C * padded_h(i.H) * padded_w(i.W), i.C, nullptr, 0,
-                                        fptr(o) + (size_t)lo * o.C * padded_h(o.H) * padded_w(o.W), hi - lo, o.H, o.W, st, 0.2f, nullptr, nullptr);
+                                        fptr(o) + (size_t)lo * o.C * padded_h(o.H) * padded_w(o.W), hi - lo, o.H, o.W, st, 0.2f, nullptr, nullptr,
+                                        ks_part ? ks_part + (size_t)lo * (P.ks_part_per_image / sizeof(float)) : nullptr,
+                                        ks_cnt ? ks_cnt + (size_t)lo * (P.ks_cnt_per_image / sizeof(unsigned)) : nullptr);
           };
           PNPX_TRY(slice(12, P.p[4], P.a[4]));
           PNPX_TRY(slice(13, P.a[4], P.b[4]));
@@ -708,6 +717,7 @@ static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, con
     const bool ups_fused = ctx->opt_fp32_fuse_up && ctx->opt_fp32_winograd && ctx->conv_wino_u[li0] && ((ctx->opt_fp32_wino8 >> li0) & 1) &&
                            P.x[l].H == 2 * h && P.x[l].W == 2 * w && conv3x3_wino8_ups_ok(P.x[l].C, below->C, ctx->conv[li0].cout, 2 * h, 2 * w);
     if (ups_fused) {
+      // nothing to launch
     } else if ((2 * w) % 4 == 0 && (size_t)B * below->C <= 65535) {
       const int quads = w / 2, bx = quads >= 64 ? 64 : quads, by = 256 / bx;
       hipLaunchKernelGGL(upsample2x_v4_kernel, dim3((quads + bx - 1) / bx, (2 * h + by * UPS_ROWS - 1) / (by * UPS_ROWS), B * below->C), dim3(bx, by), 0, s,
@@ -716,8 +726,10 @@ static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, con
       hipLaunchKernelGGL(upsample2x_kernel, g1d(n_up), dim3(256), 0, s, fptr(*below), fptr(P.u[l]), n_up, h, w, P.u[l].H,
                          P.u[l].W, sy, sx);
     }
-    PNPX_LAUNCH_CHECK();
-    if (!ups_fused) PNPX_TRY(rec.mark("upsample2x", 0));
+    if (!ups_fused) {
+      PNPX_LAUNCH_CHECK();
+      PNPX_TRY(rec.mark("upsample2x", 0));
+    }
     // first convolution of a decoder block: the fused instance reads the low-resolution tensor
     auto entry = [&](const Act& ta) -> int {
       if (!ups_fused) return conv(li0, P.x[l], &P.u[l], ta);

@@ -590,6 +590,8 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
   PNPX_LAUNCH_CHECK();
   return PNPX_OK;
   };
+  // the adjoint chain always forks exactly TWO launch chains when fp32_chains >= 2 (measured best, profiles/r5_wino8.md; the forward
+  // honours larger n): documented in include/pnpx.h
   if (ctx->opt_fp32_chains >= 2 && B >= 2)
     return fan_out_chains(ctx, 2, B, s, [&](int lo, int hi, hipStream_t st) -> int { return run(lo, hi - lo, st); });
   return run(0, B, s);

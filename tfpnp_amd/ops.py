@@ -102,7 +102,7 @@ class Context:
         self._policy = (int(num_inputs), int(n_det))
 
     def set_option(self, key, value):
-        """e.g. set_option('conv_mode', 0) selects the plain-fp32 MFMA convolutions (default 1 = half-split f16)."""
+        """e.g. set_option('conv_mode', 1) selects the fast half-split f16 MFMA convolutions (default 0 = fp32 arithmetic)."""
         check(_lib.lib().pnpx_ctx_set_option(self.handle, key.encode(), int(value)))
 
     def get_option(self, key):

@@ -17,7 +17,8 @@ CURRENT_DIR = os.path.dirname(os.path.abspath(__file__))
 
 class UNetDenoiser2D(torch.nn.Module):
     def __init__(self, ckpt_path=None, state_dict=None, conv_mode=None):
-        """conv_mode: None/1 = half-split f16 MFMA convolutions (default), 0 = plain fp32 MFMA convolutions."""
+        """conv_mode: None/0 = fp32 MFMA convolutions, the reference's arithmetic (default since r6); 1 = the fast mode:
+        half-split f16 MFMA convolutions (22-bit significand, ~1.55x the episode rate)."""
         super().__init__()
         self.conv_mode = conv_mode
         if state_dict is None:
@@ -72,8 +73,8 @@ class DRUNetDenoiser2D(UNetDenoiser2D):
     ResBlock's ReLU output and back-propagates on the same kernels (csrc/drunet.hip::drunet_denoise_backward)."""
 
     def __init__(self, ckpt_path=None, state_dict=None, nb=4, conv_mode=None):
-        """conv_mode: None/1 = half-split f16 MFMA convolutions (default; forward and VJP), 0 = fp32 arithmetic throughout
-        (csrc/drunet_f32.hip: Winograd / direct fp32 MFMA kernels; forward only)."""
+        """conv_mode: None/0 = fp32 arithmetic throughout (default since r6; csrc/drunet_f32.hip: Winograd / direct fp32 MFMA
+        kernels, forward and VJP); 1 = the fast mode: half-split f16 MFMA convolutions (forward and VJP)."""
         torch.nn.Module.__init__(self)
         self.conv_mode = conv_mode
         self.nb = nb

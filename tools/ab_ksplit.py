@@ -1,0 +1,67 @@
+"""A/B of the fp32 family's K-split (option fp32_ksplit, conv3x3_wino8.hip KSPLIT): agreement of the two settings and with the fp64 oracle,
+determinism, bit-identity of an image across batch sizes, and the forward time per batch size for both settings and chain counts.
+usage: python tools/ab_ksplit.py [H] > profiles/r6_ksplit.txt      (GPU box only)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import pnp_oracle as O
+from tests.golden_inputs import denoiser_inputs
+from tfpnp_amd import synth
+from tfpnp_amd.pnp import UNetDenoiser2D
+
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dev = torch.device("cuda:0")
+params = synth.make_unet_params(0)
+den = UNetDenoiser2D(state_dict=params)
+ctx = den.context(dev)
+rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+
+# numerics
+x, s = denoiser_inputs(3, H, H, 21)
+xt, st = torch.from_numpy(x).to(dev), torch.from_numpy(s).to(dev)
+outs = {}
+for k in (1, 0):
+    ctx.set_option("fp32_ksplit", k)
+    a = den.forward_preclamp(xt, st)[1].clone()
+    b = den.forward_preclamp(xt, st)[1].clone()
+    outs[k] = a
+    print(f"fp32_ksplit {k}: deterministic {torch.equal(a, b)}")
+p64 = {k: torch.as_tensor(v).double() for k, v in params.items()}
+with torch.no_grad():
+    sig = torch.from_numpy(s).double().view(3, 1, 1, 1).expand(3, 1, H, H)
+    ref = O.unet_forward(torch.cat([torch.from_numpy(x).double(), sig], 1), p64)
+print(f"split vs unsplit {rel(outs[1], outs[0]):.2e}; vs fp64 oracle: split {rel(outs[1].cpu(), ref):.2e} unsplit {rel(outs[0].cpu(), ref):.2e}")
+ctx.set_option("fp32_ksplit", 1)
+xb, sb = denoiser_inputs(13, H, H, 5)
+xb, sb = torch.from_numpy(xb).to(dev), torch.from_numpy(sb).to(dev)
+full = den.forward_preclamp(xb, sb)[1].clone()
+for n in (1, 2, 5, 6, 12):
+    part = den.forward_preclamp(xb[:n].contiguous(), sb[:n].contiguous())[1]
+    print(f"first {n} of 13 images alone: bit-identical to their rows of the 13-image call: {torch.equal(part, full[:n])}")
+
+# timing
+print("\n| B | chains | ksplit 0 ms | ksplit 1 ms | ratio |\n|---|---|---|---|---|")
+for B in (1, 2, 3, 6, 12, 24, 48):
+    xx = torch.rand(B, 1, H, H, device=dev)
+    ss = torch.full((B,), 0.1, device=dev)
+    for chains in (0, 2):
+        if chains > B:
+            continue
+        ctx.set_option("fp32_chains", chains)
+        t = {}
+        for k in (0, 1):
+            ctx.set_option("fp32_ksplit", k)
+            for _ in range(3):
+                den(xx, ss)
+            torch.cuda.synchronize()
+            n = 20 if B <= 12 else 10
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    den(xx, ss)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / n * 1e3)
+            t[k] = best
+        print(f"| {B} | {chains} | {t[0]:.3f} | {t[1]:.3f} | {t[1] / t[0]:.3f} |")
+ctx.set_option("fp32_chains", 2)

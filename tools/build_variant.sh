@@ -1,5 +1,5 @@
 #!/bin/bash
-# build_variant.sh <name> <extra hipcc flags...>  ->  tfpnp_amd/libpnpx_<name>.so  (A/B builds for tools/, PNPX_LIB=...)
+# build_variant.sh <name> <extra hipcc flags...>  ->  tools/_build/libpnpx_<name>.so  (A/B builds for tools/, PNPX_LIB=...)
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -9,6 +9,7 @@ cp -r $root/tfpnp_amd/csrc $tmp/tfpnp_amd/csrc
 cp $root/include/pnpx.h $tmp/include/
 rm -f $tmp/tfpnp_amd/csrc/*.o
 make -C $tmp/tfpnp_amd/csrc -j16 EXTRA="$*" tuning >/dev/null
-cp $tmp/tfpnp_amd/libpnpx_tune.so $root/tfpnp_amd/libpnpx_$name.so
+mkdir -p $root/tools/_build
+cp $tmp/tools/_build/libpnpx_tune.so $root/tools/_build/libpnpx_$name.so
 rm -rf $tmp
-echo built tfpnp_amd/libpnpx_$name.so with "$*"
+echo built tools/_build/libpnpx_$name.so with "$*"

@@ -1,6 +1,6 @@
 """Per-step timeline of conv_hs (workgroup 8, wave 0) from an HS_TRACE build: tools/build_variant.sh trace -DHS_TRACE.
 
-usage: PNPX_LIB=tfpnp_amd/libpnpx_trace.so python tools/trace_conv.py [B] [H] [out.txt]
+usage: PNPX_LIB=tools/_build/libpnpx_trace.so python tools/trace_conv.py [B] [H] [out.txt]
 Stamps (s_memtime, shader clocks): 1 loop top, 2 DMA wait done, 3 barrier passed, 4 chunk multiplied, 5 epilogue done."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

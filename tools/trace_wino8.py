@@ -1,7 +1,7 @@
 """Timeline of the 8-wave Winograd kernel (conv3x3_wino8.hip built with -DWINO8_TRACE = libpnpx_trace.so, `make -C tfpnp_amd/csrc trace`).
 Waves 0 (transform role) and 4 (DMA role) of workgroup 0 stamp the shader clock behind every stage's barrier and at the phases of the
 epilogue; this prints, per layer, the cycles per stage and per epilogue phase.  GPU box only.
-usage: PNPX_LIB=tfpnp_amd/libpnpx_trace.so python tools/trace_wino8.py [B] [H] [layer ...]"""
+usage: PNPX_LIB=tools/_build/libpnpx_trace.so python tools/trace_wino8.py [B] [H] [layer ...]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

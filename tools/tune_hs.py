@@ -1,5 +1,5 @@
 """Sweep conv_hs launch configurations per (cout tile, level width) with the tuning build (make -C tfpnp_amd/csrc tuning):
-PNPX_LIB=tfpnp_amd/libpnpx_tune.so python tools/tune_hs.py [B] [H].  Override hook: PNPX_HS_<MT>_<W>="nbw,nw"."""
+PNPX_LIB=tools/_build/libpnpx_tune.so python tools/tune_hs.py [B] [H].  Override hook: PNPX_HS_<MT>_<W>="nbw,nw"."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

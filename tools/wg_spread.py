@@ -1,6 +1,6 @@
 """Per-workgroup start / end spread of every conv_hs launch of one denoiser forward (tuning build, PNPX_HS_WGT).
 
-usage: PNPX_LIB=tfpnp_amd/libpnpx_tune.so python tools/wg_spread.py [B] [H] [out.txt]
+usage: PNPX_LIB=tools/_build/libpnpx_tune.so python tools/wg_spread.py [B] [H] [out.txt]
 Stamps are wall_clock64() (100 MHz).  Per launch: HIP-event time around the launch, span = max(end) - min(start), the
 spread of the start stamps, and the distribution of per-workgroup busy time -- span minus the median busy time is what a
 perfectly balanced walk with no fill / drain would save."""
