@@ -69,10 +69,13 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *      source inside the 8-wave kernel (tfpnp/pnp/denoiser/models/unet.py:92-121; no up-sampled tensor); 0 = the separate kernel
  *      (results agree to 5e-7).
  *  "fp32_ksplit" (default 1, r6): in conv_mode 0 the layers of the two deepest levels (<= 16 tiles of 64 couts x 16 x 16 px per image)
- *      split their input-channel chunks over 2 or 4 workgroups of the 8-wave kernel; the pieces' partial sums meet in a scratch slab and
- *      the last arriver adds them in piece order (a rule of the layer's geometry alone: per-image results are bit-identical across
- *      batch sizes and launch chains).  Fills the chip at small batches and evens out the 16 x 16 level's rounds at B = 48.
- *      0 = unsplit (a different summation order: 1e-7-class differences).
+ *      can split their input-channel chunks over 4 / 2 workgroups of the 8-wave kernel; the pieces' partial sums go to a scratch slab and
+ *      a second small launch adds them in piece order (deterministic), then bias + activation.
+ *      1 = in calls whose unsplit tiles cannot fill the chip (tiles per image x batch < 256: below 32 images of 256 x 256 at the
+ *      16 x 16 level, below 16 at 32 x 32): -15 % per forward at B = 6, -9 % at 12, nothing changes from 32 images up.  A given image
+ *      gets the same bits in every call of the same class; across the class boundary results differ in the summation order
+ *      (5e-7).  2 = split at every batch size: bit-identical per image across ALL batch sizes, +5 % at 48 x 256^2.  0 = never.
+ *      "fp32_ksplit_rule" (tuning): pieces per tile class.
  *  "range_guard": the half-split kernels carry activations as f16 hi+lo pairs of 16*v, i.e. |v| < 4095.  Their
  *      epilogues set a sticky flag when a stored value leaves that range or is NaN.
  *      1 (default): the flag is looked at (no synchronisation) at the top of the next call; once seen, the context

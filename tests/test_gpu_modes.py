@@ -491,6 +491,56 @@ def test_fp32_launch_chains_are_bit_identical(unet_params):
         ctx.set_option("fp32_chains", 2)
 
 
+def test_fp32_ksplit_is_deterministic_and_batch_independent(unet_params):
+    """r6: the layers of the two deepest levels split their input-channel chunks over 2 / 4 workgroups of the 8-wave
+    Winograd kernel (conv3x3_wino8.hip KSPLIT: every piece writes its output-transformed partial sums to a scratch slab, a second small
+    launch adds the pieces in piece order, then bias + activation).  Option fp32_ksplit: 2 = at every batch size -- per-image results
+    bit-identical across batch sizes and launch chains; 1 (default) = only in calls whose unsplit tiles cannot fill the chip -- a small
+    call reproduces the always-split bits, a large one the unsplit bits; 0 = never.  All within fp32 rounding of the fp64 oracle."""
+    from oracle import pnp_oracle as O
+    from tfpnp_amd.pnp import UNetDenoiser2D
+    den = UNetDenoiser2D(state_dict=unet_params)
+    ctx = den.context(dev())
+    assert ctx.get_option("fp32_ksplit") == 1 and ctx.get_option("conv_mode") == 0
+    p64 = {k: torch.as_tensor(v).double() for k, v in unet_params.items()}
+    try:
+        for (B, H, W) in [(7, 128, 128), (3, 256, 256), (5, 64, 64)]:
+            x, s = denoiser_inputs(B, H, W, 700 + B)
+            xt, st = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
+            outs = {}
+            for k in (0, 2, 1):
+                ctx.set_option("fp32_ksplit", k)
+                outs[k] = den.forward_preclamp(xt, st)[1].clone()
+                for _ in range(3):                                           # which workgroup runs which piece varies; the bits must not
+                    assert torch.equal(den.forward_preclamp(xt, st)[1], outs[k]), (B, H, W, k)
+            assert not torch.equal(outs[2], outs[0]), "the K-split instances did not run"
+            assert torch.equal(outs[1], outs[2]), "a small call must take the split path"
+            with torch.no_grad():
+                sig = torch.from_numpy(s).double().view(B, 1, 1, 1).expand(B, 1, H, W)
+                ref = O.unet_forward(torch.cat([torch.from_numpy(x).double(), sig], 1), p64)
+            assert rel(outs[2].cpu().double(), ref) < 3e-6 and rel(outs[0].cpu().double(), ref) < 3e-6 and rel(outs[2], outs[0]) < 3e-6
+            ctx.set_option("fp32_ksplit", 2)
+            for chains in (0, 2, 3):
+                ctx.set_option("fp32_chains", chains)
+                for n in (1, 2, B - 1):
+                    part = den.forward_preclamp(xt[:n].contiguous(), st[:n].contiguous())[1]
+                    assert torch.equal(part, outs[2][:n]), (B, H, W, chains, n)
+            ctx.set_option("fp32_chains", 2)
+        # a call large enough that no layer is short of tiles (128 x 128: >= 64 images) takes the unsplit path in the default mode
+        x, s = denoiser_inputs(64, 128, 128, 9)
+        xt, st = torch.from_numpy(x).to(dev()), torch.from_numpy(s).to(dev())
+        ctx.set_option("fp32_ksplit", 0)
+        a = den(xt, st).clone()
+        ctx.set_option("fp32_ksplit", 1)
+        assert torch.equal(den(xt, st), a)
+        ctx.set_option("fp32_ksplit", 2)
+        b = den(xt, st)
+        assert not torch.equal(b, a) and rel(b, a) < 3e-6
+    finally:
+        ctx.set_option("fp32_ksplit", 1)
+        ctx.set_option("fp32_chains", 2)
+
+
 @pytest.mark.parametrize("mode", [1, 0])
 def test_solver_call_replays_from_a_hip_graph(unet_params, mode):
     """A solver call launches on the caller's stream (+ side streams forked and joined by events for the launch chains) and, once its

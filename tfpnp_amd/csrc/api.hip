@@ -255,8 +255,12 @@ int pnpx_ctx_set_option(pnpx_ctx* ctx, const char* key, int value) {
     ctx->opt_fp32_fuse_up = value;
     return PNPX_OK;
   }
-  if (is("fp32_ksplit") && (value == 0 || value == 1)) {
+  if (is("fp32_ksplit") && value >= 0 && value <= 2) {
     ctx->opt_fp32_ksplit = value;
+    return PNPX_OK;
+  }
+  if (is("fp32_ksplit_rule") && value >= 1 && value < 256) {      // tuning: 1 the default rule, else pieces per tile class (conv3x3_wino8_ksplit)
+    ctx->opt_ksplit_rule = value;
     return PNPX_OK;
   }
   if (is("fp32_wino8_layers") && value >= 0 && value < (1 << 27)) {     // bit li: layer li on the 8-wave Winograd kernel
@@ -331,6 +335,7 @@ int pnpx_ctx_get_option(pnpx_ctx* ctx, const char* key, int* value) {
   else if (is("fp32_wino8_layers")) *value = ctx->opt_fp32_wino8;
   else if (is("fp32_fuse_up")) *value = ctx->opt_fp32_fuse_up;
   else if (is("fp32_ksplit")) *value = ctx->opt_fp32_ksplit;
+  else if (is("fp32_ksplit_rule")) *value = ctx->opt_ksplit_rule;
   else if (is("fp32_chains")) *value = ctx->opt_fp32_chains;
   else if (is("fft_tile")) *value = ctx->opt_fft_tile;
   else if (is("range_guard")) *value = ctx->opt_range_guard;

@@ -205,8 +205,9 @@ struct pnpx_ctx {
   int opt_fp32_chains = 2;         // conv_mode 0: n >= 2 = the forward as n launch chains over slices of the batch (default 2: this family is not
                                    // power-capped, a second chain fills the other's tails and partial rounds: 8.76 -> 8.44 ms at 48 x 256^2, -7 % at
                                    // B = 24; 3 and 4 chains measured slower); 1 = only the bottom level forks two chains; 0 = one chain
-  int opt_fp32_ksplit = 1;         // conv_mode 0, r6: the deep levels' layers split their channel chunks over 2 / 4 work items (conv3x3_wino8.hip KSPLIT;
-                                   // a rule of the layer's geometry, not of the batch); 0 = unsplit (a different summation tree: not bit-identical to 1)
+  int opt_fp32_ksplit = 1;         // conv_mode 0, r6: the deep levels' layers split their channel chunks over 2 / 4 work items (conv3x3_wino8.hip KSPLIT):
+                                   // 1 = in calls whose unsplit tiles cannot fill the chip, 2 = always (bit-identical across all batch sizes), 0 = never
+  int opt_ksplit_rule = 1;         // tuning: pieces per tile class (conv3x3_wino8_ksplit; 1 = the default rule)
   int opt_fp32_fuse_up = 1;        // conv_mode 0: the decoder entries up-sample their second source inside the 8-wave Winograd kernel (no up-sampled tensor)
   pnpx::ConvLayer conv_bwd[27];    // adjoint (input-gradient) convolutions, fp32 kernel family
   pnpx::ConvLayerHsDev conv_hs_bwd[27];  // ... and packed for the half-split kernel family

@@ -61,11 +61,10 @@ int launch_conv3x3_wino_outc(const float* u, const float* bias, const float* in0
 bool conv3x3_wino8_ok(int C0, int C1, int cout, int H, int W);
 int launch_conv3x3_wino8(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
                          float* out, int B, int H, int W, hipStream_t s, float slope = 0.2f, const float* res = nullptr,
-                         float* pool_out = nullptr, float* ks_part = nullptr, unsigned* ks_cnt = nullptr);
+                         float* pool_out = nullptr, float* ks_part = nullptr, int ks_rule = 1);
 // r6: K-split of the deep levels' layers (a rule of the layer's geometry alone; 1 = no split) and the scratch a caller provides for it
-int conv3x3_wino8_ksplit(int C0, int C1, int cout, int H, int W);
+int conv3x3_wino8_ksplit(int C0, int C1, int cout, int H, int W, int rule = 1);
 size_t conv3x3_wino8_ksplit_bytes_per_image();
-size_t conv3x3_wino8_ksplit_counters_per_image();
 int launch_conv3x3_wino8_grad(const float* u, const float* zero_bias, int cout, const float* gin, int cin, float* gout, const float* dmask,
                               float mask_slope, int B, int H, int W, hipStream_t s);
 bool conv3x3_wino8_ups_ok(int C0, int C1, int cout, int H, int W);

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     const float* s1u;  // UPS: origin of the low-resolution window in the second source, pre-offset by -C0 channels
     int ok, rlo;       // (ints, no tail padding: a struct copy with padding bytes goes through scratch)
     int clo, c0;       // c0 (KSPLIT): first channel chunk of this work item
-    int item, g;       // KSPLIT: tile number (scratch slab / arrival counters) and piece
+    int item, g;       // KSPLIT: tile number (scratch slab) and piece
   };
   const int hpwp_lo = UPS ? (a.ups_h + 2) * (a.ups_w + 2 * PADL) : 0;
   auto decode = [&](int k) {
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
         const float bias = bias_r[j];
         float y00 = (lo[0] + lo[1]) + hi[0], y01 = (lo[1] - hi[0]) - hi[1];
         float y10 = (lo[2] + lo[3]) + hi[2], y11 = (lo[3] - hi[2]) - hi[3];
-        if (KSPLIT) {      // this piece's share of the sums over the input channels: finished below by the wave that arrives last
+        if (KSPLIT) {      // this piece's share of the sums over the input channels: wino8_ksplit_finish_kernel adds the pieces
           *reinterpret_cast<f32x4*>(part_mine + j * 256) = (f32x4){y00, y01, y10, y11};
           return;
         }
@@ -681,47 +681,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
           if (a.pool) pb[(size_t)co * HpWp_pool] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));   // same association as maxpool2_kernel
         }
       });
-      if (KSPLIT) {
-        // Arrival: this wave's eight partial rows are in memory (vmcnt(0) + release fence), then one agent-scope counter per
-        // (tile, wave).  The wave that finds ksplit - 1 earlier arrivals reads all pieces back (its own included: one code path, one
-        // summation order -- piece 0 + piece 1 [+ piece 2 + piece 3], left to right, whoever arrives last) and finishes the rows.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        unsigned* const cnt = a.part_cnt + (size_t)T.item * 8 + wave;
-        unsigned seen = 0;
-        if (lane == 0) seen = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seen = __builtin_amdgcn_readfirstlane(seen);
-        if (seen == (unsigned)(a.ksplit - 1)) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-          const int G = a.ksplit;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int R = R0 + j;
-            const int co = cbase + (R & 3) + 8 * (R >> 2);
-            f32x4 y = *reinterpret_cast<const f32x4*>(part_tile + j * 256);
-            for (int g = 1; g < G; ++g) {
-              const f32x4 pg = *reinterpret_cast<const f32x4*>(part_tile + (size_t)g * (8 * 2048) + j * 256);
-              y[0] += pg[0];
-              y[1] += pg[1];
-              y[2] += pg[2];
-              y[3] += pg[3];
-            }
-            const float bias = bias_r[j];
-            float y00 = y[0] + bias, y01 = y[1] + bias, y10 = y[2] + bias, y11 = y[3] + bias;
-            y00 = fmaxf(y00, y00 * a.slope);
-            y01 = fmaxf(y01, y01 * a.slope);
-            y10 = fmaxf(y10, y10 * a.slope);
-            y11 = fmaxf(y11, y11 * a.slope);
-            float* o = ob + (size_t)co * HpWp;
-            *reinterpret_cast<f32x2*>(o) = (f32x2){y00, y01};
-            *reinterpret_cast<f32x2*>(o + a.Wp) = (f32x2){y10, y11};
-            if (a.pool) pb[(size_t)co * HpWp_pool] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
-          }
-        }
-        // the stage waits that follow count no epilogue stores for these instances (NST = 0): the queue is empty here
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
       WINO8_STAMP(19);
       if (FUSE_OUTC) {
         // this wave holds couts 16 P .. 16 P + 15 (4 kg + (R & 3) + 8 (R >> 2)): the other lane half, then the other wave (through LDS)
@@ -762,7 +721,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
     };
 
     // VMEM operations a DMA wave leaves in its queue across an epilogue (its stores); halo gathers per DMA wave (wave 0: one more)
-    constexpr int NST = KSPLIT ? 0 : (FUSE_OUTC ? (P == 0 ? 4 : 0) : 16);
+    constexpr int NST = KSPLIT ? 8 : (FUSE_OUTC ? (P == 0 ? 4 : 0) : 16);      // (KSPLIT: the eight partial rows)
     constexpr int NRAW = C::NRAW;
 
     int k = 0;
@@ -895,6 +854,54 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
   else body(I1{});
 }
 
+// K-split, second launch: out = act(bias + piece 0 + piece 1 [+ piece 2 + piece 3]) per output, pieces added left to right (a fixed
+// order: the bits do not depend on which workgroup ran which piece, or when).  One workgroup per tile, the thread <-> output map of the main
+// kernel's epilogue (wave = 4 P + sw: cout half wm = sw & 1, tile half wn = sw >> 1; lane: tile l31, cout group kg; the wave's rows
+// R = 8 P + j), so every load is the 16-byte record its writer stored: [tile][piece][wave][row][lane] f32x4.
+// A kernel boundary, not an in-kernel arrival protocol: the protocol (write-through sc1 slab stores, device-scope counter per (tile,
+// wave), last arriver sums) was built first and measured -- the returned atomic and the drained stores cost ~6 us per work item with
+// nothing to hide them behind (+19 % on the split layers at B = 48), and an agent-scope release fence instead (buffer_wbl2) ~60 us per
+// item under this kernel's output traffic (profiles/r6_ksplit.md).  The boundary costs ~2 us per split layer.
+__global__ __launch_bounds__(512) void wino8_ksplit_finish_kernel(WinoArgs a) {
+  using C = Cfg8<64>;
+  const int item = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int reg = item / a.nct, ct = item - reg * a.nct;
+  const int t1 = reg / a.rx, txr = reg - t1 * a.rx, b = t1 / a.ry, tyr = t1 - b * a.ry;
+  const int x0 = txr * C::RPXW, y0 = tyr * 16;
+  const int P = wave >> 2, sw = wave & 3, wm = sw & 1, wn = sw >> 1, l31 = lane & 31, kg = lane >> 5;
+  const int tile = wn * 32 + l31, ty = tile / C::TX, tx = tile % C::TX;
+  const int cbase = ct * 64 + wm * 32 + 4 * kg;
+  const size_t HpWp = (size_t)a.Hp * a.Wp;
+  float* ob = a.out + ((size_t)b * a.Cout) * HpWp + (size_t)(y0 + 2 * ty + 1) * a.Wp + x0 + 2 * tx + PADL;
+  const int Hp_pool = padded_h(a.H / 2), Wp_pool = padded_w(a.W / 2);
+  const size_t HpWp_pool = (size_t)Hp_pool * Wp_pool;
+  float* pb = a.pool ? a.pool + (size_t)b * a.Cout * HpWp_pool + (size_t)(y0 / 2 + ty + 1) * Wp_pool + x0 / 2 + tx + PADL : nullptr;
+  const float* part = a.part + ((size_t)item * a.ksplit * 8 + wave) * 2048 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int R = 8 * P + j;
+    const int co = cbase + (R & 3) + 8 * (R >> 2);
+    f32x4 y = *reinterpret_cast<const f32x4*>(part + j * 256);
+    for (int g = 1; g < a.ksplit; ++g) {
+      const f32x4 pg = *reinterpret_cast<const f32x4*>(part + (size_t)g * (8 * 2048) + j * 256);
+      y[0] += pg[0];
+      y[1] += pg[1];
+      y[2] += pg[2];
+      y[3] += pg[3];
+    }
+    const float bias = a.bias[co];
+    float y00 = y[0] + bias, y01 = y[1] + bias, y10 = y[2] + bias, y11 = y[3] + bias;
+    y00 = fmaxf(y00, y00 * a.slope);
+    y01 = fmaxf(y01, y01 * a.slope);
+    y10 = fmaxf(y10, y10 * a.slope);
+    y11 = fmaxf(y11, y11 * a.slope);
+    float* o = ob + (size_t)co * HpWp;
+    *reinterpret_cast<f32x2*>(o) = (f32x2){y00, y01};
+    *reinterpret_cast<f32x2*>(o + a.Wp) = (f32x2){y10, y11};
+    if (a.pool) pb[(size_t)co * HpWp_pool] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));   // same association as maxpool2_kernel
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -914,15 +921,19 @@ bool conv3x3_wino8_ok(int C0, int C1, int cout, int H, int W) { return wino8_ct(
 // -> 4 pieces, <= 16 (32 x 32: four regions x 4) -> 2; every piece keeps >= 4 chunks.  At B = 48 this turns the 16 x 16 level's 384 tiles
 // on 256 workgroups (two rounds for 1.5 rounds of work) into 1536 quarter-tiles = 6 even rounds; at B = 6 it puts 192 instead of 48 / 96
 // workgroups on the chip.
-int conv3x3_wino8_ksplit(int C0, int C1, int cout, int H, int W) {
-  if (wino8_ct(C0, C1, cout, H, W) != 64) return 1;
+// rule: 1 = the default (4 pieces up to 8 tiles per image, 2 up to 16); any other value (tuning) = pieces for t <= 8 in bits 0-3, for
+// t <= 16 in bits 4-7.
+int conv3x3_wino8_ksplit(int C0, int C1, int cout, int H, int W, int rule) {
+  if (wino8_ct(C0, C1, cout, H, W) != 64 || rule <= 0) return 1;
   const int t = (H / 16) * (W / 16) * (cout / 64), nch = (C0 + C1) / 16;
-  int g = t <= 8 ? 4 : (t <= 16 ? 2 : 1);
+  const int g8 = rule == 1 ? 4 : (rule & 15), g16 = rule == 1 ? 2 : ((rule >> 4) & 15);
+  int g = t <= 8 ? g8 : (t <= 16 ? g16 : 1);
+  if (g != 1 && g != 2 && g != 4) g = 1;
+  while (g > 1 && g * t > 32) g /= 2;      // the scratch slab holds 32 (tile, piece) slots per image
   while (g > 1 && (nch % g != 0 || nch / g < 4)) g /= 2;
   return g;
 }
 size_t conv3x3_wino8_ksplit_bytes_per_image() { return (size_t)32 * 8 * 2048 * sizeof(float); }     // <= 32 (tile, piece) slots of 64 KiB
-size_t conv3x3_wino8_ksplit_counters_per_image() { return 16 * 8; }                                  // <= 16 tiles x 8 waves
 
 template <int CT, bool FUSE_OUTC, bool RES, bool UPS = false, bool KSPLIT = false>
 static int launch_wino8(WinoArgs a, hipStream_t s) {
@@ -946,12 +957,16 @@ static int launch_wino8(WinoArgs a, hipStream_t s) {
     PNPX_HIP(e);
   }
   const int vnct = a.nct * a.ksplit;                 // work items per region
-  const long long ntiles = (long long)a.rx * a.ry * a.B * vnct;
+  const long long nreg = (long long)a.rx * a.ry * a.B, ntiles = nreg * vnct;
   long long grid = 256;
   if (grid >= ntiles) grid = ntiles;
   else if ((grid / 8) % vnct != 0 && grid >= 8LL * vnct) grid -= grid % (8 * vnct);
   hipLaunchKernelGGL((conv3x3_wino8_f32_kernel<CT, FUSE_OUTC, RES, UPS, KSPLIT>), dim3((unsigned)grid), dim3(512), LDS_REQ8, s, a);
   PNPX_LAUNCH_CHECK();
+  if (KSPLIT) {
+    hipLaunchKernelGGL(wino8_ksplit_finish_kernel, dim3((unsigned)(nreg * a.nct)), dim3(512), 0, s, a);
+    PNPX_LAUNCH_CHECK();
+  }
   return PNPX_OK;
 }
 
@@ -1057,7 +1072,7 @@ int launch_conv3x3_wino8_grad(const float* u, const float* zero_bias, int cout, 
 
 int launch_conv3x3_wino8(const float* u, const float* bias, int cout, const float* in0, int C0, const float* in1, int C1,
                          float* out, int B, int H, int W, hipStream_t s, float slope, const float* res, float* pool_out, float* ks_part,
-                         unsigned* ks_cnt) {
+                         int ks_rule) {
   const int ct = wino8_ct(C0, C1, cout, H, W);
   if (!ct) {
     set_error("conv3x3_wino8: unsupported geometry (%d + %d -> %d channels, %d x %d)", C0, C1, cout, H, W);
@@ -1081,13 +1096,12 @@ int launch_conv3x3_wino8(const float* u, const float* bias, int cout, const floa
   a.Cout = cout;
   a.slope = slope;
   if (res) return ct == 64 ? launch_wino8<64, false, true>(a, s) : launch_wino8<32, false, true>(a, s);
-  // K-split instances: when the caller hands over the scratch slab + arrival counters (>= conv3x3_wino8_ksplit_bytes_per_image() /
-  // _counters_per_image() per image of the batch, counters zero) and the layer's geometry calls for it
-  const int g = (ks_part && ks_cnt) ? conv3x3_wino8_ksplit(C0, C1, cout, H, W) : 1;
+  // K-split instances: when the caller hands over the scratch slab (>= conv3x3_wino8_ksplit_bytes_per_image() per image of the batch)
+  // and the layer's geometry calls for it
+  const int g = ks_part ? conv3x3_wino8_ksplit(C0, C1, cout, H, W, ks_rule) : 1;
   if (g > 1) {
     a.ksplit = g;
     a.part = ks_part;
-    a.part_cnt = ks_cnt;
     return launch_wino8<64, false, false, false, true>(a, s);
   }
   return ct == 64 ? launch_wino8<64, false, false>(a, s) : launch_wino8<32, false, false>(a, s);

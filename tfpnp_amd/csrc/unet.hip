@@ -615,13 +615,20 @@ static int unet_forward_hs(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, cons
 // fp32 forward pass (conv_mode 0) over B images that are images b_base .. b_base + B - 1 of the arena (x / sigma / out already point at the
 // first of them): the whole batch, or one of two launch chains (unet_denoise).  level_chains: the bottom level may fork two chains itself.
 static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, const float* x, const float* sigma, int sigma_stride, float* out,
-                            float* out_pre, int B, int H, int W, hipStream_t s, Recorder& rec, bool keep_all, bool level_chains, int b_base = 0) {
+                            float* out_pre, int B, int H, int W, hipStream_t s, Recorder& rec, bool keep_all, bool level_chains, int b_base = 0, int B_call = 0) {
+  if (B_call <= 0) B_call = B;      // the whole call's batch (this may be one launch chain's slice of it)
   // ---- plain-fp32 path (conv_mode 0): padded planar fp32 activations, whole batch per launch
   char* A = static_cast<char*>(ar.buf.p);
   auto fptr = [&](const Act& d) { return reinterpret_cast<float*>(A + d.off + (size_t)b_base * act_bytes_per_image(CONV_F32, d.C, d.H, d.W)); };
-  // r6: scratch of the K-split launches (this slice's images; option fp32_ksplit = 0 hands none over: the layers then run unsplit)
-  float* const ks_part = ctx->opt_fp32_ksplit ? reinterpret_cast<float*>(A + P.ks_part + (size_t)b_base * P.ks_part_per_image) : nullptr;
-  unsigned* const ks_cnt = ctx->opt_fp32_ksplit ? reinterpret_cast<unsigned*>(A + P.ks_cnt + (size_t)b_base * P.ks_cnt_per_image) : nullptr;
+  // r6: scratch of the K-split launches (this slice's images).  Option fp32_ksplit: 0 = never; 1 (default) = the layers whose unsplit
+  // tiles cannot fill the chip for THIS call's batch (tiles per image x B_call < 256: launch chains beside each other count as one call);
+  // 2 = every layer the geometry rule names, at every batch size (per-image results then bit-identical across ALL batch sizes; costs
+  // 4 % at 48 x 256^2, where the extra epilogues and the slab round trip buy nothing: profiles/r6_ksplit.md)
+  float* const ks_part0 = reinterpret_cast<float*>(A + P.ks_part + (size_t)b_base * P.ks_part_per_image);
+  auto ks_on = [&](int cout, int h, int w) {
+    if (ctx->opt_fp32_ksplit == 2) return true;
+    return ctx->opt_fp32_ksplit == 1 && (long long)(h / 16) * (w / 16) * (cout / 64) * B_call < 256;
+  };
   // the first convolution (2 -> 32 channels) straight from the fp32 image on the vector ALU (training forwards too: the VJP needs the
   // layer's output, not its padded input tensor)
   const bool first_valu = ctx->opt_fuse_first && W % 4 == 0 && ctx->conv[0].cout == 32;
@@ -639,9 +646,11 @@ static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, con
     if (pooled_done) *pooled_done = false;
     if (ctx->opt_fp32_winograd && ctx->conv_wino_u[li] && conv3x3_wino_ok(i0.C, C1, L.cout, o.H, o.W)) {
       const bool w8 = ((ctx->opt_fp32_wino8 >> li) & 1) && conv3x3_wino8_ok(i0.C, C1, L.cout, o.H, o.W);
-      if (w8)
+      if (w8) {
+        const bool ks = ks_on(L.cout, o.H, o.W);
         PNPX_TRY(launch_conv3x3_wino8(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1, fptr(o), B, o.H, o.W, s, 0.2f,
-                                      nullptr, pooled ? fptr(*pooled) : nullptr, ks_part, ks_cnt));
+                                      nullptr, pooled ? fptr(*pooled) : nullptr, ks ? ks_part0 : nullptr, ctx->opt_ksplit_rule));
+      }
       else
         PNPX_TRY(launch_conv3x3_wino(ctx->conv_wino_u[li], L.b, L.cout, fptr(i0), i0.C, i1 ? fptr(*i1) : nullptr, C1, fptr(o), B, o.H, o.W, s, 0.2f,
                                      nullptr, pooled ? fptr(*pooled) : nullptr));
@@ -691,8 +700,8 @@ static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, con
             const ConvLayer& L = ctx->conv[li];
             return launch_conv3x3_wino8(ctx->conv_wino_u[li], L.b, L.cout, fptr(i) + (size_t)lo * i.C * padded_h(i.H) * padded_w(i.W), i.C, nullptr, 0,
                                         fptr(o) + (size_t)lo * o.C * padded_h(o.H) * padded_w(o.W), hi - lo, o.H, o.W, st, 0.2f, nullptr, nullptr,
-                                        ks_part ? ks_part + (size_t)lo * (P.ks_part_per_image / sizeof(float)) : nullptr,
-                                        ks_cnt ? ks_cnt + (size_t)lo * (P.ks_cnt_per_image / sizeof(unsigned)) : nullptr);
+                                        ks_on(o.C, o.H, o.W) ? ks_part0 + (size_t)lo * (P.ks_part_per_image / sizeof(float)) : nullptr,
+                                        ctx->opt_ksplit_rule);
           };
           PNPX_TRY(slice(12, P.p[4], P.a[4]));
           PNPX_TRY(slice(13, P.a[4], P.b[4]));
@@ -854,7 +863,7 @@ int unet_denoise(pnpx_ctx* ctx, const float* x, const float* sigma, int sigma_st
     return fan_out_chains(ctx, ctx->opt_fp32_chains, B, s, [&](int lo, int hi, hipStream_t st) -> int {
       Recorder none{nullptr, st};
       return unet_forward_f32(ctx, ar, P, x + lo * px, sigma + (size_t)lo * sigma_stride, sigma_stride, out + lo * px,
-                              out_pre ? out_pre + lo * px : nullptr, hi - lo, H, W, st, none, keep_all, false, lo);
+                              out_pre ? out_pre + lo * px : nullptr, hi - lo, H, W, st, none, keep_all, false, lo, B);
     });
   }
   return unet_forward_f32(ctx, ar, P, x, sigma, sigma_stride, out, out_pre, B, H, W, s, rec, keep_all, !prof && ctx->opt_fp32_chains == 1);

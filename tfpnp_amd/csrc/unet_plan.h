@@ -19,12 +19,11 @@ struct UNetPlan {
   Act u[4];               // upsampled decoder inputs at level l (l <= 3): channels 64<<l
   Act y[4];               // decoder outputs at level l (l <= 3)
   size_t total = 0;       // bytes, for capB images
-  // conv_mode 0, r6: scratch of the K-split Winograd launches (conv3x3_wino8.hip KSPLIT): partial-sum slab and arrival counters, per image
-  size_t ks_part = 0, ks_cnt = 0;
-  size_t ks_part_per_image = 0, ks_cnt_per_image = 0;      // bytes
+  // conv_mode 0, r6: scratch of the K-split Winograd launches (conv3x3_wino8.hip KSPLIT): the partial-sum slab, per image
+  size_t ks_part = 0;
+  size_t ks_part_per_image = 0;      // bytes
 };
 size_t conv3x3_wino8_ksplit_bytes_per_image();
-size_t conv3x3_wino8_ksplit_counters_per_image();
 
 inline size_t act_bytes_per_image(int mode, int C, int h, int w) {
   if (mode == CONV_HS) return (size_t)((C + 7) / 8) * (h + 2) * (w + 2) * 32;
@@ -59,11 +58,8 @@ inline UNetPlan make_plan(int mode, int capB, int H, int W) {
   off += 1u << 20;             // 1 MiB slack: overhanging tiles read (never write) past their tensor
   if (mode != CONV_HS) {
     P.ks_part_per_image = conv3x3_wino8_ksplit_bytes_per_image();
-    P.ks_cnt_per_image = conv3x3_wino8_ksplit_counters_per_image() * sizeof(unsigned);
     P.ks_part = off;
     off += P.ks_part_per_image * (size_t)capB;
-    P.ks_cnt = off;
-    off += (P.ks_cnt_per_image * (size_t)capB + 255) & ~(size_t)255;
   }
   P.total = off;
   return P;

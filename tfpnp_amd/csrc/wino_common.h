@@ -40,10 +40,9 @@ struct WinoArgs {
   float mask_slope;
   // KSPLIT instances of the 8-wave kernel (r6): the channel chunks of a tile are dealt to `ksplit` work items (nch = chunks per item,
   // nch_all = per tile); every item writes its output-transformed partial sums to `part` ([tile][piece][wave][row 8][lane 64] f32x4) and
-  // the wave that arrives last at `part_cnt[tile * 8 + wave]` adds the pieces in piece order, then bias + activation + stores
+  // a second launch (wino8_ksplit_finish_kernel) adds the pieces in piece order, then bias + activation + stores
   int ksplit, nch_all;
   float* part;
-  unsigned* part_cnt;
 };
 
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the builtin widens every lane offset to a
