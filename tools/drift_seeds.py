@@ -2,7 +2,7 @@
 For every seed and both convolution families: HIP vs the fp64 oracle, HIP vs the fp32 CPU oracle (the distance north_star's 1e-4
 is stated on) and the fp32 CPU oracle vs fp64 (the yardstick: what fp32 arithmetic itself drifts by on this chaotic map).
 Same case as tests/test_gpu_modes.py::test_csmri_episode_drift_not_worse_than_fp32 (B = 2, 64 x 64, 6 x 5 iterations).
-usage: drift_seeds.py [n_seeds] > profiles/r5_drift_seeds.md      (GPU box only)"""
+usage: drift_seeds.py [n_seeds] > profiles/r6_drift_seeds.md      (GPU box only)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,6 +12,7 @@ from tfpnp_amd.pnp import UNetDenoiser2D
 from tfpnp_amd.tasks.csmri import ADMMSolver_CSMRI
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+torch.set_num_threads(16)
 dev = torch.device("cuda:0")
 params = synth.make_unet_params(0)
 B, H, W = 2, 64, 64
@@ -42,9 +43,9 @@ for seed in range(31, 31 + n_seeds):
             v = sol((v, (g(d["y0"]), g(d["mask"]))), (g(a["sigma_d"]), g(a["mu"])))
         out = sol.get_output(v).double().cpu()
         rows.append((seed, mode, rel(out, ref64), rel(out, ref32), e_cpu))
-print("# r5: 30-iteration CS-MRI ADMM drift on the expansive (He-scaled) synthetic UNet, per seed\n")
+print("# r6: 30-iteration CS-MRI ADMM drift on the expansive (He-scaled) synthetic UNet, per seed\n")
 print("`python tools/drift_seeds.py %d` on one MI355X (B = 2, 64 x 64, 6 x 5 iterations, radial x4; relative L2 of the reconstructed image)." % n_seeds)
-print("conv_mode 1 = half-split f16 x 3 MFMA (default), 0 = fp32 arithmetic (8-wave Winograd + direct fp32 MFMA kernels).")
+print("conv_mode 0 = fp32 arithmetic (the DEFAULT since r6: 8-wave Winograd incl. the K-split deep levels + direct fp32 MFMA kernels), 1 = the opt-in fast mode (half-split f16 x 3 MFMA).")
 print("`cpu32` = the fp32 CPU oracle (= the reference's arithmetic, `tasks/csmri/solver.py:43-55`), `fp64` = the same oracle in double.\n")
 print("| seed | conv_mode | HIP vs fp64 | HIP vs cpu32 | cpu32 vs fp64 | HIP-vs-fp64 / cpu32-vs-fp64 |")
 print("|---|---|---|---|---|---|")
