@@ -109,6 +109,82 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
   g_src[o] = acc * dlrelu(act_at(src_act, b, C, c, h, w, ys, xs));
 }
 
+// r6: the same adjoint from an LDS window (fp32 family; at 48 x 256^2 the plain kernel above spent 1.4 ms on the full-resolution level --
+// 25 scattered L1 reads and 49 loop iterations per source pixel -- 2.4 ms of the 13 ms backward pass per iteration).  A workgroup = one
+// 16 x 16 tile of source pixels of one (image, channel): the 38 x 38 window of destination pixels is read once, coalesced, into two
+// column-parity planes (the 16 lanes of a tile row read every second window column: consecutive words of one plane); the seven candidate
+// row / column weights are computed once per thread with the plain kernel's float arithmetic and the 7 x 7 loop keeps its accumulation
+// order, so the result is bit-identical to upsample_bwd_kernel.
+// Tile = 16 rows x TX columns of source pixels (TX = 64 where the level is that wide: 536-byte window rows, 1.24x the useful bytes read;
+// 16 x 16 tiles read 1.41x in 152-byte pieces), 256 threads x TX / 16 pixels each.
+constexpr int UBF_T = 16;
+template <int TX>
+__global__ __launch_bounds__(256) void upsample_bwd_lds_kernel(const float* __restrict__ gcat, int Ccat, int c_off, const float* __restrict__ src_act,
+                                                               float* __restrict__ g_src, int C, int h, int w, int Ht, int Wt, float sy, float sx) {
+  constexpr int WH = 2 * UBF_T + 6, WW = 2 * TX + 6, WP = WW / 2 + 1;      // window rows / columns, plane row stride (words)
+  __shared__ float win[2][WH][WP];
+  const int c = blockIdx.z % C;
+  const size_t b = blockIdx.z / C;
+  const int xs0 = blockIdx.x * TX, ys0 = blockIdx.y * UBF_T;
+  const int H = 2 * h, W = 2 * w;
+  const int Hp = padded_h(Ht), Wp = padded_w(Wt), hp = padded_h(h), wp = padded_w(w);
+  const float* g = gcat + (b * Ccat + c_off + c) * (size_t)Hp * Wp;
+  const int wy0 = 2 * ys0 - 3, wx0 = 2 * xs0 - 3;            // window origin (may be negative: clamped entries carry weight 0)
+  for (int k = threadIdx.x; k < WH * WW; k += 256) {
+    const int ry = k / WW, rx = k - ry * WW;
+    const int yd = min(max(wy0 + ry, 0), H - 1), xd = min(max(wx0 + rx, 0), W - 1);
+    win[rx & 1][ry][rx >> 1] = g[(size_t)(yd + 1) * Wp + xd + PADL];
+  }
+  __syncthreads();
+  const int ys = ys0 + (threadIdx.x / 16);
+  if (ys >= h) return;
+  float wyv[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int yd = 2 * ys - 3 + i;
+    wyv[i] = 0.f;
+    if (yd >= 0 && yd < H) {
+      const float fy = sy * yd;
+      const int y0 = (int)fy;
+      const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+      const float ly = fy - y0;
+      if (y0 == ys) wyv[i] += 1.f - ly;
+      if (y1 == ys) wyv[i] += ly;
+    }
+  }
+  const int oy = 2 * (ys - ys0);
+#pragma unroll
+  for (int kx = 0; kx < TX / 16; ++kx) {
+    const int xs = xs0 + (threadIdx.x % 16) + 16 * kx;
+    if (xs >= w) continue;
+    float wxv[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int xd = 2 * xs - 3 + i;
+      wxv[i] = 0.f;
+      if (xd >= 0 && xd < W) {
+        const float fx = sx * xd;
+        const int x0 = (int)fx;
+        const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float lx = fx - x0;
+        if (x0 == xs) wxv[i] += 1.f - lx;
+        if (x1 == xs) wxv[i] += lx;
+      }
+    }
+    const int ox = 2 * (xs - xs0);       // window position of candidate (0, 0)
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      if (wyv[i] == 0.f) continue;
+#pragma unroll
+      for (int j = 0; j < 7; ++j)
+        if (wxv[j] != 0.f) acc += wyv[i] * wxv[j] * win[(ox + j) & 1][oy + i][(ox + j) >> 1];
+    }
+    const size_t o = (b * C + c) * (size_t)hp * wp + (size_t)(ys + 1) * wp + xs + PADL;
+    g_src[o] = acc * dlrelu(src_act[o]);
+  }
+}
+
 // Gradient reaching an encoder output x[l] (H x W, C channels): the skip part of the decoder's concat gradient
 // (channels [0, C) of gcat) plus, for l < 4, the max-pool routing of g_pool (first maximum in scan order, like ATen),
 // all times lrelu'(x[l]).
@@ -147,6 +223,49 @@ __global__ __launch_bounds__(256) void skip_pool_merge_kernel(const float* __res
     }
   }
   g_x[o] = g * dlrelu(act_at(xact, b, C, c, H, W, y, x));
+}
+
+// r6: the same for fp32 planar tensors with even H, W, one thread per 2 x 2 block (the max-pool window): the four saved activations, the
+// two gradient rows and the pooled gradient are read once per block as 8-byte pieces instead of once per pixel (1.1 ms per backward pass
+// at 48 x 256^2 before); same arithmetic per pixel, bit-identical.
+__global__ __launch_bounds__(256) void skip_pool_merge_f32_kernel(const float* __restrict__ gcat, int Ccat, const float* __restrict__ g_pool,
+                                                                  const float* __restrict__ xact, float* __restrict__ g_x, int C, int H, int W,
+                                                                  size_t nblk) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblk) return;
+  const int Wo = W / 2, Ho = H / 2;
+  const int xo = (int)(i % Wo);
+  size_t t = i / Wo;
+  const int yo = (int)(t % Ho);
+  t /= Ho;
+  const int c = (int)(t % C);
+  const size_t b = t / C;
+  const int Hp = padded_h(H), Wp = padded_w(W);
+  const size_t plane = (size_t)Hp * Wp;
+  const size_t o = (b * C + c) * plane + (size_t)(2 * yo + 1) * Wp + 2 * xo + PADL;
+  const f2 a0 = *reinterpret_cast<const f2*>(xact + o), a1 = *reinterpret_cast<const f2*>(xact + o + Wp);
+  f2 g0 = {0.f, 0.f}, g1v = {0.f, 0.f};
+  if (gcat) {
+    const size_t oc = (b * Ccat + c) * plane + (size_t)(2 * yo + 1) * Wp + 2 * xo + PADL;
+    g0 = *reinterpret_cast<const f2*>(gcat + oc);
+    g1v = *reinterpret_cast<const f2*>(gcat + oc + Wp);
+  }
+  if (g_pool) {
+    int arg = 0;
+    float m = a0[0];
+    if (a0[1] > m) { m = a0[1]; arg = 1; }
+    if (a1[0] > m) { m = a1[0]; arg = 2; }
+    if (a1[1] > m) { m = a1[1]; arg = 3; }
+    const int Hpo = padded_h(Ho), Wpo = padded_w(Wo);
+    const float gpv = g_pool[(b * C + c) * (size_t)Hpo * Wpo + (size_t)(yo + 1) * Wpo + xo + PADL];
+    if (arg == 0) g0[0] += gpv;
+    else if (arg == 1) g0[1] += gpv;
+    else if (arg == 2) g1v[0] += gpv;
+    else g1v[1] += gpv;
+  }
+  *reinterpret_cast<f2*>(g_x + o) = (f2){g0[0] * dlrelu(a0[0]), g0[1] * dlrelu(a0[1])};
+  *reinterpret_cast<f2*>(g_x + o + Wp) = (f2){g1v[0] * dlrelu(a1[0]), g1v[1] * dlrelu(a1[1])};
 }
 
 // gx = g_in0[:, 0] + g_res;  gsigma[b] = sum over pixels of g_in0[:, 1]   (two-stage, deterministic)
@@ -566,16 +685,30 @@ int unet_denoise_backward(pnpx_ctx* ctx, const float* x, const float* sigma, int
     const float sy = (2 * h > 1) ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     const float sx = (2 * w > 1) ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
     const size_t n = (size_t)B * Cb * h * w;
-    hipLaunchKernelGGL(upsample_bwd_kernel, g1(n), dim3(256), 0, s, gp(G.cat[l]), G.cat[l].C, F.x[l].C, sa(below_f),
-                       gp(below_g), Cb, h, w, G.cat[l].H, G.cat[l].W, sy, sx, n);
+    if (!hs && (size_t)B * Cb <= 65535) {      // r6: LDS-window form (bit-identical; fp32 planar activations)
+      if (w >= 64)
+        hipLaunchKernelGGL(upsample_bwd_lds_kernel<64>, dim3((w + 63) / 64, (h + UBF_T - 1) / UBF_T, (unsigned)(B * Cb)), dim3(256), 0, s, gp(G.cat[l]),
+                           G.cat[l].C, F.x[l].C, static_cast<const float*>(sa(below_f).p), gp(below_g), Cb, h, w, G.cat[l].H, G.cat[l].W, sy, sx);
+      else
+        hipLaunchKernelGGL(upsample_bwd_lds_kernel<16>, dim3((w + 15) / 16, (h + UBF_T - 1) / UBF_T, (unsigned)(B * Cb)), dim3(256), 0, s, gp(G.cat[l]),
+                           G.cat[l].C, F.x[l].C, static_cast<const float*>(sa(below_f).p), gp(below_g), Cb, h, w, G.cat[l].H, G.cat[l].W, sy, sx);
+    } else {
+      hipLaunchKernelGGL(upsample_bwd_kernel, g1(n), dim3(256), 0, s, gp(G.cat[l]), G.cat[l].C, F.x[l].C, sa(below_f),
+                         gp(below_g), Cb, h, w, G.cat[l].H, G.cat[l].W, sy, sx, n);
+    }
     PNPX_LAUNCH_CHECK();
   }
   // 5. encoder blocks, bottom (level 4) to top
   for (int l = 4; l >= 0; --l) {
     if (l < 4) {   // gradient reaching x[l]: skip part of the decoder concat + max-pool routing from level l+1
       const size_t n = (size_t)B * F.x[l].C * F.x[l].H * F.x[l].W;
-      hipLaunchKernelGGL(skip_pool_merge_kernel, g1(n), dim3(256), 0, s, gp(G.cat[l]), G.cat[l].C, gp(G.p[l + 1]),
-                         sa(F.x[l]), gp(G.x[l]), F.x[l].C, F.x[l].H, F.x[l].W, n);
+      if (F.x[l].H % 2 == 0 && F.x[l].W % 2 == 0) {      // r6: one thread per max-pool window (bit-identical)
+        hipLaunchKernelGGL(skip_pool_merge_f32_kernel, g1(n / 4), dim3(256), 0, s, gp(G.cat[l]), G.cat[l].C, gp(G.p[l + 1]),
+                           static_cast<const float*>(sa(F.x[l]).p), gp(G.x[l]), F.x[l].C, F.x[l].H, F.x[l].W, n / 4);
+      } else {
+        hipLaunchKernelGGL(skip_pool_merge_kernel, g1(n), dim3(256), 0, s, gp(G.cat[l]), G.cat[l].C, gp(G.p[l + 1]),
+                           sa(F.x[l]), gp(G.x[l]), F.x[l].C, F.x[l].H, F.x[l].W, n);
+      }
       PNPX_LAUNCH_CHECK();
     }
     PNPX_TRY(convT(3 * l + 2, G.x[l], G.b[l], &F.b[l]));
