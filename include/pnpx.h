@@ -72,7 +72,8 @@ int pnpx_ctx_reserve(pnpx_ctx* ctx, int B, int H, int W);
  *      can split their input-channel chunks over 4 / 2 workgroups of the 8-wave kernel; the pieces' partial sums go to a scratch slab and
  *      a second small launch adds them in piece order (deterministic), then bias + activation.
  *      1 = in calls whose unsplit tiles cannot fill the chip (tiles per image x batch < 256: below 32 images of 256 x 256 at the
- *      16 x 16 level, below 16 at 32 x 32): -15 % per forward at B = 6, -9 % at 12, nothing changes from 32 images up.  A given image
+ *      16 x 16 level, below 16 at 32 x 32; the 32 x 32 decoder entry then runs unfused so that it splits too): -20 % per forward at B = 6,
+ *      -9 % at 12, nothing changes from 32 images up.  A given image
  *      gets the same bits in every call of the same class; across the class boundary results differ in the summation order
  *      (5e-7).  2 = split at every batch size: bit-identical per image across ALL batch sizes, +5 % at 48 x 256^2.  0 = never.
  *      "fp32_ksplit_rule" (tuning): pieces per tile class.

@@ -723,7 +723,13 @@ static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, con
     // chunk's halo staged in LDS, bilinear x2 into the halo buffer) -- no up-sampled tensor in HBM (models/unet.py:92-121)
     const int li0 = 15 + 3 * (3 - l);
     // (training forwards too: the VJP of the up-sampling is linear in the gradient and reads no up-sampled activation)
-    const bool ups_fused = ctx->opt_fp32_fuse_up && ctx->opt_fp32_winograd && ctx->conv_wino_u[li0] && ((ctx->opt_fp32_wino8 >> li0) & 1) &&
+    // r6: a decoder entry that the K-split would take in this call (the 32 x 32 level's 768 -> 256 entry when the call cannot fill the chip:
+    // its 48-chunk tiles are the longest of the forward) runs UNFUSED -- the separate up-sampling kernel + the plain two-source instance,
+    // which splits; the fused instance's interpolation pipeline assumes a tile starts in its first, full-resolution source.  (The two
+    // forms agree to 2-5e-7; like the K-split itself this is a property of the call's class, not of the batch.)
+    const bool entry_splits = ks_on(ctx->conv[li0].cout, 2 * h, 2 * w) &&
+                              conv3x3_wino8_ksplit(P.x[l].C, below->C, ctx->conv[li0].cout, 2 * h, 2 * w, ctx->opt_ksplit_rule) > 1;
+    const bool ups_fused = !entry_splits && ctx->opt_fp32_fuse_up && ctx->opt_fp32_winograd && ctx->conv_wino_u[li0] && ((ctx->opt_fp32_wino8 >> li0) & 1) &&
                            P.x[l].H == 2 * h && P.x[l].W == 2 * w && conv3x3_wino8_ups_ok(P.x[l].C, below->C, ctx->conv[li0].cout, 2 * h, 2 * w);
     if (ups_fused) {
       // nothing to launch
