@@ -1,4 +1,7 @@
-"""Per-iteration time of the PR / CT / SPI solver loops at the BASELINE config sizes, with the denoiser share."""
+"""Per-iteration time of the PR / CT / SPI solver loops at the BASELINE config sizes, with the denoiser share.
+(`prox+update` = iteration time minus a SEPARATELY timed denoiser forward at the same batch: both are wall-clock loops, so the difference
+carries +-0.15 ms of box noise and can come out negative for the 0.06-0.13 ms prox steps; the per-kernel times are in the counter table
+profiles/r*_tasks_pmc.md.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
