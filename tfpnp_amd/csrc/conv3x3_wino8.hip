@@ -861,7 +861,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32_kernel(WinoArgs a) {
 // A kernel boundary, not an in-kernel arrival protocol: the protocol (write-through sc1 slab stores, device-scope counter per (tile,
 // wave), last arriver sums) was built first and measured -- the returned atomic and the drained stores cost ~6 us per work item with
 // nothing to hide them behind (+19 % on the split layers at B = 48), and an agent-scope release fence instead (buffer_wbl2) ~60 us per
-// item under this kernel's output traffic (profiles/r6_ksplit.md).  The boundary costs ~2 us per split layer.
+// item under this kernel's output traffic.  The boundary costs ~2 us per split layer.
 __global__ __launch_bounds__(512) void wino8_ksplit_finish_kernel(WinoArgs a) {
   using C = Cfg8<64>;
   const int item = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -915,12 +915,12 @@ static int wino8_ct(int C0, int C1, int cout, int H, int W) {
 }
 bool conv3x3_wino8_ok(int C0, int C1, int cout, int H, int W) { return wino8_ct(C0, C1, cout, H, W) != 0; }
 
-// r6: which layers split their channel chunks over several work items, and into how many.  A rule of the LAYER'S geometry alone (never of
-// the batch): the summation tree of an output is then the same at every batch size, and per-image results stay bit-identical across
-// batch sizes, slices and launch chains.  t = tiles per image: <= 8 (the 16 x 16 level of a 256 x 256 input: one region x 8 cout tiles)
-// -> 4 pieces, <= 16 (32 x 32: four regions x 4) -> 2; every piece keeps >= 4 chunks.  At B = 48 this turns the 16 x 16 level's 384 tiles
-// on 256 workgroups (two rounds for 1.5 rounds of work) into 1536 quarter-tiles = 6 even rounds; at B = 6 it puts 192 instead of 48 / 96
-// workgroups on the chip.
+// r6: which layers CAN split their channel chunks over several work items, and into how many pieces.  A rule of the LAYER'S geometry alone
+// (never of the batch): whenever a layer splits, the summation tree of an output is the same, and per-image results are bit-identical across
+// batch sizes, slices and launch chains among the calls that split (unet.hip decides per call WHETHER the deep levels split: option
+// fp32_ksplit).  t = tiles per image: <= 8 (the 16 x 16 level of a 256 x 256 input: one region x 8 cout tiles) -> 4 pieces, <= 16
+// (32 x 32: four regions x 4) -> 2; every piece keeps >= 4 chunks.  At B = 6 this puts 192 instead of 48 / 96 workgroups on the chip
+// (measured per batch size in profiles/r6_ksplit.txt).
 // rule: 1 = the default (4 pieces up to 8 tiles per image, 2 up to 16); any other value (tuning) = pieces for t <= 8 in bits 0-3, for
 // t <= 16 in bits 4-7.
 int conv3x3_wino8_ksplit(int C0, int C1, int cout, int H, int W, int rule) {
