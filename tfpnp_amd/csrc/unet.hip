@@ -623,7 +623,7 @@ static int unet_forward_f32(pnpx_ctx* ctx, UNetArena& ar, const UNetPlan& P, con
   // r6: scratch of the K-split launches (this slice's images).  Option fp32_ksplit: 0 = never; 1 (default) = the layers whose unsplit
   // tiles cannot fill the chip for THIS call's batch (tiles per image x B_call < 256: launch chains beside each other count as one call);
   // 2 = every layer the geometry rule names, at every batch size (per-image results then bit-identical across ALL batch sizes; costs
-  // 4 % at 48 x 256^2, where the extra epilogues and the slab round trip buy nothing: profiles/r6_ksplit.md)
+  // 4 % at 48 x 256^2, where the extra epilogues and the slab round trip buy nothing: profiles/r6_ksplit.txt)
   float* const ks_part0 = reinterpret_cast<float*>(A + P.ks_part + (size_t)b_base * P.ks_part_per_image);
   auto ks_on = [&](int cout, int h, int w) {
     if (ctx->opt_fp32_ksplit == 2) return true;
